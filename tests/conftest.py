@@ -1,0 +1,37 @@
+import base64
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name)) as fh:
+        return json.load(fh)
+
+
+def case_payload(case):
+    return base64.b64decode(case["fastq_b64"])
+
+
+def write_case_file(case, directory):
+    """Materialise a golden case's FASTQ under its recorded file name."""
+    path = os.path.join(str(directory), case["filename"])
+    with open(path, "wb") as fh:
+        fh.write(case_payload(case))
+    return path
+
+
+@pytest.fixture(scope="session")
+def golden_cases():
+    return load_golden("hotpath_cases.json") + load_golden("hotpath_random.json")
