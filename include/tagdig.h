@@ -1,0 +1,149 @@
+/* libtagdig -- C-ABI of the MI355X tag-counting engine.
+ *
+ * Drop-in boundary for ONE path of lvclark/tagdigger: the per-read
+ * barcode-demux + known-tag count loop, tagdigger_fun.find_tags_fastq
+ * (reference tagdigger_fun.py:192-277) and the index primitives under it
+ * (:60-190).  The reference has no FFI of its own (it is pure Python); these
+ * are the entry points a ctypes binding of that function needs, and
+ * tagdigger_amd/_binding.py is that binding (INTEGRATION.md shows the stub a
+ * reference maintainer would add).
+ *
+ * Conventions: plain pointers and sizes only; every buffer is caller-owned
+ * unless said otherwise; functions return 0 on success or a negative TD_E_*
+ * code with a message available from td_last_error(); nothing here calls
+ * exit()/abort().  One handle drives one GPU; a handle is not thread-safe.
+ * There is NO CPU fallback: without a usable HIP device td_create fails.
+ */
+#ifndef TAGDIG_H
+#define TAGDIG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct td_handle td_handle;
+
+enum {
+    TD_OK = 0,
+    TD_E_HIP = -1,        /* a HIP runtime call failed                                   */
+    TD_E_ARG = -2,        /* bad argument (NULL, misaligned device pointer, ...)          */
+    TD_E_OVERLAP = -3,    /* index build: reference's AssertionError "Problematic
+                             sequence: {idx}" (tagdigger_fun.py:82); idx via td_last_bad_index */
+    TD_E_EMPTY = -4,      /* index build: empty barcode or tag list (IndexError, :76)     */
+    TD_E_ROOTLEAF = -5,   /* index build: first sequence empty, not the :109 special case;
+                             the reference dies at its first lookup       */
+    TD_E_ALPHABET = -6,   /* non-ACGT character in an index sequence (:198-204 asserts)   */
+    TD_E_LIMIT = -7,      /* beyond an implementation limit (barcode+site > 32 bases,
+                             tag > 320 bases, > 32767 barcode entries, ...)               */
+    TD_E_NONASCII = -8,   /* a counted sequence line holds a byte >= 0x80                 */
+    TD_E_STATE = -9,      /* call order (no index set, ...)                               */
+    TD_E_INTERNAL = -10,  /* look-back timeout or other should-not-happen condition       */
+    TD_E_IO = -11,        /* file could not be opened / read / inflated                   */
+    TD_E_TASSEL = -12     /* tassel_tagcount: header without a parsable count= value      */
+};
+
+/* stats[] slots filled by td_get_stats (all cumulative since td_reset) */
+enum {
+    TD_STAT_READS = 0,    /* readscount   of tagdigger_fun.py:246,255 */
+    TD_STAT_BARCUT = 1,   /* barcutcount  of :247,259                 */
+    TD_STAT_TAG = 2,      /* tagcount     of :248,263                 */
+    TD_STAT_LINES = 3,    /* line terminators seen                    */
+    TD_STAT_NSTATS = 8
+};
+
+const char *td_last_error(void);
+uint32_t td_last_bad_index(void);
+
+/* ---- lifetime ----------------------------------------------------------- */
+int td_create(td_handle **out, int device_id);
+void td_destroy(td_handle *h);
+
+/* ---- index: replaces build_sequence_tree x2 inside find_tags_fastq --------
+ * (tagdigger_fun.py:207-233).  The caller passes exactly the two string
+ * lists the reference hands to build_sequence_tree:
+ *   barcut[n_barcut]  upper-case barcode+cutsite strings, all cut-site
+ *                     variants concatenated as at :215-217; entry k belongs to
+ *                     barcode row k % barnum (:102-108)
+ *   tagoff[barnum]    barcutlen of :209/:231 -- where the tag search starts
+ *   tags[ntags]       upper-case tags after the strip decision of :222-231;
+ *                     tag k is count-matrix column k
+ * Duplicate / extension shadowing and the overlap assertion of :76-82 are
+ * reproduced (TD_E_OVERLAP).  The count matrix becomes barnum x ntags, zeroed. */
+int td_set_index(td_handle *h,
+                 const char *const *barcut, uint32_t n_barcut, uint32_t barnum,
+                 const uint32_t *tagoff,
+                 const char *const *tags, uint32_t ntags);
+
+/* Use caller-provided device memory (barnum*ntags uint32, zeroed by the
+ * caller) for the count matrix, e.g. a torch tensor that is later all-reduced
+ * over RCCL.  NULL returns to the internal buffer. */
+int td_bind_counts(td_handle *h, void *d_counts);
+
+/* Zero the count matrix, the statistics and the host-side accumulators. */
+int td_reset(td_handle *h);
+
+/* ---- the hot path: replaces the record loop of find_tags_fastq ------------
+ * (tagdigger_fun.py:249-274) on a buffer already resident in HBM.
+ *   d_fastq      device pointer, 16-byte aligned, nbytes bytes of FASTQ text
+ *                made of whole lines (the last line may lack a terminator)
+ *   first_line   global index of the buffer's first line (lineindex of :249)
+ *   max_reads    reads (sequence lines) with ordinal > max_reads are ignored;
+ *                pass max(1, ceil(maxreads)) for the semantics of :272-273
+ *   weights      0 for the plain +1 count (:267); 1 for tassel_tagcount
+ *                (:251-253,:264-265): header lines carry count=N
+ *   stream       hipStream_t to launch on (NULL = default stream)
+ * Asynchronous: returns once the work is enqueued. */
+int td_count_device(td_handle *h, const void *d_fastq, uint64_t nbytes,
+                    uint64_t first_line, uint64_t max_reads, int weights, void *stream);
+
+/* Same for a host buffer: staged through pinned memory in pieces cut at line
+ * ends, copies overlapped with counting.  Synchronous.  *lines_out (optional)
+ * receives the number of lines consumed. */
+int td_count_host(td_handle *h, const void *fastq, uint64_t nbytes,
+                  uint64_t first_line, uint64_t max_reads, int weights, uint64_t *lines_out);
+
+/* Whole file, plain or gzip (chosen by name as at :240: last two characters
+ * 'gz' in any case), streamed and inflated on the host.  Synchronous. */
+int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weights);
+
+/* Line terminators (\n, \r\n, bare \r) in a device buffer -- what a shard of a
+ * byte-split file must know about the shards before it.  Synchronous. */
+int td_count_lines_device(td_handle *h, const void *d_fastq, uint64_t nbytes,
+                          void *stream, uint64_t *terminators_out);
+
+/* ---- results ---------------------------------------------------------------
+ * Both synchronise with all work enqueued through this handle first and
+ * return TD_E_NONASCII / TD_E_INTERNAL if a kernel flagged a problem. */
+int td_get_counts(td_handle *h, uint64_t *out_rows_by_cols);   /* barnum*ntags, row-major */
+int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
+
+/* ---- tuning / introspection ------------------------------------------------ */
+/* name: "tile_kb" (16|32), "blocks_per_cu", "prescan" (0|1: two-pass line
+ * phase instead of in-kernel look-back).  Returns TD_E_ARG for unknown names. */
+int td_set_option(td_handle *h, const char *name, int64_t value);
+/* Average device time (ms) of the count kernel over the launches since the
+ * last call (HIP events on the launch stream); launches_out optional. */
+int td_kernel_time_ms(td_handle *h, double *ms_per_launch, uint32_t *launches_out);
+
+/* ---- device memory helpers (so a binding needs no other GPU runtime) ------- */
+int td_dev_alloc(td_handle *h, uint64_t nbytes, void **d_out);
+int td_dev_free(td_handle *h, void *d_ptr);
+int td_memcpy_h2d(td_handle *h, void *d_dst, const void *src, uint64_t nbytes);
+int td_memcpy_d2h(td_handle *h, void *dst, const void *d_src, uint64_t nbytes);
+int td_device_sync(td_handle *h);
+
+/* ---- bench/test utility: canonical synthetic FASTQ written straight into
+ * HBM (include/td_synth_spec.h).  Not on the counting path. */
+struct td_synth_params_s;
+int td_synth_fill_device(td_handle *h, const void *params /* td_synth_params* */,
+                         uint64_t first_read, uint64_t nreads,
+                         const char *bar_tab, const uint8_t *bar_len, const char *cut_tab,
+                         const char *tag_tab, const uint16_t *tag_len,
+                         void *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

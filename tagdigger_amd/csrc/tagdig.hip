@@ -1,0 +1,790 @@
+// Host side of libtagdig: handle, index builder, launches, streaming, C-ABI.
+// See include/tagdig.h for the contract and kernels.hpp for the device code.
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tagdig.h"
+#include "../../include/td_synth_spec.h"
+#include "kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+thread_local uint32_t g_bad = 0;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(TD_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+// base codes must match the device's (byte >> 1) & 3:  A 0, C 1, T 2, G 3
+inline int base_code(char c) {
+    switch (c) { case 'A': return 0; case 'C': return 1; case 'T': return 2; case 'G': return 3; default: return -1; }
+}
+// first base in the top bits of word 0
+void pack_bases(const std::string &s, uint64_t *words, int nwords) {
+    for (int w = 0; w < nwords; w++) words[w] = 0;
+    for (size_t i = 0; i < s.size(); i++)
+        words[i >> 5] |= (uint64_t)base_code(s[i]) << (62 - 2 * (i & 31));
+}
+inline uint32_t hash_key(uint64_t key) {   // must match tdk::hash_key
+    uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    uint32_t h = (lo * 0x9E3779B1u) ^ ((hi + 0x7F4A7C15u) * 0x85EBCA77u);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+    return h;
+}
+
+// ---------------------------------------------------------------------------
+// Shadowing / overlap rules of the reference's trie build (tagdigger_fun.py
+// :71-113), applied to a sorted array instead of a tree: at the node reached by
+// prefix P the group is every sequence starting with P, in input order.
+//   first member == P      -> it is stored, the rest of the group is dropped (:76-77)
+//   a later member == P    -> AssertionError with that member's index (:82)
+// survivors are prefix-free.  Index = input position mod numseq (:102-108).
+// ---------------------------------------------------------------------------
+struct Resolver {
+    const std::vector<std::string> &seqs;
+    uint32_t numseq;
+    std::vector<uint32_t> order;                             // sorted by (string, position)
+    std::vector<std::pair<std::string, uint32_t>> out;       // survivors: (sequence, index)
+    int err = TD_OK;
+    uint32_t bad = 0;
+
+    Resolver(const std::vector<std::string> &s, uint32_t n) : seqs(s), numseq(n) {}
+    uint32_t idx_of(uint32_t pos) const { return numseq ? pos % numseq : pos; }
+
+    void walk(size_t lo, size_t hi, size_t depth) {
+        if (err) return;
+        uint32_t first = order[lo];
+        for (size_t i = lo + 1; i < hi; i++) first = std::min(first, order[i]);
+        if (seqs[first].size() == depth) {
+            if (depth == 0) { err = TD_E_ROOTLEAF; return; }
+            out.emplace_back(seqs[first], idx_of(first));
+            return;
+        }
+        if (seqs[order[lo]].size() == depth) { err = TD_E_OVERLAP; bad = idx_of(order[lo]); return; }
+        size_t i = lo;
+        while (i < hi) {
+            char c = seqs[order[i]][depth];
+            size_t j = i + 1;
+            while (j < hi && seqs[order[j]][depth] == c) j++;
+            walk(i, j, depth + 1);
+            if (err) return;
+            i = j;
+        }
+    }
+    int run() {
+        if (seqs.empty()) return TD_E_EMPTY;
+        for (auto &s : seqs) for (char c : s) if (base_code(c) < 0) return TD_E_ALPHABET;
+        if (numseq == 1 && seqs.size() == 1 && seqs[0].empty()) {   // :109-110
+            for (const char *b : {"A", "C", "G", "T"}) out.emplace_back(b, 0u);
+            return TD_OK;
+        }
+        order.resize(seqs.size());
+        for (uint32_t i = 0; i < seqs.size(); i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            int c = seqs[a].compare(seqs[b]);
+            return c < 0 || (c == 0 && a < b);
+        });
+        walk(0, order.size(), 0);
+        return err;
+    }
+};
+
+template <typename T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    int ensure(size_t want) {
+        if (want <= n && p) return TD_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        HIPCHK(hipMalloc(&p, std::max<size_t>(want, 1) * sizeof(T)));
+        n = want;
+        return TD_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+constexpr int W_CHOICES[] = {1, 2, 3, 4, 6, 10};
+constexpr uint32_t MAX_SHORT = 16;
+constexpr size_t LDS_BUDGET = 64 * 1024;     // per workgroup
+
+}  // namespace
+
+struct td_handle {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t copy_stream = nullptr, work_stream = nullptr;
+    // index
+    bool have_index = false;
+    uint32_t barnum = 0, ntags = 0;
+    int W = 2;
+    uint32_t nch = 0, maxwo = 0, halo = 128, m_bases = 32, nshort = 0, slot_mask = 0;
+    uint32_t bblob_bytes = 0, off_bmeta = 0, off_bdir = 0, off_bcand = 0;
+    DevBuf<uint32_t> d_bblob;
+    DevBuf<uint4> d_slots, d_shorts;
+    // results
+    DevBuf<uint32_t> d_counts;
+    DevBuf<unsigned long long> d_counts64;
+    uint32_t *bound_counts = nullptr;
+    bool used64 = false;
+    DevBuf<unsigned long long> d_stats;       // TD_STAT_NSTATS
+    std::vector<uint64_t> host_acc;           // flushed counts
+    uint64_t bytes_since_flush = 0;
+    // launch state
+    DevBuf<uint64_t> d_state, d_tilecounts;
+    DevBuf<uint32_t> d_ticket;
+    DevBuf<unsigned long long> d_cursor;      // [2] line cursor for streamed pieces
+    // options
+    int tile_kb = 16, blocks_per_cu = 0, prescan = 0, timing = 0;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    const void *occ_fn = nullptr; size_t occ_lds = 0; int occ_val = 1;
+};
+
+namespace {
+
+using KFn = void (*)(const tdk::KParams);
+template <int CPT, bool TASSEL> KFn pick_w(int W) {
+    switch (W) {
+    case 1: return tdk::k_count<CPT, 1, TASSEL>;
+    case 2: return tdk::k_count<CPT, 2, TASSEL>;
+    case 3: return tdk::k_count<CPT, 3, TASSEL>;
+    case 4: return tdk::k_count<CPT, 4, TASSEL>;
+    case 6: return tdk::k_count<CPT, 6, TASSEL>;
+    default: return tdk::k_count<CPT, 10, TASSEL>;
+    }
+}
+KFn pick_kernel(int tile_kb, int W, bool tassel) {
+    if (tassel) return pick_w<4, true>(W);
+    return tile_kb == 32 ? pick_w<8, false>(W) : pick_w<4, false>(W);
+}
+
+size_t lds_bytes(const td_handle *h, int tile_kb) {
+    size_t tile = (size_t)tile_kb * 1024;
+    return tile + h->halo + tile / 16 * 2 + tdk::RLIST_CAP * 2 + 256 + h->bblob_bytes;
+}
+
+int zero_results(td_handle *h) {
+    if (h->d_counts.p) HIPCHK(hipMemsetAsync(h->d_counts.p, 0, (size_t)h->barnum * h->ntags * 4, h->work_stream));
+    if (h->d_counts64.p) HIPCHK(hipMemsetAsync(h->d_counts64.p, 0, (size_t)h->barnum * h->ntags * 8, h->work_stream));
+    HIPCHK(hipMemsetAsync(h->d_stats.p, 0, TD_STAT_NSTATS * 8, h->work_stream));
+    HIPCHK(hipStreamSynchronize(h->work_stream));
+    std::fill(h->host_acc.begin(), h->host_acc.end(), 0);
+    h->bytes_since_flush = 0;
+    h->used64 = false;
+    return TD_OK;
+}
+
+// move device uint32 counts into the host accumulator so cells cannot wrap
+int flush_counts(td_handle *h) {
+    if (h->bound_counts || !h->d_counts.p) return TD_OK;
+    size_t cells = (size_t)h->barnum * h->ntags;
+    std::vector<uint32_t> tmp(cells);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(tmp.data(), h->d_counts.p, cells * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_counts.p, 0, cells * 4));
+    if (h->host_acc.size() != cells) h->host_acc.assign(cells, 0);
+    for (size_t i = 0; i < cells; i++) h->host_acc[i] += tmp[i];
+    h->bytes_since_flush = 0;
+    return TD_OK;
+}
+
+// Enqueue one pass of the count kernel.  cursor_in/out (device, optional) carry
+// the line index between streamed pieces without a host round trip.
+int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, uint64_t max_reads,
+                 int weights, hipStream_t stream, const unsigned long long *cursor_in = nullptr,
+                 unsigned long long *cursor_out = nullptr) {
+    if (!h->have_index) return fail(TD_E_STATE, "td_set_index has not been called");
+    if (((uintptr_t)d_fastq & 15) != 0) return fail(TD_E_ARG, "device FASTQ pointer must be 16-byte aligned");
+    if (nbytes == 0) return TD_OK;
+    if (max_reads == 0) max_reads = 1;
+    const bool tassel = weights != 0;
+    const int tile_kb = tassel ? 16 : h->tile_kb;
+    const uint64_t tile = (uint64_t)tile_kb * 1024;
+    const uint64_t ntiles64 = (nbytes + tile - 1) / tile;
+    if (ntiles64 > 0x7FFFFFFFull) return fail(TD_E_LIMIT, "buffer too large for one launch; split it");
+    const uint32_t ntiles = (uint32_t)ntiles64;
+
+    if (!h->bound_counts && !tassel) {       // uint32 cells: a hit needs > 4 bytes of input
+        if ((h->bytes_since_flush + nbytes) / 4 >= 0xFFFFFFFFull) { int rc = flush_counts(h); if (rc) return rc; }
+        h->bytes_since_flush += nbytes;
+    }
+    if (tassel) {
+        if (!h->d_counts64.p) {
+            int rc = h->d_counts64.ensure((size_t)h->barnum * h->ntags); if (rc) return rc;
+            HIPCHK(hipMemsetAsync(h->d_counts64.p, 0, (size_t)h->barnum * h->ntags * 8, stream));
+        }
+        h->used64 = true;
+    }
+    { int rc = h->d_state.ensure(ntiles); if (rc) return rc; }
+
+    tdk::KParams p{};
+    p.buf = (const uint8_t *)d_fastq; p.nbytes = nbytes; p.first_line = first_line;
+    // last countable sequence line: ordinal r (1-based) sits on line 4(r-1)+1
+    p.limit_line = max_reads >= (1ull << 60) ? ~0ull - 8 : 4 * (max_reads - 1) + 1;
+    p.state = h->d_state.p; p.ticket = h->d_ticket.p; p.ntiles = ntiles; p.halo = h->halo;
+    p.bblob = h->d_bblob.p; p.bblob_bytes = h->bblob_bytes; p.off_bmeta = h->off_bmeta;
+    p.off_bdir = h->off_bdir; p.off_bcand = h->off_bcand;
+    p.slots = h->d_slots.p; p.slot_mask = h->slot_mask; p.m_bases = h->m_bases;
+    p.shorts = h->d_shorts.p; p.nshort = h->nshort;
+    p.counts = h->bound_counts ? h->bound_counts : h->d_counts.p; p.counts64 = h->d_counts64.p;
+    p.ncols = h->ntags; p.stats = h->d_stats.p; p.nch = h->nch; p.maxwo = h->maxwo;
+    p.prefilled = h->prescan ? 1u : 0u;
+    p.cursor_in = cursor_in; p.cursor_out = cursor_out;
+
+    HIPCHK(hipMemsetAsync(h->d_ticket.p, 0, 4, stream));
+    if (h->prescan) {
+        int rc = h->d_tilecounts.ensure(ntiles); if (rc) return rc;
+        uint32_t g = std::min<uint32_t>(ntiles, (uint32_t)h->num_cu * 8);
+        if (tile_kb == 32) hipLaunchKernelGGL((tdk::k_count_lines<8>), dim3(g), dim3(tdk::BLOCK), 0, stream, p.buf, nbytes, ntiles, h->d_tilecounts.p);
+        else hipLaunchKernelGGL((tdk::k_count_lines<4>), dim3(g), dim3(tdk::BLOCK), 0, stream, p.buf, nbytes, ntiles, h->d_tilecounts.p);
+        hipLaunchKernelGGL(tdk::k_scan_tiles, dim3(1), dim3(1024), 0, stream, h->d_tilecounts.p, ntiles, h->d_state.p, (unsigned long long *)nullptr);
+    } else {
+        HIPCHK(hipMemsetAsync(h->d_state.p, 0, (size_t)ntiles * 8, stream));
+    }
+
+    KFn fn = pick_kernel(tile_kb, h->W, tassel);
+    const size_t lds = lds_bytes(h, tile_kb);
+    if (lds > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int bpc = h->blocks_per_cu;
+    if (bpc <= 0) {
+        if (h->occ_fn != (const void *)fn || h->occ_lds != lds) {
+            int occ = 0;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, tdk::BLOCK, lds));
+            h->occ_fn = (const void *)fn; h->occ_lds = lds; h->occ_val = std::max(1, occ);
+        }
+        bpc = h->occ_val;
+    }
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)h->num_cu * bpc);
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing) {
+        if (h->ev_used == h->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+            h->ev_pool.emplace_back(a, b);
+        }
+        e0 = h->ev_pool[h->ev_used].first; e1 = h->ev_pool[h->ev_used].second; h->ev_used++;
+        HIPCHK(hipEventRecord(e0, stream));
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(tdk::BLOCK), lds, stream, p);
+    HIPCHK(hipGetLastError());
+    if (h->timing) HIPCHK(hipEventRecord(e1, stream));
+    return TD_OK;
+}
+
+int check_device_errors(td_handle *h, const unsigned long long *st) {
+    unsigned long long e = st[tdk::ST_ERR];
+    if (e & tdk::ERR_SPIN) return fail(TD_E_INTERNAL, "look-back wait timed out inside the count kernel");
+    if (e & tdk::ERR_NONASCII) return fail(TD_E_NONASCII, "non-ASCII byte in a sequence line");
+    if (e & tdk::ERR_TASSEL) return fail(TD_E_TASSEL, "invalid literal for int() with base 10 (count= header)");
+    (void)h;
+    return TD_OK;
+}
+
+}  // namespace
+
+// ============================================================================ C-ABI
+extern "C" {
+
+const char *td_last_error(void) { return g_err.c_str(); }
+uint32_t td_last_bad_index(void) { return g_bad; }
+
+int td_create(td_handle **out, int device_id) {
+    if (!out) return fail(TD_E_ARG, "out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(TD_E_HIP, "no usable HIP device (libtagdig has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail(TD_E_ARG, "device_id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    td_handle *h = new td_handle();
+    h->device = device_id;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->work_stream, hipStreamNonBlocking));
+    int rc = h->d_stats.ensure(TD_STAT_NSTATS); if (rc) { delete h; return rc; }
+    rc = h->d_ticket.ensure(4); if (rc) { delete h; return rc; }
+    rc = h->d_cursor.ensure(2); if (rc) { delete h; return rc; }
+    HIPCHK(hipMemset(h->d_stats.p, 0, TD_STAT_NSTATS * 8));
+    *out = h;
+    return TD_OK;
+}
+
+void td_destroy(td_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
+    h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
+    h->d_ticket.release(); h->d_cursor.release();
+    for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->work_stream) (void)hipStreamDestroy(h->work_stream);
+    delete h;
+}
+
+int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uint32_t barnum,
+                 const uint32_t *tagoff, const char *const *tags, uint32_t ntags) {
+    if (!h) return fail(TD_E_ARG, "handle is NULL");
+    HIPCHK(hipSetDevice(h->device));
+    h->have_index = false;
+    std::vector<std::string> bs(n_barcut), ts(ntags);
+    for (uint32_t i = 0; i < n_barcut; i++) bs[i] = barcut[i];
+    for (uint32_t i = 0; i < ntags; i++) ts[i] = tags[i];
+
+    Resolver rb(bs, barnum);
+    int rc = rb.run();
+    if (rc) { g_bad = rb.bad; return fail(rc, rc == TD_E_OVERLAP ? "overlapping barcode+cutsite sequences" : "barcode index build failed"); }
+    Resolver rt(ts, ntags);
+    rc = rt.run();
+    if (rc) { g_bad = rt.bad; return fail(rc, rc == TD_E_OVERLAP ? "overlapping tags" : "tag index build failed"); }
+
+    // ---- barcode blob: bval u64[n] | bmeta u32[n] | bdir u16[1024] | bcand u16[ncand]
+    const size_t nb = rb.out.size();
+    if (nb > 32767) return fail(TD_E_LIMIT, "more than 32767 barcode+cutsite entries");
+    if (barnum > 65535) return fail(TD_E_LIMIT, "more than 65535 barcodes");
+    uint32_t max_off = 0;
+    std::vector<uint64_t> bval(nb);
+    std::vector<uint32_t> bmeta(nb);
+    std::vector<std::vector<uint16_t>> buckets(tdk::BDIR_SIZE);
+    for (size_t e = 0; e < nb; e++) {
+        const std::string &s = rb.out[e].first;
+        const uint32_t row = rb.out[e].second;
+        if (s.size() > 32) return fail(TD_E_LIMIT, "barcode+cutsite longer than 32 bases");
+        const uint32_t off = tagoff[row];
+        if (off > 1023) return fail(TD_E_LIMIT, "tag offset beyond 1023 bases");
+        max_off = std::max(max_off, off);
+        pack_bases(s, &bval[e], 1);
+        bmeta[e] = (uint32_t)s.size() | (off << 6) | (row << 16);
+        const uint32_t L = (uint32_t)s.size();
+        const uint32_t base = (uint32_t)(bval[e] >> (64 - 2 * tdk::BDIR_BASES));
+        const uint32_t span = L >= tdk::BDIR_BASES ? 1u : 1u << (2 * (tdk::BDIR_BASES - L));
+        for (uint32_t k = 0; k < span; k++) buckets[base + k].push_back((uint16_t)e);
+    }
+    std::vector<uint16_t> bdir(tdk::BDIR_SIZE, 0xFFFF), bcand;
+    for (uint32_t b = 0; b < tdk::BDIR_SIZE; b++) {
+        if (buckets[b].empty()) continue;
+        if (bcand.size() + buckets[b].size() > 65534) return fail(TD_E_LIMIT, "barcode directory too large");
+        bdir[b] = (uint16_t)bcand.size();
+        for (size_t k = 0; k < buckets[b].size(); k++)
+            bcand.push_back(buckets[b][k] | (k + 1 == buckets[b].size() ? 0x8000u : 0u));
+    }
+    if (bcand.size() & 1) bcand.push_back(0x8000);
+    h->off_bmeta = (uint32_t)(nb * 8);
+    h->off_bdir = h->off_bmeta + (uint32_t)((nb * 4 + 7) / 8 * 8);
+    h->off_bcand = h->off_bdir + tdk::BDIR_SIZE * 2;
+    h->bblob_bytes = (h->off_bcand + (uint32_t)bcand.size() * 2 + 15) / 16 * 16;
+    std::vector<uint8_t> blob(h->bblob_bytes, 0);
+    memcpy(blob.data(), bval.data(), nb * 8);
+    memcpy(blob.data() + h->off_bmeta, bmeta.data(), nb * 4);
+    memcpy(blob.data() + h->off_bdir, bdir.data(), tdk::BDIR_SIZE * 2);
+    memcpy(blob.data() + h->off_bcand, bcand.data(), bcand.size() * 2);
+
+    // ---- tag table
+    size_t maxlen = 0;
+    std::vector<uint32_t> lens;
+    for (auto &t : rt.out) { maxlen = std::max(maxlen, t.first.size()); lens.push_back((uint32_t)t.first.size()); }
+    int W = 0;
+    for (int w : W_CHOICES) if ((size_t)w * 32 >= maxlen) { W = w; break; }
+    if (!W) return fail(TD_E_LIMIT, "tag longer than 320 bases");
+    std::sort(lens.begin(), lens.end());
+    uint32_t m = 32;
+    if (lens.size() > MAX_SHORT) m = std::min<uint32_t>(32, lens[MAX_SHORT]);
+    m = std::max<uint32_t>(m, 1);
+    const int slot_u4 = (W + 2) / 2;
+    size_t nslots = 16;
+    while (nslots < 2 * rt.out.size()) nslots <<= 1;
+    std::vector<uint32_t> slots(nslots * slot_u4 * 4, 0);
+    std::vector<uint32_t> shorts;
+    std::vector<uint64_t> words(W);
+    for (auto &t : rt.out) {
+        const uint32_t L = (uint32_t)t.first.size();
+        pack_bases(t.first, words.data(), W);
+        if (L < m) {
+            shorts.push_back((uint32_t)words[0]); shorts.push_back((uint32_t)(words[0] >> 32));
+            shorts.push_back(L); shorts.push_back(t.second);
+            continue;
+        }
+        size_t s = hash_key(words[0] >> (64 - 2 * m)) & (nslots - 1);
+        while (slots[s * slot_u4 * 4 + 2 * W] != 0) s = (s + 1) & (nslots - 1);
+        uint32_t *sp = &slots[s * slot_u4 * 4];
+        for (int w = 0; w < W; w++) { sp[2 * w] = (uint32_t)words[w]; sp[2 * w + 1] = (uint32_t)(words[w] >> 32); }
+        sp[2 * W] = L; sp[2 * W + 1] = t.second;
+    }
+    h->W = W; h->m_bases = m; h->slot_mask = (uint32_t)(nslots - 1); h->nshort = (uint32_t)(shorts.size() / 4);
+    h->maxwo = max_off >> 4;
+    const uint32_t need = 15 + max_off + (uint32_t)maxlen;
+    h->nch = std::min<uint32_t>(2 * W + 3, std::max<uint32_t>(3, (need + 15) / 16));
+    h->halo = (h->nch * 16 + 63) / 64 * 64;
+    h->barnum = barnum; h->ntags = ntags;
+    if (lds_bytes(h, 16) > LDS_BUDGET) return fail(TD_E_LIMIT, "barcode index does not fit the LDS budget");
+    if (lds_bytes(h, h->tile_kb) > LDS_BUDGET) h->tile_kb = 16;
+
+    rc = h->d_bblob.ensure(h->bblob_bytes / 4); if (rc) return rc;
+    HIPCHK(hipMemcpy(h->d_bblob.p, blob.data(), h->bblob_bytes, hipMemcpyHostToDevice));
+    rc = h->d_slots.ensure(nslots * slot_u4); if (rc) return rc;
+    HIPCHK(hipMemcpy(h->d_slots.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+    rc = h->d_shorts.ensure(std::max<size_t>(1, shorts.size() / 4)); if (rc) return rc;
+    if (!shorts.empty()) HIPCHK(hipMemcpy(h->d_shorts.p, shorts.data(), shorts.size() * 4, hipMemcpyHostToDevice));
+    h->d_counts64.release();
+    if (!h->bound_counts) { rc = h->d_counts.ensure((size_t)barnum * ntags); if (rc) return rc; }
+    h->host_acc.assign((size_t)barnum * ntags, 0);
+    h->have_index = true;
+    return zero_results(h);
+}
+
+int td_bind_counts(td_handle *h, void *d_counts) {
+    if (!h) return fail(TD_E_ARG, "handle is NULL");
+    h->bound_counts = (uint32_t *)d_counts;
+    if (!d_counts && h->have_index) { int rc = h->d_counts.ensure((size_t)h->barnum * h->ntags); if (rc) return rc; return zero_results(h); }
+    return TD_OK;
+}
+
+int td_reset(td_handle *h) {
+    if (!h) return fail(TD_E_ARG, "handle is NULL");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    return zero_results(h);
+}
+
+int td_count_device(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, uint64_t max_reads,
+                    int weights, void *stream) {
+    if (!h) return fail(TD_E_ARG, "handle is NULL");
+    HIPCHK(hipSetDevice(h->device));
+    return launch_count(h, d_fastq, nbytes, first_line, max_reads, weights, (hipStream_t)stream);
+}
+
+int td_count_lines_device(td_handle *h, const void *d_fastq, uint64_t nbytes, void *stream, uint64_t *out) {
+    if (!h || !out) return fail(TD_E_ARG, "NULL argument");
+    if (((uintptr_t)d_fastq & 15) != 0) return fail(TD_E_ARG, "device FASTQ pointer must be 16-byte aligned");
+    HIPCHK(hipSetDevice(h->device));
+    *out = 0;
+    if (nbytes == 0) return TD_OK;
+    const uint64_t tile = 16 * 1024;
+    const uint64_t nt = (nbytes + tile - 1) / tile;
+    if (nt > 0x7FFFFFFFull) return fail(TD_E_LIMIT, "buffer too large for one launch; split it");
+    int rc = h->d_tilecounts.ensure(nt); if (rc) return rc;
+    rc = h->d_state.ensure(nt); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t g = (uint32_t)std::min<uint64_t>(nt, (uint64_t)h->num_cu * 8);
+    hipLaunchKernelGGL((tdk::k_count_lines<4>), dim3(g), dim3(tdk::BLOCK), 0, s, (const uint8_t *)d_fastq, nbytes, (uint32_t)nt, h->d_tilecounts.p);
+    hipLaunchKernelGGL(tdk::k_scan_tiles, dim3(1), dim3(1024), 0, s, h->d_tilecounts.p, (uint32_t)nt, h->d_state.p, h->d_cursor.p);
+    HIPCHK(hipGetLastError());
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->d_cursor.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *out = v;
+    return TD_OK;
+}
+
+}  // extern "C"
+
+// ---- host buffers and files: pieces cut at line ends, staged through pinned memory
+namespace {
+struct Stager {
+    td_handle *h = nullptr;
+    static constexpr int NB = 3;
+    size_t cap = 0;
+    uint8_t *pin[NB] = {nullptr, nullptr, nullptr};
+    uint8_t *dev[NB] = {nullptr, nullptr, nullptr};
+    hipEvent_t copied[NB] = {nullptr, nullptr, nullptr};  // H2D of buffer i landed
+    hipEvent_t done[NB] = {nullptr, nullptr, nullptr};    // kernel on buffer i finished
+    bool busy[NB] = {false, false, false};
+    int cur = 0;
+    uint64_t first_line = 0;
+    unsigned pieces = 0;
+    int init(td_handle *hh, size_t capacity, uint64_t first) {
+        h = hh; cap = capacity; first_line = first;
+        for (int i = 0; i < NB; i++) {
+            HIPCHK(hipHostMalloc((void **)&pin[i], cap, hipHostMallocDefault));
+            HIPCHK(hipMalloc((void **)&dev[i], cap));
+            HIPCHK(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        }
+        HIPCHK(hipMemsetAsync(h->d_cursor.p, 0, 16, h->work_stream));
+        return TD_OK;
+    }
+    ~Stager() {
+        for (int i = 0; i < NB; i++) {
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            if (dev[i]) (void)hipFree(dev[i]);
+            if (copied[i]) (void)hipEventDestroy(copied[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+        }
+    }
+    // buffer to fill next (waits until its previous use has drained)
+    int acquire(uint8_t **p) {
+        if (busy[cur]) { HIPCHK(hipEventSynchronize(done[cur])); busy[cur] = false; }
+        *p = pin[cur];
+        return TD_OK;
+    }
+    // copy on the copy stream, count on the work stream; the line index travels
+    // from piece to piece through d_cursor[pieces & 1] on the device
+    int submit(size_t n, uint64_t max_reads, int weights) {
+        if (n == 0) return TD_OK;
+        HIPCHK(hipMemcpyAsync(dev[cur], pin[cur], n, hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(hipEventRecord(copied[cur], h->copy_stream));
+        HIPCHK(hipStreamWaitEvent(h->work_stream, copied[cur], 0));
+        int rc = launch_count(h, dev[cur], n, first_line, max_reads, weights, h->work_stream,
+                              h->d_cursor.p + (pieces & 1), h->d_cursor.p + ((pieces + 1) & 1));
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(done[cur], h->work_stream));
+        busy[cur] = true;
+        pieces++;
+        cur = (cur + 1) % NB;
+        return TD_OK;
+    }
+    int finish(uint64_t *lines) {
+        unsigned long long v = 0;
+        HIPCHK(hipMemcpyAsync(&v, h->d_cursor.p + (pieces & 1), 8, hipMemcpyDeviceToHost, h->work_stream));
+        HIPCHK(hipStreamSynchronize(h->work_stream));
+        HIPCHK(hipStreamSynchronize(h->copy_stream));
+        if (lines) *lines = v;
+        return TD_OK;
+    }
+};
+
+// index just past the last complete line terminator of p[0..n); 0 if none.
+// A trailing '\r' is not trusted (its '\n' may be in the next piece).
+size_t cut_at_line_end(const uint8_t *p, size_t n) {
+    size_t i = n;
+    if (i > 0 && p[i - 1] == '\r') i--;
+    while (i > 0) {
+        if (p[i - 1] == '\n' || p[i - 1] == '\r') return i;
+        i--;
+    }
+    return 0;
+}
+
+// generic pump: `reader(dst, want)` returns bytes produced (0 at end, <0 on error)
+template <typename Reader>
+int pump(td_handle *h, Reader &&reader, uint64_t size_hint, uint64_t first_line, uint64_t max_reads, int weights,
+         uint64_t *lines_out) {
+    Stager st;
+    size_t cap = (size_t)32 << 20;
+    if (size_hint && size_hint < cap) cap = std::max<size_t>(1 << 16, (size_hint + 4095) / 4096 * 4096);
+    int rc = st.init(h, cap, first_line); if (rc) return rc;
+    std::vector<uint8_t> carry;
+    bool eof = false;
+    while (!eof) {
+        uint8_t *buf; rc = st.acquire(&buf); if (rc) return rc;
+        size_t have = carry.size();
+        if (have) memcpy(buf, carry.data(), have);
+        carry.clear();
+        while (have < cap) {
+            long got = reader(buf + have, cap - have);
+            if (got < 0) return fail(TD_E_IO, "read error while streaming FASTQ");
+            if (got == 0) { eof = true; break; }
+            have += (size_t)got;
+        }
+        size_t cut = have;
+        if (!eof) {
+            cut = cut_at_line_end(buf, have);
+            if (cut == 0) return fail(TD_E_LIMIT, "a single line exceeds the staging buffer");
+            carry.assign(buf + cut, buf + have);
+        }
+        rc = st.submit(cut, max_reads, weights); if (rc) return rc;
+    }
+    return st.finish(lines_out);
+}
+}  // namespace
+
+extern "C" {
+
+int td_count_host(td_handle *h, const void *fastq, uint64_t nbytes, uint64_t first_line, uint64_t max_reads,
+                  int weights, uint64_t *lines_out) {
+    if (!h) return fail(TD_E_ARG, "handle is NULL");
+    if (!h->have_index) return fail(TD_E_STATE, "td_set_index has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    const uint8_t *src = (const uint8_t *)fastq;
+    uint64_t pos = 0;
+    auto reader = [&](uint8_t *dst, size_t want) -> long {
+        size_t n = (size_t)std::min<uint64_t>(want, nbytes - pos);
+        if (n) memcpy(dst, src + pos, n);
+        pos += n;
+        return (long)n;
+    };
+    return pump(h, reader, nbytes + 1, first_line, max_reads, weights, lines_out);
+}
+
+int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weights) {
+    if (!h || !path) return fail(TD_E_ARG, "NULL argument");
+    if (!h->have_index) return fail(TD_E_STATE, "td_set_index has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t len = strlen(path);
+    const bool gz = len >= 2 && (path[len - 2] == 'g' || path[len - 2] == 'G') && (path[len - 1] == 'z' || path[len - 1] == 'Z');
+    if (gz) {
+        gzFile f = gzopen(path, "rb");
+        if (!f) return fail(TD_E_IO, std::string("cannot open ") + path);
+        gzbuffer(f, 1 << 20);
+        auto reader = [&](uint8_t *dst, size_t want) -> long {
+            int n = gzread(f, dst, (unsigned)std::min<size_t>(want, 1u << 30));
+            return n;
+        };
+        int rc = pump(h, reader, 0, 0, max_reads, weights, nullptr);
+        gzclose(f);
+        return rc;
+    }
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(TD_E_IO, std::string("cannot open ") + path);
+    auto reader = [&](uint8_t *dst, size_t want) -> long {
+        size_t n = fread(dst, 1, want, f);
+        if (n == 0 && ferror(f)) return -1;
+        return (long)n;
+    };
+    int rc = pump(h, reader, 0, 0, max_reads, weights, nullptr);
+    fclose(f);
+    return rc;
+}
+
+int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]) {
+    if (!h || !stats) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long st[TD_STAT_NSTATS];
+    HIPCHK(hipMemcpy(st, h->d_stats.p, sizeof(st), hipMemcpyDeviceToHost));
+    for (int i = 0; i < TD_STAT_NSTATS; i++) stats[i] = st[i];
+    return check_device_errors(h, st);
+}
+
+int td_get_counts(td_handle *h, uint64_t *out) {
+    if (!h || !out) return fail(TD_E_ARG, "NULL argument");
+    if (!h->have_index) return fail(TD_E_STATE, "td_set_index has not been called");
+    uint64_t st[TD_STAT_NSTATS];
+    int rc = td_get_stats(h, st);
+    if (rc) return rc;
+    const size_t cells = (size_t)h->barnum * h->ntags;
+    std::vector<uint32_t> tmp(cells);
+    const uint32_t *src = h->bound_counts ? h->bound_counts : h->d_counts.p;
+    HIPCHK(hipMemcpy(tmp.data(), src, cells * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < cells; i++) out[i] = (uint64_t)tmp[i] + (h->host_acc.size() == cells ? h->host_acc[i] : 0);
+    if (h->used64 && h->d_counts64.p) {
+        std::vector<unsigned long long> t64(cells);
+        HIPCHK(hipMemcpy(t64.data(), h->d_counts64.p, cells * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cells; i++) out[i] += t64[i];
+    }
+    return TD_OK;
+}
+
+int td_set_option(td_handle *h, const char *name, int64_t value) {
+    if (!h || !name) return fail(TD_E_ARG, "NULL argument");
+    std::string n(name);
+    if (n == "tile_kb") {
+        if (value != 16 && value != 32) return fail(TD_E_ARG, "tile_kb must be 16 or 32");
+        if (h->have_index && lds_bytes(h, (int)value) > LDS_BUDGET) return fail(TD_E_LIMIT, "tile does not fit the LDS budget with this index");
+        h->tile_kb = (int)value;
+    } else if (n == "blocks_per_cu") h->blocks_per_cu = (int)value;
+    else if (n == "prescan") h->prescan = value ? 1 : 0;
+    else if (n == "timing") h->timing = value ? 1 : 0;
+    else return fail(TD_E_ARG, "unknown option " + n);
+    return TD_OK;
+}
+
+int td_kernel_time_ms(td_handle *h, double *ms, uint32_t *launches) {
+    if (!h || !ms) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    double tot = 0;
+    for (size_t i = 0; i < h->ev_used; i++) {
+        HIPCHK(hipEventSynchronize(h->ev_pool[i].second));
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, h->ev_pool[i].first, h->ev_pool[i].second));
+        tot += t;
+    }
+    *ms = h->ev_used ? tot / (double)h->ev_used : 0.0;
+    if (launches) *launches = (uint32_t)h->ev_used;
+    h->ev_used = 0;
+    return TD_OK;
+}
+
+int td_dev_alloc(td_handle *h, uint64_t nbytes, void **out) {
+    if (!h || !out) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMalloc(out, std::max<uint64_t>(nbytes, 16)));
+    return TD_OK;
+}
+int td_dev_free(td_handle *h, void *p) {
+    if (!h) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (p) HIPCHK(hipFree(p));
+    return TD_OK;
+}
+int td_memcpy_h2d(td_handle *h, void *dst, const void *src, uint64_t n) {
+    if (!h) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (n) HIPCHK(hipMemcpy(dst, src, n, hipMemcpyHostToDevice));
+    return TD_OK;
+}
+int td_memcpy_d2h(td_handle *h, void *dst, const void *src, uint64_t n) {
+    if (!h) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (n) HIPCHK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+    return TD_OK;
+}
+int td_device_sync(td_handle *h) {
+    if (!h) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    return TD_OK;
+}
+
+}  // extern "C"
+
+// ---- synthetic FASTQ generator (bench / tests only)
+namespace {
+__global__ void k_synth(td_synth_params P, uint64_t first_read, uint64_t nreads, const char *bar_tab,
+                        const uint8_t *bar_len, const char *cut_tab, const char *tag_tab,
+                        const uint16_t *tag_len, uint8_t *out) {
+    const uint64_t rb = td_synth_record_bytes(P.read_len);
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (uint64_t)gridDim.x * blockDim.x)
+        td_synth_record(&P, first_read + r, bar_tab, bar_len, cut_tab, tag_tab, tag_len, out + r * rb);
+}
+}  // namespace
+
+extern "C" {
+
+int td_synth_fill_device(td_handle *h, const void *params, uint64_t first_read, uint64_t nreads,
+                         const char *bar_tab, const uint8_t *bar_len, const char *cut_tab,
+                         const char *tag_tab, const uint16_t *tag_len, void *d_out, void *stream) {
+    if (!h || !params || !d_out) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    td_synth_params P = *(const td_synth_params *)params;
+    hipStream_t s = (hipStream_t)stream;
+    char *d_bar = nullptr, *d_cut = nullptr, *d_tag = nullptr; uint8_t *d_bl = nullptr; uint16_t *d_tl = nullptr;
+    HIPCHK(hipMalloc((void **)&d_bar, (size_t)P.nbar * TD_SYNTH_BAR_STRIDE));
+    HIPCHK(hipMalloc((void **)&d_bl, P.nbar));
+    HIPCHK(hipMalloc((void **)&d_cut, (size_t)P.ncut * TD_SYNTH_CUT_STRIDE));
+    HIPCHK(hipMalloc((void **)&d_tag, (size_t)P.ntags * P.tag_stride));
+    HIPCHK(hipMalloc((void **)&d_tl, (size_t)P.ntags * 2));
+    HIPCHK(hipMemcpy(d_bar, bar_tab, (size_t)P.nbar * TD_SYNTH_BAR_STRIDE, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_bl, bar_len, P.nbar, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_cut, cut_tab, (size_t)P.ncut * TD_SYNTH_CUT_STRIDE, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tag, tag_tab, (size_t)P.ntags * P.tag_stride, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tl, tag_len, (size_t)P.ntags * 2, hipMemcpyHostToDevice));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((nreads + 255) / 256, (uint64_t)h->num_cu * 32);
+    if (nreads) hipLaunchKernelGGL(k_synth, dim3(grid), dim3(256), 0, s, P, first_read, nreads, d_bar, d_bl, d_cut, d_tag, d_tl, (uint8_t *)d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    (void)hipFree(d_bar); (void)hipFree(d_bl); (void)hipFree(d_cut); (void)hipFree(d_tag); (void)hipFree(d_tl);
+    return TD_OK;
+}
+
+}  // extern "C"

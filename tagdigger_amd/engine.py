@@ -1,0 +1,220 @@
+"""Host-side driver of the MI355X tag counter: one Engine = one GPU handle.
+
+Mirrors the set-up half of the reference's find_tags_fastq
+(tagdigger_fun.py:197-233) in Python -- asserts, cut-site enumeration,
+barcode+cutsite list, strip-or-shift decision -- and hands the two string
+lists to libtagdig (td_set_index), which builds the flat device index.  The
+record loop (:239-277) runs on the GPU.
+"""
+import ctypes as C
+import gzip
+import math
+
+from . import _binding as B
+
+# IUPAC codes in the order the reference expands them (tagdigger_fun.py:140-189)
+_IUPAC = (("R", "AG"), ("Y", "CT"), ("K", "GT"), ("M", "AC"), ("S", "CG"), ("W", "AT"),
+          ("B", "CGT"), ("D", "AGT"), ("H", "ACT"), ("V", "ACG"), ("N", "ACGT"))
+
+
+def enumerate_cut_sites(cutsite):
+    """All concrete cut sites of an IUPAC cut site, in the reference's order
+    (tagdigger_fun.py:136-190): codes are expanded one kind at a time, leftmost
+    occurrence first, the new lists concatenated per replacement base."""
+    out = [cutsite]
+    for code, bases in _IUPAC:
+        while out[0].find(code) > -1:
+            nxt = []
+            for b in bases:
+                nxt.extend(x.replace(code, b, 1) for x in out)
+            out = nxt
+    return out
+
+
+def combine_barcode_and_cutsite(barcodes, cutsite):
+    """(barcode + cutsite).upper() per barcode (tagdigger_fun.py:60-69)."""
+    assert all([set(barcode.upper()) <= set('ACGT') for barcode in barcodes]), "Non-ACGT barcode."
+    assert set(cutsite.upper()) <= set('ACGT'), "Invalid cut site."
+    return [(barcode + cutsite).upper() for barcode in barcodes]
+
+
+def effective_maxreads(maxreads):
+    """The reference tests `readscount >= maxreads` after each read
+    (tagdigger_fun.py:272-273): one read is always processed and a fractional
+    bound rounds up."""
+    if maxreads >= 2 ** 62:
+        return 2 ** 62
+    return max(1, int(math.ceil(maxreads)))
+
+
+def _c_strings(strings):
+    arr = (C.c_char_p * max(1, len(strings)))()
+    for i, s in enumerate(strings):
+        arr[i] = s.encode("ascii")
+    return arr
+
+
+class Engine:
+    """Owns a td_handle on one GPU."""
+
+    def __init__(self, device=0):
+        self._L = B.load()
+        h = C.c_void_p()
+        B.check(self._L.td_create(C.byref(h), int(device)))
+        self._h = h
+        self.device = device
+        self.barnum = 0
+        self.ntags = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.td_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ index
+    def set_index(self, barcodes, tags, cutsite="TGCAG"):
+        """Set-up of find_tags_fastq, tagdigger_fun.py:197-233."""
+        assert all([set(barcode.upper()) <= set('ACGT') for barcode in barcodes]), "Non-ACGT barcode."
+        cutsite = cutsite.upper()
+        assert set(cutsite) <= set('ACGTNRYKMSWBDHV'), "Invalid cut site."
+        tags = [tag.upper() for tag in tags]
+        assert all([set(tag) <= set('ACGT') for tag in tags]), "Non-ACGT tag."
+        cutlen = len(cutsite)
+        barcutlen = [len(x) + cutlen for x in barcodes]
+        barnum = len(barcodes)
+        cutsites = enumerate_cut_sites(cutsite)
+        barcut = []
+        for cut in cutsites:
+            barcut += combine_barcode_and_cutsite(barcodes, cut)
+        if set(x[:cutlen] for x in tags).issubset(set(cutsites)):
+            if len(cutsites) == 1:
+                tags = [x[cutlen:] for x in tags]          # site already checked with the barcode
+            else:
+                barcutlen = [x - cutlen for x in barcutlen]  # tags keep the (variable) site
+        off = (C.c_uint32 * max(1, barnum))(*barcutlen)
+        B.check(self._L.td_set_index(self._h, _c_strings(barcut), len(barcut), barnum, off,
+                                     _c_strings(tags), len(tags)))
+        self.barnum, self.ntags = barnum, len(tags)
+
+    # ------------------------------------------------------------------ counting
+    def reset(self):
+        B.check(self._L.td_reset(self._h))
+
+    def set_option(self, name, value):
+        B.check(self._L.td_set_option(self._h, name.encode(), int(value)))
+
+    def bind_counts(self, device_ptr):
+        B.check(self._L.td_bind_counts(self._h, C.c_void_p(device_ptr) if device_ptr else None))
+
+    def count_device(self, d_ptr, nbytes, first_line=0, maxreads=5e9, tassel_tagcount=False, stream=0):
+        """Enqueue one pass over a FASTQ buffer already in HBM (asynchronous)."""
+        B.check(self._L.td_count_device(self._h, C.c_void_p(d_ptr), nbytes, first_line,
+                                        effective_maxreads(maxreads), 1 if tassel_tagcount else 0,
+                                        C.c_void_p(stream) if stream else None))
+
+    def count_bytes(self, data, first_line=0, maxreads=5e9, tassel_tagcount=False):
+        """Count a host buffer of whole lines; returns the number of line terminators consumed."""
+        n = len(data)
+        lines = C.c_uint64(0)
+        if n:
+            buf = (C.c_char * n).from_buffer_copy(data) if not isinstance(data, (C.Array,)) else data
+            B.check(self._L.td_count_host(self._h, buf, n, first_line, effective_maxreads(maxreads),
+                                          1 if tassel_tagcount else 0, C.byref(lines)))
+        return lines.value
+
+    def count_file(self, path, maxreads=5e9, tassel_tagcount=False):
+        """Record loop of find_tags_fastq (tagdigger_fun.py:239-277) over a file."""
+        # same failure modes as the reference's open()/gzip.open() + first read
+        if path[-2:].lower() == 'gz':
+            with open(path, 'rb') as fh:
+                head = fh.read(2)
+            if head and head != b'\x1f\x8b':
+                raise gzip.BadGzipFile("Not a gzipped file (%r)" % head)
+        else:
+            open(path, 'rb').close()
+        B.check(self._L.td_count_file(self._h, path.encode(), effective_maxreads(maxreads),
+                                      1 if tassel_tagcount else 0))
+
+    def count_lines_device(self, d_ptr, nbytes, stream=0):
+        out = C.c_uint64(0)
+        B.check(self._L.td_count_lines_device(self._h, C.c_void_p(d_ptr), nbytes,
+                                              C.c_void_p(stream) if stream else None, C.byref(out)))
+        return out.value
+
+    # ------------------------------------------------------------------ results
+    def stats(self):
+        st = (C.c_uint64 * B.TD_STAT_NSTATS)()
+        B.check(self._L.td_get_stats(self._h, st))
+        return {"reads": st[0], "barcut": st[1], "tag": st[2], "lines": st[3]}
+
+    def counts_flat(self):
+        out = (C.c_uint64 * max(1, self.barnum * self.ntags))()
+        B.check(self._L.td_get_counts(self._h, out))
+        return out
+
+    def counts(self, signed=False):
+        """list[list[int]] shaped [barcodes][tags], like the reference's mycounts (:237)."""
+        flat = self.counts_flat()
+        n = self.ntags
+        if signed:   # tassel weights may be negative in the reference (Python ints)
+            conv = lambda v: v - (1 << 64) if v >= (1 << 63) else v
+            return [[conv(flat[r * n + c]) for c in range(n)] for r in range(self.barnum)]
+        return [list(flat[r * n:(r + 1) * n]) for r in range(self.barnum)]
+
+    def counts_numpy(self):
+        import numpy as np
+        flat = self.counts_flat()
+        return np.frombuffer(flat, dtype=np.uint64, count=self.barnum * self.ntags).reshape(
+            self.barnum, self.ntags).copy()
+
+    def kernel_time_ms(self):
+        ms = C.c_double(0)
+        n = C.c_uint32(0)
+        B.check(self._L.td_kernel_time_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ------------------------------------------------------------------ device memory helpers
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        B.check(self._L.td_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        B.check(self._L.td_dev_free(self._h, C.c_void_p(ptr)))
+
+    def h2d(self, d_ptr, data):
+        n = len(data)
+        if n:
+            buf = (C.c_char * n).from_buffer_copy(data)
+            B.check(self._L.td_memcpy_h2d(self._h, C.c_void_p(d_ptr), buf, n))
+
+    def d2h(self, d_ptr, nbytes):
+        buf = (C.c_char * max(1, nbytes))()
+        if nbytes:
+            B.check(self._L.td_memcpy_d2h(self._h, buf, C.c_void_p(d_ptr), nbytes))
+        return bytes(buf[:nbytes])
+
+    def sync(self):
+        B.check(self._L.td_device_sync(self._h))
+
+
+_default = {}
+
+
+def default_engine(device=0):
+    eng = _default.get(device)
+    if eng is None:
+        eng = _default[device] = Engine(device)
+    return eng

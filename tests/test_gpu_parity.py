@@ -1,0 +1,253 @@
+"""GPU parity tests proper: the HIP path through the C-ABI (libtagdig.so) against
+the committed golden fixtures and against the CPU oracle on identical bytes.
+Bit-exact: the path is integer/byte work, no tolerance anywhere.
+Run on an MI355X with `pytest -m gpu`."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, write_case_file, case_payload
+from helpers import dirty_fastq, small_index, synth_expected, synth_host_bytes
+from oracle import c_oracle
+from oracle import tagdigger_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+CASES = load_golden("hotpath_cases.json") + load_golden("hotpath_random.json")
+EXC = {"AssertionError": AssertionError, "IndexError": IndexError, "TypeError": TypeError,
+       "ValueError": ValueError, "FileNotFoundError": FileNotFoundError}
+# the reference raises lazily at its first lookup into a leaf root; the product at index build
+ROOTLEAF = {"tag equals cutsite first"}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import tagdigger_amd
+    e = tagdigger_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def gpu_counts(eng, data, barcodes, tags, cutsite="TGCAG", **kw):
+    eng.set_index(barcodes, tags, cutsite)
+    eng.count_bytes(data, **kw)
+    return eng.counts_numpy()
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_golden_find_tags_fastq(case, tmp_path):
+    """The drop-in function itself, file in -> matrix out, against reference outputs."""
+    from tagdigger_amd import tagdigger_fun as tf
+    path = write_case_file(case, tmp_path)
+    if case.get("filename_override"):
+        path = str(tmp_path / "nope" / case["filename_override"])
+    if "raises" in case:
+        with pytest.raises(EXC[case["raises"]]) as ei:
+            tf.find_tags_fastq(path, case["barcodes"], case["tags"], **case["kwargs"])
+        if case["message"] and case["raises"] == "AssertionError":
+            assert str(ei.value) == case["message"]
+    else:
+        got = tf.find_tags_fastq(path, case["barcodes"], case["tags"], **case["kwargs"])
+        assert got == case["counts"]
+
+
+@pytest.mark.parametrize("tile_kb,prescan", [(16, 0), (32, 0), (16, 1), (32, 1)])
+def test_golden_all_kernel_modes(eng, tile_kb, prescan):
+    """Every non-raising, non-gz fixture through the in-memory path in each kernel configuration."""
+    import base64, gzip
+    try:
+        for case in CASES:
+            if "raises" in case or case["kwargs"].get("tassel_tagcount"):
+                continue
+            data = case_payload(case)
+            if case["filename"][-2:].lower() == "gz":
+                data = gzip.decompress(data)
+            eng.set_index(case["barcodes"], case["tags"], case["kwargs"].get("cutsite", "TGCAG"))
+            eng.set_option("tile_kb", tile_kb)
+            eng.set_option("prescan", prescan)
+            eng.count_bytes(data, maxreads=case["kwargs"].get("maxreads", 5e9))
+            assert eng.counts() == case["counts"], case["name"]
+    finally:
+        eng.set_option("tile_kb", 16)
+        eng.set_option("prescan", 0)
+
+
+def test_synth_device_generator_and_counts(eng):
+    """K0 bytes == host reference bytes; counts == oracle == generator's own expected matrix."""
+    from tagdigger_amd.synth import SynthConfig
+    cfg = SynthConfig(nreads=100_000, nbar=8, nmarkers=50, seed=1234)
+    nb = cfg.nbytes()
+    d = eng.dev_alloc(nb)
+    try:
+        cfg.fill_device(eng, d, 0, cfg.nreads)
+        dev = eng.d2h(d, nb)
+        host = synth_host_bytes(cfg, 0, cfg.nreads)
+        assert dev == bytes(host)
+        eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        eng.count_device(d, nb)
+        got = eng.counts_numpy()
+        st = eng.stats()
+    finally:
+        eng.dev_free(d)
+    want, hits = synth_expected(cfg, 0, cfg.nreads)
+    ost = {}
+    ora = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(host, stats=ost)
+    assert (got == ora).all() and (got == want).all()
+    assert (st["reads"], st["barcut"], st["tag"]) == (ost["reads"], ost["barcut"], ost["tag"])
+    assert st["lines"] == 4 * cfg.nreads and st["tag"] == hits
+
+
+@pytest.mark.parametrize("cutsite,nl", [("TGCAG", ("\n",)), ("CWGC", ("\n",)), ("TGCAG", ("\r\n",)),
+                                        ("TGCAT", ("\r",)), ("", ("\n", "\r\n", "\r")), ("RCATGY", ("\n", "\r\n"))])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_vs_oracle(eng, cutsite, nl, seed):
+    """Dirty FASTQ a few tiles long: every terminator style, blanks, N, case, phase shifts."""
+    rnd = random.Random(1000 * seed + len(cutsite) + len(nl))
+    barcodes, tags, cutsites = small_index(rnd, cutsite)
+    data = dirty_fastq(rnd, barcodes, tags, cutsites, nrec=1500, nl_choices=nl, long_lines=(seed == 2))
+    ora = c_oracle.COracle(barcodes, tags, cutsite)
+    ost = {}
+    want = ora.count_bytes(data, stats=ost)
+    for tile_kb in (16, 32):
+        eng.set_index(barcodes, tags, cutsite)
+        eng.set_option("tile_kb", tile_kb)
+        lines = eng.count_bytes(data)
+        got = eng.counts_numpy()
+        st = eng.stats()
+        assert (got == want).all(), (cutsite, nl, tile_kb)
+        assert (st["reads"], st["barcut"], st["tag"]) == (ost["reads"], ost["barcut"], ost["tag"])
+        assert lines == st["lines"] == data.count(b"\n") + data.count(b"\r") - data.count(b"\r\n")
+    eng.set_option("tile_kb", 16)
+
+
+def test_tile_boundary_sweep(eng):
+    """Slide a record across a tile boundary byte by byte (16 KiB tiles), with \\r\\n split across it."""
+    barcodes, tags = ["AACG", "TTGACC"], ["TGCAGAAAC", "TGCAGGGGT"]
+    rec = b"@h\r\nAACGTGCAGAAACTT\r\n+\r\nIIII\r\n"
+    eng.set_index(barcodes, tags, "TGCAG")
+    ora = c_oracle.COracle(barcodes, tags, "TGCAG")
+    for pad in list(range(16384 - 40, 16384 + 8)):
+        # a first record whose quality line is padded so the second record lands around the boundary
+        head = b"@p\nGGGG\n+\n" + b"I" * (pad - 10 - 1) + b"\n"
+        data = head + rec + rec
+        eng.reset()
+        eng.count_bytes(data)
+        assert (eng.counts_numpy() == ora.count_bytes(data)).all(), pad
+
+
+def test_many_short_lines_overflow_rounds(eng):
+    """More sequence-line starts in a tile than the per-tile list holds (1-byte lines)."""
+    barcodes, tags = ["A"], ["CC", "GT"]
+    eng.set_index(barcodes, tags, "")
+    body = b"\n".join([b"x", b"ACC", b"y", b"z"] * 3000) + b"\n" + b"\n" * 9000 + b"@\nAGT\n+\n!\n"
+    ora = c_oracle.COracle(barcodes, tags, "")
+    for tile_kb in (16, 32):
+        eng.reset()
+        eng.set_option("tile_kb", tile_kb)
+        eng.count_bytes(body)
+        assert (eng.counts_numpy() == ora.count_bytes(body)).all()
+    eng.set_option("tile_kb", 16)
+
+
+def test_streamed_pieces_and_maxreads(eng):
+    """> 32 MiB host buffer: several staged pieces with the line index carried on the device."""
+    from tagdigger_amd.synth import SynthConfig
+    cfg = SynthConfig(nreads=400_000, nbar=24, nmarkers=500, seed=77)
+    host = synth_host_bytes(cfg, 0, cfg.nreads)          # 87.6 MB
+    shifted = b"\n" + bytes(host)                        # every line index moves by one
+    ora = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite)
+    eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+    eng.count_bytes(host)
+    want, _ = synth_expected(cfg, 0, cfg.nreads)
+    assert (eng.counts_numpy() == want).all()
+    for maxreads in (1, 123_457, 399_999):
+        eng.reset()
+        eng.count_bytes(host, maxreads=maxreads)
+        w, _ = synth_expected(cfg, 0, maxreads)
+        assert (eng.counts_numpy() == w).all() and eng.stats()["reads"] == maxreads
+    eng.reset()
+    eng.count_bytes(shifted)
+    assert int(eng.counts_numpy().sum()) == int(ora.count_bytes(shifted).sum()) == 0
+    # first_line argument: the same bytes declared to start on line 3 read as shifted by one more
+    eng.reset()
+    eng.count_bytes(shifted, first_line=3)
+    assert (eng.counts_numpy() == want).all()
+
+
+def test_count_lines_device(eng):
+    rnd = random.Random(9)
+    data = bytes(rnd.choice(b"ACGT\n\r\r\nxyz") for _ in range(200_003))
+    d = eng.dev_alloc(len(data))
+    try:
+        eng.h2d(d, data)
+        got = eng.count_lines_device(d, len(data))
+    finally:
+        eng.dev_free(d)
+    want = data.count(b"\n") + data.count(b"\r") - data.count(b"\r\n")
+    assert got == want
+
+
+def test_nonascii_policy(eng):
+    import tagdigger_amd
+    barcodes, tags = ["AACG"], ["TGCAGAAAC"]
+    eng.set_index(barcodes, tags, "TGCAG")
+    ok = "@h\xe9\nAACGTGCAGAAAC\n+\n\xff\xfe\n".encode("latin-1")      # high bytes outside sequence lines
+    eng.count_bytes(ok)
+    assert eng.counts() == [[1]]
+    bad = "@h\nAACGTGCAGAAAC\xe9\n+\nII\n".encode("latin-1")
+    eng.reset()
+    eng.count_bytes(bad)
+    with pytest.raises(tagdigger_amd.NonAsciiSequence):
+        eng.counts()
+    with pytest.raises(orc.NonAsciiSequence):
+        orc.count_bytes(bad, barcodes, tags)
+    # beyond maxreads it is never looked at
+    eng.reset()
+    eng.count_bytes(ok + bad, maxreads=1)
+    assert eng.counts() == [[1]]
+
+
+def test_long_tags_all_widths(eng):
+    """Tag lengths across every packed-width instantiation (W = 1,2,3,4,6,10 words)."""
+    rnd = random.Random(3)
+    for maxlen in (20, 60, 90, 125, 190, 300):
+        barcodes = ["ACGTAC", "TTGA", "GGGTCCAATC"]
+        tags = []
+        while len(tags) < 30:
+            t = "TGCAG" + "".join(rnd.choice("ACGT") for _ in range(rnd.randint(max(1, maxlen - 40), maxlen)))
+            if not any(t.startswith(o) or o.startswith(t) for o in tags):
+                tags.append(t)
+        data = dirty_fastq(rnd, barcodes, tags, ["TGCAG"], nrec=400)
+        want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data)
+        got = gpu_counts(eng, data, barcodes, tags, "TGCAG")
+        assert (got == want).all() and want.sum() > 50, maxlen
+
+
+def test_short_and_mixed_length_tags(eng):
+    """Tags shorter than the hashed prefix go through the short list; mixed lengths share buckets."""
+    rnd = random.Random(4)
+    barcodes = ["ACGT", "TTG"]
+    tags = ["A", "CA", "CCGT", "GGGTTTAAACCC", "GGGTTTAAACCG" + "T" * 30, "T" * 40 + "A", "T" * 40 + "C" + "G" * 25]
+    for k in range(40):
+        t = "CG" + "".join(rnd.choice("ACGT") for _ in range(rnd.randint(5, 70)))
+        if not any(t.startswith(o) or o.startswith(t) for o in tags):
+            tags.append(t)
+    data = dirty_fastq(rnd, barcodes, tags, [""], nrec=1200)
+    want = c_oracle.COracle(barcodes, tags, "").count_bytes(data)
+    got = gpu_counts(eng, data, barcodes, tags, "")
+    assert (got == want).all() and want.sum() > 300
+
+
+def test_idempotent_relaunch_and_accumulate(eng):
+    """Counting the same buffer twice doubles every cell; reset returns to zero."""
+    from tagdigger_amd.synth import SynthConfig
+    cfg = SynthConfig(nreads=30_000, nbar=8, nmarkers=50, seed=9)
+    host = bytes(synth_host_bytes(cfg, 0, cfg.nreads))
+    eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+    eng.count_bytes(host)
+    once = eng.counts_numpy()
+    eng.count_bytes(host)
+    assert (eng.counts_numpy() == 2 * once).all()
+    eng.reset()
+    assert eng.counts_numpy().sum() == 0

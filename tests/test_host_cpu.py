@@ -1,0 +1,89 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every
+declared symbol, fails loudly without a GPU, and the synthetic-stream spec is
+self-consistent against the oracle.  No compute calls on a GPU here."""
+import ctypes as C
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from helpers import synth_expected, synth_host_bytes
+from oracle import c_oracle
+from oracle import tagdigger_oracle as orc
+
+
+def test_header_symbols_exported():
+    from tagdigger_amd import _binding as B
+    L = B.load()
+    hdr = open(os.path.join(ROOT, "include", "tagdig.h")).read()
+    declared = set(re.findall(r"\b(td_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert declared == set(B.EXPORTS)
+
+
+def test_no_gpu_fails_loudly():
+    from tagdigger_amd import _binding as B
+    L = B.load()
+    h = C.c_void_p()
+    rc = L.td_create(C.byref(h), 0)
+    if rc == 0:          # running on a GPU box: nothing to check here
+        L.td_destroy(h)
+        pytest.skip("GPU present")
+    assert rc == -1 and b"no CPU fallback" in L.td_last_error()
+    import tagdigger_amd
+    with pytest.raises(tagdigger_amd.TagdigError):
+        tagdigger_amd.Engine(0)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "tagdigger_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no CPU fallback", "").lower() or f == "_binding.py" or \
+                    all("import" not in ln for ln in src.splitlines() if "oracle" in ln.lower()), f
+
+
+def test_engine_setup_matches_oracle_lists():
+    """The product's own cut-site enumeration equals the oracle's (hence the reference's)."""
+    from tagdigger_amd.engine import enumerate_cut_sites, effective_maxreads
+    for cs in ["TGCAG", "", "CWGC", "BN", "RY", "NN", "RCATGY", "VH", "NWS"]:
+        assert enumerate_cut_sites(cs) == orc.enumerate_cut_sites(cs)
+    for m in [5e9, 3, 2.5, 0, -4, 1, 1.0001]:
+        assert effective_maxreads(m) == c_oracle.effective_maxreads(m)
+
+
+def test_synth_records_and_expected_matrix():
+    from tagdigger_amd.synth import SynthConfig
+    cfg = SynthConfig(nreads=20000, nbar=8, nmarkers=50, seed=1234)
+    data = synth_host_bytes(cfg, 0, cfg.nreads)
+    assert data.nbytes == cfg.nreads * 219
+    first = bytes(data[:219]).split(b"\n")
+    assert first[0] == b"@r000000000000" and len(first[1]) == 100 and first[2] == b"+" and first[3] == b"I" * 100
+    # shards are position independent
+    mid = synth_host_bytes(cfg, 777, 10)
+    assert bytes(mid) == bytes(data[777 * 219:787 * 219])
+    want, hits = synth_expected(cfg, 0, cfg.nreads)
+    st = {}
+    got = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(data, stats=st)
+    assert (got == want).all() and hits == st["tag"] == int(want.sum())
+    assert st["reads"] == cfg.nreads and 0.83 * cfg.nreads < st["barcut"] < 0.9 * cfg.nreads
+    # and the slow Python oracle agrees on a prefix
+    sub = bytes(data[:219 * 1500])
+    assert orc.count_bytes(sub, cfg.barcodes, cfg.tags, cfg.cutsite) == \
+        c_oracle.count_bytes(sub, cfg.barcodes, cfg.tags, cfg.cutsite)
+
+
+def test_synth_multicut_config():
+    from tagdigger_amd.synth import SynthConfig
+    cfg = SynthConfig(nreads=5000, nbar=12, nmarkers=40, seed=5, cutsite="CWGC", bclen=(4, 10))
+    data = synth_host_bytes(cfg, 0, cfg.nreads)
+    want, _ = synth_expected(cfg, 0, cfg.nreads)
+    got = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(data)
+    assert (got == want).all()
