@@ -32,7 +32,8 @@ def synth_expected(cfg, first_read, nreads):
     return counts, hits
 
 
-def dirty_fastq(rnd, barcodes, tags, cutsites, nrec, nl_choices=("\n",), long_lines=False):
+def dirty_fastq(rnd, barcodes, tags, cutsites, nrec, nl_choices=("\n",), long_lines=False,
+                permanent_shifts=False):
     """FASTQ-ish bytes with every irregularity the reference tolerates."""
     out = []
     for ri in range(nrec):
@@ -66,8 +67,14 @@ def dirty_fastq(rnd, barcodes, tags, cutsites, nrec, nl_choices=("\n",), long_li
         if rnd.random() < 0.03:
             nl = rnd.choice(["\n", "\r\n", "\r"])
         out.append(hdr + nl + seq + nl + "+" + nl + qual + nl)
-        if rnd.random() < 0.01:
-            out.append(rnd.choice(["\n", "\n\n", "\r", "\r\n\n", "\n\n\n\n"]))   # phase shifts
+        r = rnd.random()
+        if r < 0.01:
+            out.append(rnd.choice(["\n\n\n\n", "\r\n\r\n\n\r", "\r\r\r\r"]))   # four blank lines: phase kept
+        elif r < 0.012:
+            shift = rnd.choice(["\n", "\n\n", "\r", "\r\n\n"])                   # phase lost ...
+            out.append(shift)
+            pending = 4 - (shift.count("\n") + shift.count("\r") - shift.count("\r\n"))
+            out.append("\r" * pending if not (permanent_shifts and rnd.random() < 0.3) else "")                 # ... and usually restored
     return "".join(out).encode("latin-1")
 
 

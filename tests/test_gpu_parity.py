@@ -105,7 +105,8 @@ def test_fuzz_vs_oracle(eng, cutsite, nl, seed):
     """Dirty FASTQ a few tiles long: every terminator style, blanks, N, case, phase shifts."""
     rnd = random.Random(1000 * seed + len(cutsite) + len(nl))
     barcodes, tags, cutsites = small_index(rnd, cutsite)
-    data = dirty_fastq(rnd, barcodes, tags, cutsites, nrec=1500, nl_choices=nl, long_lines=(seed == 2))
+    data = dirty_fastq(rnd, barcodes, tags, cutsites, nrec=1500, nl_choices=nl, long_lines=(seed == 2),
+                       permanent_shifts=(seed == 2))
     ora = c_oracle.COracle(barcodes, tags, cutsite)
     ost = {}
     want = ora.count_bytes(data, stats=ost)
