@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FASTQ reads/s of the tag-counting hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (libtagdig's fused count kernel, through
+the C-ABI) over one synthetic FASTQ library already resident in HBM, plus --
+for N > 1 -- the one RCCL all-reduce of the integer count matrix.  Workload at
+N=1: the configuration BASELINE.json's metric is quoted on (200 M reads x 384
+barcodes x 100 k tags, 100 bp reads, 219 B/record = 43.8 GB), one such library
+per GPU (weak scaling, BASELINE config 4's file-per-GPU sharding).
+
+Rank 0 prints ONE JSON line (see the driver contract in the task statement).
+The `roofline` object prices the count kernel against HBM bandwidth using
+ALGORITHMIC bytes = 219 B x reads per launch and the kernel's own duration
+from HIP events on the launch stream; `cpu_baseline` times the oracle's C
+restatement on a bounded prefix of the same stream on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=200_000_000, help="reads per GPU")
+    ap.add_argument("--barcodes", type=int, default=384)
+    ap.add_argument("--markers", type=int, default=50_000, help="tags = 2 x markers")
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--tile-kb", type=int, default=0)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import tagdigger_amd
+    from tagdigger_amd.synth import SynthConfig
+
+    cfg = SynthConfig(nreads=args.reads, nbar=args.barcodes, nmarkers=args.markers, seed=args.seed)
+    eng = tagdigger_amd.Engine(local_rank)
+    if args.tile_kb:
+        eng.set_option("tile_kb", args.tile_kb)
+    if args.blocks_per_cu:
+        eng.set_option("blocks_per_cu", args.blocks_per_cu)
+    nbytes = cfg.nbytes()
+    fastq = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    first_read = rank * cfg.nreads                      # this GPU's library = its own slice of the stream
+    cfg.fill_device(eng, fastq.data_ptr(), first_read, cfg.nreads)
+    counts = torch.zeros(len(cfg.barcodes) * len(cfg.tags), dtype=torch.int32, device=dev)
+    eng.bind_counts(counts.data_ptr())               # the matrix lives in a torch tensor so RCCL can reduce it
+    eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        counts.zero_()
+        eng.count_device(fastq.data_ptr(), nbytes, stream=stream)
+        if world > 1:
+            dist.all_reduce(counts)       # the path's one exchange: integer sum over xGMI (RCCL)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+
+    # ---- correctness of what is being timed (rank-local shard, before any all-reduce)
+    check = None
+    if not args.no_check:
+        from helpers import synth_expected
+        counts.zero_()
+        eng.reset()
+        eng.count_device(fastq.data_ptr(), nbytes, stream=stream)
+        torch.cuda.synchronize()
+        got = counts.cpu().numpy().astype(np.int64).reshape(len(cfg.barcodes), len(cfg.tags))
+        want, hits = synth_expected(cfg, first_read, cfg.nreads)
+        st = eng.stats()
+        ok = bool((got == want.astype(np.int64)).all()) and st["tag"] == hits and st["reads"] == cfg.nreads
+        check = {"bit_exact_vs_expected": ok, "reads": int(st["reads"]), "barcut": int(st["barcut"]), "tag": int(st["tag"])}
+        if not ok:
+            print("bench.py: rank %d COUNT MISMATCH against the generator's expected matrix" % rank, file=sys.stderr)
+            sys.exit(3)
+
+    eng.set_option("timing", 1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kms, klaunches = eng.kernel_time_ms()
+    eng.set_option("timing", 0)
+
+    if world > 1:
+        t = torch.tensor([elapsed, kms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kms = float(t[0]), float(t[1])
+        # every rank now holds the same summed matrix: its total must equal the sum of all shards' hits
+        tot = torch.tensor([int(counts.to(torch.int64).sum())], dtype=torch.int64, device=dev)
+        mine = torch.tensor([check["tag"] if check else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(mine)
+        if check and int(tot[0]) != int(mine[0]):
+            print("bench.py: all-reduced matrix total %d != sum of shard hits %d" % (int(tot[0]), int(mine[0])),
+                  file=sys.stderr)
+            sys.exit(3)
+
+    if rank == 0:
+        total_reads = cfg.nreads * world * args.steps
+        value = total_reads / elapsed
+        algo_bytes = cfg.record_bytes * cfg.nreads
+        achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "FASTQ reads/sec (whole node), 200M-read x 100k-tag synthetic, 1/2/4/8 MI355X",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2] shape, device-resident (tier T1): %d reads x %d barcodes x %d tags "
+                                   "per GPU, 100 bp reads, %d B/record, one library per GPU"
+                                   % (cfg.nreads, len(cfg.barcodes), len(cfg.tags), cfg.record_bytes),
+                       "reads_per_gpu": cfg.nreads, "barcodes": len(cfg.barcodes), "tags": len(cfg.tags),
+                       "fastq_bytes_per_gpu": nbytes, "sharding": "library-per-GPU + RCCL all-reduce(int32 count matrix)"
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "tdk::k_count", "kernel_ms": kms, "kernel_launches": klaunches,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+            "check": check,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample, cfg.nreads))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+def cpu_baseline(cfg, sample_reads):
+    """The oracle's C restatement (oracle/oracle.c, scalar, one thread) on the first
+    `sample_reads` reads of the same stream, produced by the host reference generator."""
+    from helpers import synth_host_bytes
+    from oracle import c_oracle
+    data = synth_host_bytes(cfg, 0, sample_reads)
+    t0 = time.perf_counter()
+    ora = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite)
+    build_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ora.count_bytes(data)
+    loop_s = time.perf_counter() - t0
+    return {"value": sample_reads / loop_s, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the same synthetic stream (%.2f GB), record loop only; "
+                      "trie build %.2f s timed separately; scalar C restatement oracle/oracle.c"
+                      % (sample_reads, data.nbytes / 1e9, build_s),
+            "index_build_s": build_s, "loop_s": loop_s}
+
+
+if __name__ == "__main__":
+    main()
