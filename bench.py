@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--debug-ablate", type=int, default=0, help="timing-only kernel ablation bits (implies --no-check)")
     args = ap.parse_args()
 
     import numpy as np
@@ -72,6 +73,9 @@ def main():
         eng.set_option("tile_kb", args.tile_kb)
     if args.blocks_per_cu:
         eng.set_option("blocks_per_cu", args.blocks_per_cu)
+    if args.debug_ablate:
+        eng.set_option("debug_ablate", args.debug_ablate)
+        args.no_check = True
     nbytes = cfg.nbytes()
     fastq = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     first_read = rank * cfg.nreads                      # this GPU's library = its own slice of the stream

@@ -127,6 +127,10 @@ int td_set_option(td_handle *h, const char *name, int64_t value);
  * last call (HIP events on the launch stream); launches_out optional. */
 int td_kernel_time_ms(td_handle *h, double *ms_per_launch, uint32_t *launches_out);
 
+/* Diagnostic counters (24 x uint64).  All zero in the shipped build; the phase-stamp
+ * build (make prof -> libtagdig_prof.so) fills [0..7] with shader-clock cycles per phase. */
+int td_debug_counters(td_handle *h, uint64_t out[24]);
+
 /* ---- device memory helpers (so a binding needs no other GPU runtime) ------- */
 int td_dev_alloc(td_handle *h, uint64_t nbytes, void **d_out);
 int td_dev_free(td_handle *h, void *d_ptr);

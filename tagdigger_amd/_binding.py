@@ -15,7 +15,7 @@ import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtagdig.so")
+LIB_PATH = os.environ.get("TAGDIG_LIB") or os.path.join(_HERE, "libtagdig.so")
 
 TD_STAT_NSTATS = 8
 TD_E = {
@@ -105,6 +105,7 @@ def load():
     sig("td_get_stats", i32, vp, C.POINTER(u64))
     sig("td_set_option", i32, vp, C.c_char_p, C.c_int64)
     sig("td_kernel_time_ms", i32, vp, C.POINTER(C.c_double), C.POINTER(u32))
+    sig("td_debug_counters", i32, vp, C.POINTER(u64))
     sig("td_dev_alloc", i32, vp, u64, C.POINTER(vp))
     sig("td_dev_free", i32, vp, vp)
     sig("td_memcpy_h2d", i32, vp, vp, vp, u64)
@@ -123,7 +124,7 @@ EXPORTS = [
     "td_last_error", "td_last_bad_index", "td_create", "td_destroy", "td_set_index",
     "td_bind_counts", "td_reset", "td_count_device", "td_count_host", "td_count_file",
     "td_count_lines_device", "td_get_counts", "td_get_stats", "td_set_option",
-    "td_kernel_time_ms", "td_dev_alloc", "td_dev_free", "td_memcpy_h2d", "td_memcpy_d2h",
+    "td_kernel_time_ms", "td_debug_counters", "td_dev_alloc", "td_dev_free", "td_memcpy_h2d", "td_memcpy_d2h",
     "td_device_sync", "td_synth_fill_device",
 ]
 

@@ -6,18 +6,24 @@
 //
 //   tile claim     a workgroup takes the next tile by ticket (atomic counter),
 //                  so every predecessor tile is owned by a running workgroup
-//   phase 1a       coalesced 16 B/lane loads -> LDS, and per 16-byte chunk a
+//   phase 1a       coalesced 16 B/lane loads into registers; per 16-byte chunk a
 //                  16-bit line-terminator mask (\n, \r\n, bare \r: Python's
-//                  universal newlines, :241-250) by SWAR + v_dot4
+//                  universal newlines, :241-250) by SWAR + v_dot4 -> LDS
 //   phase 1b       each thread owns CPT consecutive chunks: popcount, block
-//                  scan, then decoupled look-back over per-tile state words
-//                  gives the global line index of every terminator, hence
+//                  scan, publish the tile's terminator count, and issue the
+//                  loads of the decoupled look-back over per-tile state words
+//   phase 1c       while those loads fly, EVERY chunk is upper-cased, validated
+//                  and 2-bit packed by all lanes (v_perm/v_dot4) and only the
+//                  packed form (8 B per 16 bytes) is staged in LDS
+//   look-back      gives the global line index of every terminator, hence
 //                  which lines are sequence lines (lineindex % 4 == 1, :254)
-//   phase 2        one lane per sequence line: skip leading blanks (:256),
-//                  2-bit pack + validate from LDS (v_perm/v_dot4), barcode
+//   phase 2        one lane per sequence line: packed bases from LDS, barcode
 //                  prefix lookup in an LDS directory (:257), tag lookup in a
-//                  hash table of packed tags in global memory / L2 (:260),
-//                  one no-return atomic add into the count matrix (:267)
+//                  bucketed hash table of packed tags in global memory / L2
+//                  (:260), one no-return atomic add into the count matrix
+//                  (:267).  Lines that start with a non-base byte (blanks to
+//                  skip, :256) or run past the staged window take a slow path
+//                  that re-reads raw bytes from global memory.
 //
 // The reference's pointer trie (:71-134) is re-laid flat: because the stored
 // sequences are prefix-free after the build-time shadowing rules, "walk the
@@ -31,13 +37,21 @@
 namespace tdk {
 
 constexpr int BLOCK = 256;
-constexpr int RLIST_CAP = 1024;            // sequence-line starts kept per tile; overflow is handled inline
+constexpr int TLIST_CAP = 2048;            // line starts (one per terminator) listed per round; more -> extra rounds
+constexpr int LBQ = 4;                     // look-back: tile states examined per thread per round (window 1024)
 constexpr uint64_t FLAG_AGG = 1ull << 62;  // tile state: own terminator count published
 constexpr uint64_t FLAG_INC = 2ull << 62;  // tile state: inclusive prefix published
 constexpr uint64_t VAL_MASK = (1ull << 62) - 1;
 constexpr uint32_t BDIR_BASES = 5;         // barcode directory is keyed on the first 5 bases
 constexpr uint32_t BDIR_SIZE = 1u << (2 * BDIR_BASES);
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
+// per-line result of the matcher (top two bits) | count-matrix cell
+constexpr uint64_t R_NONE = 0, R_BAR = 1ull << 62, R_TAG = 2ull << 62, R_DEFER = 3ull << 62, R_CELL = (1ull << 62) - 1;
+constexpr int IPL = 4;                     // line starts examined per lane per batch (the select chains below assume 4)
+
+// timing-only ablation switches (td_set_option "debug_ablate")
+constexpr uint32_t DBG_NO_ATOMIC = 1, DBG_NO_PROBE = 2, DBG_NO_PHASE2 = 4, DBG_NO_LOOKBACK = 8,
+                   DBG_NO_PACK = 16, DBG_STATIC_TILES = 32;
 
 // device-side error bits (stats[ST_ERR])
 constexpr unsigned long long ERR_NONASCII = 1, ERR_SPIN = 2, ERR_TASSEL = 4;
@@ -55,9 +69,10 @@ struct KParams {
     // barcode index blob (copied to LDS): bval u64[nent] | bmeta u32[nent] | bdir u16[1024] | bcand u16[ncand]
     const uint32_t *bblob;
     uint32_t bblob_bytes, off_bmeta, off_bdir, off_bcand;
-    // tag hash table
-    const uint4 *slots;
-    uint32_t slot_mask;
+    // tag hash table: buckets of 64 B (W<=3) or 128 B; dword 0 = overflow flag, then slots of
+    // {W x u64 packed bases, u32 meta = col<<10 | len}; empty slot: meta 0
+    const uint4 *buckets;
+    uint32_t bucket_mask;
     uint32_t m_bases;        // tags are hashed on their first m bases (1..32)
     const uint4 *shorts;     // tags shorter than m: {u64 bases, u32 len, u32 col}
     uint32_t nshort;
@@ -72,6 +87,7 @@ struct KParams {
     // leave the running total for the next piece; both may be null
     const unsigned long long *cursor_in;
     unsigned long long *cursor_out;
+    uint32_t dbg;            // timing-only ablations (results wrong when nonzero); see DBG_*
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -144,22 +160,64 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
     return v;
 }
 
+// In-kernel phase stamps: a separate diagnostic build only (-DTD_PHASE_PROF, libtagdig_prof.so).
+// Thread 0 of each workgroup adds the shader-clock cycles spent between consecutive stamps to
+// stats[8 + phase]; shares are read, the build's run time is never quoted.
+#ifdef TD_PHASE_PROF
+#define TD_STAMP(i)                                                         \
+    do {                                                                    \
+        if (tid == 0) {                                                     \
+            unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+            prof_acc[i] += now_ - prof_last;                                \
+            prof_last = now_;                                               \
+        }                                                                   \
+    } while (0)
+#else
+#define TD_STAMP(i) do {} while (0)
+#endif
+constexpr int PROF_PHASES = 12;
+
 // ---------------------------------------------------------------- the kernel
+// 2-bit codes (first base in the top bits) and per-base invalid flags (bit 15 = first base)
+// of one 16-byte chunk.  A 0, C 1, T 2, G 3 = (byte >> 1) & 3; [ACGTacgt] are the valid bytes.
+__device__ __forceinline__ uint2 convert_chunk(const uint4 &v) {
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t cw = 0, iw = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t code = (x[d] >> 1) & 0x03030303u;
+        uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, code);
+        uint32_t diff = (x[d] & 0xDFDFDFDFu) ^ expect;            // 0 where the byte is a base
+        uint32_t nz = ((((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) >> 7) & 0x01010101u;
+        cw = (cw << 8) | udot4(code, 0x01041040u, 0u);
+        iw = (iw << 4) | udot4(nz, 0x01020408u, 0u);
+    }
+    return make_uint2(cw, iw);
+}
+
 // CPT: 16-byte chunks per thread per tile (tile = CPT*4 KiB); W: 64-bit words per packed tag
+#ifndef TD_WAVES_PER_SIMD
+#define TD_WAVES_PER_SIMD 4   // register budget: 4 workgroups of 256 threads per CU
+#endif
 template <int CPT, int W, bool TASSEL>
-__global__ __launch_bounds__(BLOCK) void k_count(const KParams p) {
+__global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_count(const KParams p) {
     constexpr int TILE_CH = CPT * BLOCK;
     constexpr uint32_t TILE = TILE_CH * 16;
     constexpr int NCHMAX = 2 * W + 3;
     constexpr int NS = 2 * W + 4;      // aligned 16-base words kept (zero padded)
-    constexpr int SLOT_U4 = (W + 2) / 2;
+    constexpr int BUCKET_U4 = W <= 3 ? 4 : 8;          // 64- or 128-byte buckets
+    constexpr int SLOT_DW = 2 * W + 1;
+    constexpr int SPB = (BUCKET_U4 * 4 - 1) / SLOT_DW;  // slots per bucket
 
+    // LDS: packed chunks of the tile + halo | terminator masks (later: line-start list) | misc | barcode index
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t win = TILE + p.halo;
-    uint8_t *L_data = lds;
-    uint16_t *L_mask = reinterpret_cast<uint16_t *>(lds + win);
-    uint16_t *L_rlist = L_mask + TILE_CH;
-    uint32_t *L_misc = reinterpret_cast<uint32_t *>(L_rlist + RLIST_CAP);   // 64 dwords
+    const uint32_t halo_ch = p.halo / 16u;
+    const uint32_t win_ch = TILE_CH + halo_ch;           // chunks staged in LDS
+    uint2 *L_conv = reinterpret_cast<uint2 *>(lds);
+    uint16_t *L_mask = reinterpret_cast<uint16_t *>(lds + (size_t)win_ch * 8u);
+    uint16_t *L_tlist = L_mask;                          // aliases the masks once they are in registers
+    constexpr uint32_t MASK_BYTES = (TILE_CH * 2 > TLIST_CAP * 2) ? TILE_CH * 2 : TLIST_CAP * 2;
+    uint32_t *L_misc = reinterpret_cast<uint32_t *>(lds + (size_t)win_ch * 8u + MASK_BYTES);   // 64 dwords
     unsigned long long *L_misc64 = reinterpret_cast<unsigned long long *>(L_misc + 32);
     uint8_t *L_bidx = reinterpret_cast<uint8_t *>(L_misc + 64);
     const unsigned long long *L_bval = reinterpret_cast<const unsigned long long *>(L_bidx);
@@ -174,45 +232,46 @@ __global__ __launch_bounds__(BLOCK) void k_count(const KParams p) {
 
     uint32_t st_reads = 0, st_bar = 0, st_tag = 0;
     unsigned long long st_lines = 0;
+#ifdef TD_PHASE_PROF
+    unsigned long long prof_acc[PROF_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#endif
     const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
     const uint64_t first_line = p.first_line + carried;
 
     // ------------------------------------------------------------ per-read matcher
-    // srel: offset of the line's first byte relative to the tile start (may lie in the halo)
-    auto match_read = [&](uint64_t tbase, uint32_t srel, unsigned long long weight) {
-        st_reads++;
-        auto peek = [&](uint32_t rel) -> uint32_t {
-            if (rel < win) return L_data[rel];
-            uint64_t g = tbase + rel;
-            return g < p.nbytes ? p.buf[g] : 0u;
-        };
-        while (is_blank(peek(srel))) srel++;   // ends at the terminator at the latest
-        const uint32_t a = srel & 15u, c0 = srel >> 4;
+    // srel: offset of the line's first byte relative to the tile start (may lie in the halo).
+    // Fast path: packed chunks from LDS.  Slow path (`slow`, or decided here): raw bytes from
+    // global memory -- leading blanks to skip (:256) or a window beyond what is staged.
+    // Returns R_NONE (no barcode+site), R_BAR (barcode+site only), R_TAG | cell, or -- fast mode
+    // only -- R_DEFER when the raw bytes are needed.  No side effects: the caller commits.
+    // gpos: absolute position of the line's first byte; srel: the same relative to the tile (fast mode)
+    auto match_read = [&](uint64_t gpos, uint32_t srel, bool slow) -> uint64_t {
+        if (!slow) {
+            const uint32_t c0f = srel >> 4;
+            if (c0f + p.nch > win_ch) return R_DEFER;
+            // first byte is not a base: a blank to strip (slow path), or simply no match
+            if ((L_conv[c0f].y >> (15u - (srel & 15u))) & 1u) return R_DEFER;
+        }
+        if (slow) {
+            while (gpos < p.nbytes && is_blank(p.buf[gpos])) gpos++;   // ends at the terminator at the latest
+        }
+        const uint32_t a = (uint32_t)(gpos & 15u);
+        const uint64_t g0 = gpos & ~15ull;             // slow path: first chunk (tile bases are 16-aligned)
+        const uint32_t c0 = srel >> 4;                 // fast path
         uint32_t codes[NCHMAX + 1];
         uint32_t inv[(NCHMAX + 1) / 2];
 #pragma unroll
         for (int i = 0; i < (NCHMAX + 1) / 2; i++) inv[i] = 0;
 #pragma unroll
         for (int i = 0; i < NCHMAX; i++) {
-            uint32_t cw = 0, iw = 0xFFFFu;
+            uint2 e = make_uint2(0u, 0xFFFFu);
             if (i < (int)p.nch) {
-                const uint32_t o = (c0 + i) * 16u;
-                uint4 v = (o + 16u <= win) ? *reinterpret_cast<const uint4 *>(L_data + o)
-                                           : load_chunk(p, tbase + o);
-                const uint32_t x[4] = {v.x, v.y, v.z, v.w};
-                iw = 0;
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    uint32_t code = (x[d] >> 1) & 0x03030303u;           // A0 C1 T2 G3
-                    uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, code);
-                    uint32_t diff = (x[d] & 0xDFDFDFDFu) ^ expect;        // 0 where the byte is [ACGTacgt]
-                    uint32_t nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) >> 7 & 0x01010101u;
-                    cw = (cw << 8) | udot4(code, 0x01041040u, 0u);        // first base in the top bits
-                    iw = (iw << 4) | udot4(nz, 0x01020408u, 0u);
-                }
+                if (!slow) e = L_conv[c0 + i];
+                else e = convert_chunk(load_chunk(p, g0 + 16ull * i));
             }
-            codes[i] = cw;
-            if (i & 1) inv[i >> 1] |= iw; else inv[i >> 1] |= iw << 16;
+            codes[i] = e.x;
+            if (i & 1) inv[i >> 1] |= e.y; else inv[i >> 1] |= e.y << 16;
         }
         codes[NCHMAX] = 0;
         if ((NCHMAX & 1)) inv[NCHMAX >> 1] |= 0xFFFFu;   // padding half-word is invalid
@@ -239,6 +298,7 @@ __global__ __launch_bounds__(BLOCK) void k_count(const KParams p) {
                 S[w] = (uint32_t)(pr >> (32u - 2u * a));
             } else S[w] = 0;
         }
+        TD_STAMP(8);    // (inside phase 2) fetch packed chunks + alignment
         // ---- barcode + cut site (reference :257)
         const uint64_t K = ((uint64_t)S[0] << 32) | S[1];
         uint32_t ci = L_bdir[S[0] >> (32 - 2 * BDIR_BASES)];
@@ -254,10 +314,10 @@ __global__ __launch_bounds__(BLOCK) void k_count(const KParams p) {
                 ci++;
             }
         }
-        if (!bhit) return;
-        st_bar++;
+        TD_STAMP(9);    // barcode directory walk
+        if (!bhit) return R_NONE;
         const uint32_t off = (meta >> 6) & 1023u, row = meta >> 16;
-        if (nvalid <= off) return;
+        if (nvalid <= off) return R_BAR;
         const uint32_t nrem = nvalid - off;
         // ---- tag (reference :260): bases off.. of the read, as 64-bit words
         const uint32_t wo = off >> 4, sh = 2u * (off & 15u);
@@ -289,23 +349,28 @@ __global__ __launch_bounds__(BLOCK) void k_count(const KParams p) {
         };
         bool thit = false;
         uint32_t col = 0;
-        if (nrem >= p.m_bases) {
-            uint32_t slot = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.slot_mask;
-            for (uint32_t probes = 0; probes <= p.slot_mask; probes++) {
-                const uint4 *sp = p.slots + (size_t)slot * SLOT_U4;
-                uint32_t raw[SLOT_U4 * 4];
+        if (nrem >= p.m_bases && !(p.dbg & DBG_NO_PROBE)) {
+            uint32_t bk = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
+            for (uint32_t probes = 0; probes <= p.bucket_mask; probes++) {
+                const uint4 *bp = p.buckets + (size_t)bk * BUCKET_U4;
+                uint32_t raw[BUCKET_U4 * 4];
 #pragma unroll
-                for (int q = 0; q < SLOT_U4; q++) {
-                    uint4 v = sp[q];
+                for (int q = 0; q < BUCKET_U4; q++) {
+                    uint4 v = bp[q];
                     raw[4 * q] = v.x; raw[4 * q + 1] = v.y; raw[4 * q + 2] = v.z; raw[4 * q + 3] = v.w;
                 }
-                const uint32_t len = raw[2 * W];
-                if (len == 0) break;                       // empty slot: not in the table
-                uint64_t T[W];
 #pragma unroll
-                for (int w = 0; w < W; w++) T[w] = ((uint64_t)raw[2 * w + 1] << 32) | raw[2 * w];
-                if (len <= nrem && prefix_eq(T, len)) { thit = true; col = raw[2 * W + 1]; break; }
-                slot = (slot + 1) & p.slot_mask;
+                for (int sl = 0; sl < SPB; sl++) {
+                    const uint32_t meta2 = raw[1 + sl * SLOT_DW + 2 * W];
+                    const uint32_t len = meta2 & 1023u;
+                    uint64_t T[W];
+#pragma unroll
+                    for (int w = 0; w < W; w++)
+                        T[w] = ((uint64_t)raw[1 + sl * SLOT_DW + 2 * w + 1] << 32) | raw[1 + sl * SLOT_DW + 2 * w];
+                    if (len != 0 && len <= nrem && prefix_eq(T, len)) { thit = true; col = meta2 >> 10; }
+                }
+                if (thit || !(raw[0] & 1u)) break;      // found, or the bucket never overflowed
+                bk = (bk + 1) & p.bucket_mask;
             }
         }
         if (!thit) {
@@ -316,18 +381,16 @@ __global__ __launch_bounds__(BLOCK) void k_count(const KParams p) {
                 if (len <= nrem && ((R[0] ^ tv) >> (64u - 2u * len)) == 0) { thit = true; col = v.w; break; }
             }
         }
-        if (!thit) return;
-        st_tag++;
-        const size_t cell = (size_t)row * p.ncols + col;
-        if (TASSEL) __hip_atomic_fetch_add(p.counts64 + cell, weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_fetch_add(p.counts + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        TD_STAMP(10);   // tag hash probes (+ short list)
+        if (!thit) return R_BAR;
+        return R_TAG | ((uint64_t)row * p.ncols + col);
     };
 
     // tassel_tagcount (reference :251-253): hrel = start of a header line.  Parses
-    // int(line[line.find("count=")+6:].strip()), then counts the following line.
-    auto header_then_read = [&](uint64_t tbase, uint32_t hrel) {
+    // int(line[line.find("count=")+6:].strip()) and returns the position of the following
+    // line (or ~0 when there is none / the header is malformed).
+    auto parse_header = [&](uint64_t hs, unsigned long long &weight) -> uint64_t {
         auto gb = [&](uint64_t g) -> uint32_t { return g < p.nbytes ? p.buf[g] : 0x0Au; };
-        const uint64_t hs = tbase + hrel;
         uint64_t he = hs;
         while (he < p.nbytes && gb(he) != 0x0Au && gb(he) != 0x0Du) he++;
         uint64_t at = hs + 5;                       // find()==-1 -> slice [5:]
@@ -345,27 +408,34 @@ __global__ __launch_bounds__(BLOCK) void k_count(const KParams p) {
             uint32_t b = gb(q);
             if (b < '0' || b > '9') ok = false; else v = v * 10ull + (b - '0');
         }
-        if (!ok) { atomicOr(p.stats + ST_ERR, ERR_TASSEL); return; }
-        if (neg) v = 0ull - v;
-        // the sequence line follows the header's terminator, if the file goes on
-        uint64_t ss = he;
+        if (!ok) { atomicOr(p.stats + ST_ERR, ERR_TASSEL); return ~0ull; }
+        weight = neg ? 0ull - v : v;
+        uint64_t ss = he;                           // the sequence line follows the header's terminator
         if (ss < p.nbytes) { if (gb(ss) == 0x0Du && gb(ss + 1) == 0x0Au) ss += 2; else ss += 1; }
-        if (ss >= p.nbytes) return;
-        match_read(tbase, (uint32_t)(ss - tbase), v);
+        return ss < p.nbytes ? ss : ~0ull;
     };
 
+    uint32_t dbg_iter = 0;
     for (;;) {
-        if (tid == 0) { L_misc[0] = atomicAdd(p.ticket, 1u); L_misc[1] = 0; }
+        TD_STAMP(7);   // (tail of the previous tile)
+        if (tid == 0) {
+            L_misc[0] = (p.dbg & DBG_STATIC_TILES) ? blockIdx.x + (dbg_iter++) * gridDim.x : atomicAdd(p.ticket, 1u);
+            L_misc[1] = 0;
+        }
         __syncthreads();
         const uint32_t t = L_misc[0];
         if (t >= p.ntiles) break;
+        TD_STAMP(0);   // ticket
         const uint64_t tbase = (uint64_t)t * TILE;
 
-        // ---------------- phase 1a: stream the tile into LDS, terminator masks per chunk
-        {
-            uint4 v[CPT];
+        // ---------------- phase 1a: tile -> registers, terminator mask per chunk -> LDS
+        uint4 v[CPT];
+        uint4 vh = make_uint4(0u, 0u, 0u, 0u);         // this thread's chunk of the halo (halo <= 4 KiB)
+        const bool has_halo = (uint32_t)tid < halo_ch;
 #pragma unroll
-            for (int j = 0; j < CPT; j++) v[j] = load_chunk(p, tbase + (uint64_t)(j * BLOCK + tid) * 16u);
+        for (int j = 0; j < CPT; j++) v[j] = load_chunk(p, tbase + (uint64_t)(j * BLOCK + tid) * 16u);
+        if (has_halo) vh = load_chunk(p, tbase + (uint64_t)(TILE_CH + tid) * 16u);
+        {
             uint32_t hiacc = 0;
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
@@ -380,14 +450,13 @@ __global__ __launch_bounds__(BLOCK) void k_count(const KParams p) {
                 }
                 if (g + 16 > p.nbytes) term &= g < p.nbytes ? ((1u << (uint32_t)(p.nbytes - g)) - 1u) : 0u;
                 hiacc |= v[j].x | v[j].y | v[j].z | v[j].w;
-                *reinterpret_cast<uint4 *>(L_data + c * 16u) = v[j];
                 L_mask[c] = (uint16_t)term;
             }
-            for (uint32_t c = TILE_CH + tid; c * 16u < win; c += BLOCK)
-                *reinterpret_cast<uint4 *>(L_data + c * 16u) = load_chunk(p, tbase + (uint64_t)c * 16u);
             if (hiacc & 0x80808080u) L_misc[1] = 1;
         }
+        TD_STAMP(1);   // tile load + terminator masks
         __syncthreads();
+        TD_STAMP(2);   // barrier (other waves' loads)
 
         const bool tile_has_hi = L_misc[1] != 0;
         // ---------------- phase 1b: terminators of this thread's CPT consecutive chunks
@@ -399,80 +468,29 @@ __global__ __launch_bounds__(BLOCK) void k_count(const KParams p) {
         for (int i = 0; i < CPT / 2; i++) cnt += __builtin_popcount(mm[i]);
         uint32_t incl = wave_incl_scan(cnt, lane);
         if (lane == 63) L_misc[4 + wave] = incl;
-        __syncthreads();
+        __syncthreads();                               // (also: every thread now holds its masks; L_tlist may overwrite them)
         uint32_t wbase = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; w++) { uint32_t x = L_misc[4 + w]; if (w < wave) wbase += x; total += x; }
         const uint32_t excl = wbase + incl - cnt;
+        TD_STAMP(3);   // block scan
 
-        // ---------------- decoupled look-back: terminators before this tile
-        if (tid == 0 && !p.prefilled) st_state(p.state + t, FLAG_AGG | total);
-        uint64_t P = 0;
-        {
-            int64_t base = t;
-            for (;;) {
-                const int64_t idx = base - 1 - tid;
-                uint64_t s = FLAG_INC;
-                if (idx >= 0) {
-                    s = ld_state(p.state + idx);
-                    uint32_t spins = 0;
-                    while ((s >> 62) == 0) {
-                        __builtin_amdgcn_s_sleep(2);
-                        s = ld_state(p.state + idx);
-                        if (++spins > SPIN_LIMIT) { atomicOr(p.stats + ST_ERR, ERR_SPIN); s = FLAG_INC; break; }
-                    }
-                }
-                const bool inc = (s >> 62) == 2;
-                const uint64_t b = __ballot(inc);
-                const int f = b ? __builtin_ctzll(b) : 64;
-                const uint64_t ws = wave_sum64(lane <= f ? (s & VAL_MASK) : 0ull);
-                if (lane == 0) { L_misc64[wave] = ws; L_misc[8 + wave] = b ? 1u : 0u; }
-                __syncthreads();
-                bool done = false;
+        // ---------------- decoupled look-back, part 1: publish, then put the state loads in flight
+        const bool no_lb = (p.dbg & DBG_NO_LOOKBACK) != 0;
+        if (tid == 0 && !p.prefilled && !no_lb) st_state(p.state + t, FLAG_AGG | total);
+        uint64_t s[LBQ];
 #pragma unroll
-                for (int w = 0; w < BLOCK / 64; w++) {
-                    if (!done) { P += L_misc64[w]; done = L_misc[8 + w] != 0; }
-                }
-                __syncthreads();
-                if (done) break;
-                base -= BLOCK;
-            }
-        }
-        if (tid == 0 && !p.prefilled) st_state(p.state + t, FLAG_INC | (P + total));
-        if (tid == 0) {
-            st_lines += total;
-            if (p.cursor_out && t == p.ntiles - 1) *p.cursor_out = carried + P + total;
+        for (int q = 0; q < LBQ; q++) {
+            const int64_t idx = (int64_t)t - 1 - (q * BLOCK + tid);
+            s[q] = (idx >= 0 && !no_lb) ? ld_state(p.state + idx) : FLAG_INC;
         }
 
-        const uint64_t Lb = first_line + P + excl;   // index of the line this thread's span starts in
-        const uint32_t span0 = tid * CPT * 16u;
-        const uint32_t want = TASSEL ? 0u : 1u;         // line phase that starts a unit of work
-        const uint64_t lim = TASSEL ? p.limit_line - 1 : p.limit_line;
-
-        // ---------------- rare: bytes >= 0x80 in the tile -- are any inside a counted sequence line?
-        if (tile_has_hi) {
-            uint32_t seen = 0;
-#pragma nounroll
-            for (uint32_t q = 0; q < CPT * 16u; q++) {
-                const uint32_t rel = span0 + q;
-                if (L_data[rel] >= 0x80u && tbase + rel < p.nbytes) {
-                    const uint64_t line = Lb + seen;
-                    if ((line & 3) == 1 && line <= p.limit_line) atomicOr(p.stats + ST_ERR, ERR_NONASCII);
-                }
-                seen += (L_mask[rel >> 4] >> (rel & 15u)) & 1u;
-            }
-        }
-
-        // ---------------- lines to process.  In-tile terminator ordinal i (0-based) is followed by
-        // line first_line+P+i+1, so the wanted lines follow the ordinals i == r0 (mod 4) and the
-        // j-th of them gets list slot j: no scan, no atomics.  Slot 0 of tile 0 is the buffer's
-        // first line.  The list is processed in rounds of RLIST_CAP (one round for sane input).
-        const uint32_t r0 = (want + 3u - (uint32_t)((first_line + P) & 3)) & 3u;
-        const uint32_t extra = t == 0 ? 1u : 0u;
-        const uint32_t nslots = extra + (total > r0 ? (total - r0 + 3u) / 4u : 0u);
-        for (uint32_t rbase = 0; rbase < nslots; rbase += RLIST_CAP) {
-            if (t == 0 && tid == 0 && rbase == 0)
-                L_rlist[0] = (p.nbytes > 0 && (first_line & 3) == want && first_line <= lim) ? (uint16_t)0 : (uint16_t)0xFFFF;
+        // ---------------- phase 1c (under the look-back latency): pack every chunk, list the line starts
+        if (!(p.dbg & DBG_NO_PACK))
+#pragma unroll
+        for (int j = 0; j < CPT; j++) L_conv[j * BLOCK + tid] = convert_chunk(v[j]);
+        if (has_halo) L_conv[TILE_CH + tid] = convert_chunk(vh);
+        auto list_terminators = [&](uint32_t rbase) {
             uint32_t i = excl;
 #pragma unroll
             for (int k = 0; k < CPT / 2; k++) {
@@ -480,29 +498,171 @@ __global__ __launch_bounds__(BLOCK) void k_count(const KParams p) {
                 while (m) {
                     const uint32_t bit = __builtin_ctz(m);
                     m &= m - 1;
-                    if ((i & 3u) == r0) {
-                        const uint32_t slot = extra + ((i - r0) >> 2);
-                        if (slot >= rbase && slot < rbase + RLIST_CAP) {
-                            const uint64_t line = first_line + P + i + 1;
-                            const uint32_t srel = span0 + 32u * k + bit + 1u;
-                            const bool ok = line <= lim && tbase + srel < p.nbytes;
-                            L_rlist[slot - rbase] = ok ? (uint16_t)srel : (uint16_t)0xFFFF;
-                        }
-                    }
+                    if (i >= rbase && i < rbase + TLIST_CAP) L_tlist[i - rbase] = (uint16_t)(tid * CPT * 16u + 32u * k + bit + 1u);
                     i++;
                 }
             }
-            __syncthreads();
-            // ------------ phase 2: one lane per line
-            const uint32_t n = min(nslots - rbase, (uint32_t)RLIST_CAP);
-            for (uint32_t e = tid; e < n; e += BLOCK) {
-                const uint32_t srel = L_rlist[e];
-                if (srel != 0xFFFFu) {
-                    if (TASSEL) header_then_read(tbase, srel);
-                    else match_read(tbase, srel, 1ull);
+        };
+        list_terminators(0);
+        TD_STAMP(5);   // pack + list
+
+        __syncthreads();                               // packed chunks and the line-start list are visible
+        TD_STAMP(2);
+
+        // ---------------- phase 2, speculative: every listed line start is matched NOW, whatever its
+        // line phase (headers, '+' and quality lines fail at their first byte), while the look-back
+        // loads are in flight and the predecessors publish.  Then the look-back resolves the phase and
+        // only the wanted lines are committed.  Lines whose raw bytes are needed (R_DEFER: first byte
+        // not a base, or window beyond the staged chunks) are resolved after the look-back, as is
+        // everything in tassel mode and in batches beyond the first (pathological line density).
+        const uint32_t want = TASSEL ? 0u : 1u;         // line phase that starts a unit of work
+        const uint64_t lim = TASSEL ? p.limit_line - 1 : p.limit_line;
+        // tile 0 owns the buffer's first line: a virtual terminator with in-tile ordinal -1 (item 0)
+        const uint32_t extra = (t == 0 && p.nbytes > 0) ? 1u : 0u;
+        const uint32_t nitems = total + extra;
+        uint64_t P = 0;
+        uint32_t r0 = 0;
+        uint32_t rbase = 0;                             // first ordinal held in L_tlist
+        for (uint32_t b0 = 0; b0 == 0 || b0 < nitems; b0 += IPL * BLOCK) {
+            if (b0) {                                   // next stretch of line starts
+                rbase = b0 - extra;
+                __syncthreads();
+                list_terminators(rbase);
+                __syncthreads();
+            }
+            uint64_t res[IPL];
+            uint32_t sr[IPL];
+            unsigned long long wgt[IPL];
+#pragma unroll
+            for (int k = 0; k < IPL; k++) { res[k] = R_DEFER; sr[k] = 0xFFFFFFFFu; wgt[k] = 1ull; }
+            uint32_t tried = 0;                         // bit k: item k went through the speculative pass
+#pragma nounroll
+            for (int pass = (b0 == 0 && !TASSEL) ? 0 : 1; pass < 2; pass++) {
+                if (pass == 1 && b0 == 0) {
+                    // ------------ look-back, part 2: terminators before this tile
+                    int64_t base = t;
+                    for (;;) {
+#pragma unroll
+                        for (int q = 0; q < LBQ; q++) {
+                            const int64_t idx = base - 1 - (q * BLOCK + tid);
+                            uint32_t spins = 0;
+                            while ((s[q] >> 62) == 0) {
+                                __builtin_amdgcn_s_sleep(1);
+                                s[q] = ld_state(p.state + idx);
+                                if (++spins > SPIN_LIMIT) { atomicOr(p.stats + ST_ERR, ERR_SPIN); s[q] = FLAG_INC; break; }
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < LBQ; q++) {
+                            const uint64_t b = __ballot((s[q] >> 62) == 2);
+                            const int f = b ? __builtin_ctzll(b) : 64;
+                            const uint64_t ws = wave_sum64(lane <= f ? (s[q] & VAL_MASK) : 0ull);
+                            if (lane == 0) { L_misc64[q * 4 + wave] = ws; L_misc[8 + q * 4 + wave] = b ? 1u : 0u; }
+                        }
+                        __syncthreads();
+                        bool done = false;
+#pragma unroll
+                        for (int w = 0; w < LBQ * (BLOCK / 64); w++) {
+                            if (!done) { P += L_misc64[w]; done = L_misc[8 + w] != 0; }
+                        }
+                        __syncthreads();
+                        if (done) break;
+                        base -= LBQ * BLOCK;
+#pragma unroll
+                        for (int q = 0; q < LBQ; q++) {
+                            const int64_t idx = base - 1 - (q * BLOCK + tid);
+                            s[q] = idx >= 0 ? ld_state(p.state + idx) : FLAG_INC;
+                        }
+                    }
+                    if (tid == 0 && !p.prefilled && !no_lb) st_state(p.state + t, FLAG_INC | (P + total));
+                    TD_STAMP(4);   // look-back (what phase 2 did not hide)
+                    if (tid == 0) {
+                        st_lines += total;
+                        if (p.cursor_out && t == p.ntiles - 1) *p.cursor_out = carried + P + total;
+                    }
+                    // in-tile terminator ordinal i is followed by line first_line+P+i+1: the wanted
+                    // lines follow the ordinals i == r0 (mod 4)
+                    r0 = (want + 3u - (uint32_t)((first_line + P) & 3)) & 3u;
+                }
+#pragma nounroll
+                for (int k = 0; k < IPL; k++) {
+                    // lanes take 4 consecutive items each, so one k = one line phase across the wave:
+                    // three of the four rounds end at the first byte for (almost) every lane
+                    const uint32_t e = b0 + IPL * tid + k;
+                    if (e >= nitems || (p.dbg & DBG_NO_PHASE2)) continue;
+                    const bool first_item = e < extra;
+                    const uint32_t i = e - extra;                    // in-tile ordinal of the terminator before the line (-1: none)
+                    uint32_t srk = k == 0 ? sr[0] : k == 1 ? sr[1] : k == 2 ? sr[2] : sr[3];
+                    uint64_t rk = k == 0 ? res[0] : k == 1 ? res[1] : k == 2 ? res[2] : res[3];
+                    unsigned long long wk = 1ull;
+                    bool run = false, slow = false;
+                    uint64_t gpos = 0;
+                    if (pass == 0) {
+                        srk = first_item ? 0u : L_tlist[i - rbase];
+                        gpos = tbase + srk;
+                        run = gpos < p.nbytes;
+                        tried |= 1u << k;
+                    } else {
+                        if (srk == 0xFFFFFFFFu) srk = first_item ? 0u : L_tlist[i - rbase];
+                        gpos = tbase + srk;
+                        const bool wanted = (i & 3u) == r0 && first_line + P + e + 1 - extra <= lim && gpos < p.nbytes;
+                        if (!wanted) { srk = 0xFFFFFFFEu; }
+                        else if ((rk >> 62) == 3) {                  // not settled by the speculative pass
+                            run = slow = true;
+                            if (TASSEL) {
+                                gpos = parse_header(gpos, wk);
+                                if (gpos == ~0ull) { srk = 0xFFFFFFFEu; run = false; }   // no sequence line follows
+                            } else if ((tried >> k) & 1u) {
+                                // deferred by the fast path: a non-blank non-base first byte inside the
+                                // staged window is simply "no barcode"
+                                if (!is_blank(p.buf[gpos]) && (srk >> 4) + p.nch <= win_ch) { run = false; rk = R_NONE; }
+                            }
+                        }
+                    }
+                    if (run) rk = match_read(gpos, srk, slow);
+                    if (k == 0) { sr[0] = srk; res[0] = rk; wgt[0] = wk; }
+                    else if (k == 1) { sr[1] = srk; res[1] = rk; wgt[1] = wk; }
+                    else if (k == 2) { sr[2] = srk; res[2] = rk; wgt[2] = wk; }
+                    else { sr[3] = srk; res[3] = rk; wgt[3] = wk; }
                 }
             }
-            __syncthreads();
+            // ------------ commit the wanted lines of this batch
+#pragma unroll
+            for (int k = 0; k < IPL; k++) {
+                if (sr[k] >= 0xFFFFFFFEu) continue;                  // no item, or not a wanted line
+                st_reads++;
+                const uint32_t kind = (uint32_t)(res[k] >> 62);
+                if (kind >= 1) st_bar++;
+                if (kind == 2) {
+                    st_tag++;
+                    if (!(p.dbg & DBG_NO_ATOMIC)) {
+                        const size_t cell = (size_t)(res[k] & R_CELL);
+                        if (TASSEL) __hip_atomic_fetch_add(p.counts64 + cell, wgt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else __hip_atomic_fetch_add(p.counts + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            TD_STAMP(6);   // phase 2 + commit
+        }
+
+        // ---------------- rare: bytes >= 0x80 in the tile -- are any inside a counted sequence line?
+        if (tile_has_hi) {
+            const uint64_t Lb = first_line + P + excl;   // index of the line this thread's span starts in
+            const uint32_t span0 = tid * CPT * 16u;
+            uint32_t seen = 0;
+#pragma unroll
+            for (int k = 0; k < CPT / 2; k++) {
+                const uint32_t m = mm[k];
+#pragma nounroll
+                for (uint32_t q = 0; q < 32u; q++) {
+                    const uint64_t g = tbase + span0 + 32u * k + q;
+                    if (g < p.nbytes && p.buf[g] >= 0x80u) {
+                        const uint64_t line = Lb + seen;
+                        if ((line & 3) == 1 && line <= p.limit_line) atomicOr(p.stats + ST_ERR, ERR_NONASCII);
+                    }
+                    seen += (m >> q) & 1u;
+                }
+            }
         }
     }
 
@@ -514,6 +674,10 @@ __global__ __launch_bounds__(BLOCK) void k_count(const KParams p) {
         if (g) atomicAdd(p.stats + ST_TAG, g);
         if (l) atomicAdd(p.stats + ST_LINES, l);
     }
+#ifdef TD_PHASE_PROF
+    if (tid == 0)
+        for (int i = 0; i < PROF_PHASES; i++) atomicAdd(p.stats + 8 + i, prof_acc[i]);
+#endif
 }
 
 // ---------------------------------------------------------------- terminator count only

@@ -121,6 +121,7 @@ template <typename T> struct DevBuf {
 constexpr int W_CHOICES[] = {1, 2, 3, 4, 6, 10};
 constexpr uint32_t MAX_SHORT = 16;
 constexpr size_t LDS_BUDGET = 64 * 1024;     // per workgroup
+constexpr size_t STATS_SLOTS = 32;           // TD_STAT_NSTATS public + diagnostic counters
 
 }  // namespace
 
@@ -132,7 +133,7 @@ struct td_handle {
     bool have_index = false;
     uint32_t barnum = 0, ntags = 0;
     int W = 2;
-    uint32_t nch = 0, maxwo = 0, halo = 128, m_bases = 32, nshort = 0, slot_mask = 0;
+    uint32_t nch = 0, maxwo = 0, halo = 128, m_bases = 32, nshort = 0, bucket_mask = 0;
     uint32_t bblob_bytes = 0, off_bmeta = 0, off_bdir = 0, off_bcand = 0;
     DevBuf<uint32_t> d_bblob;
     DevBuf<uint4> d_slots, d_shorts;
@@ -149,7 +150,8 @@ struct td_handle {
     DevBuf<uint32_t> d_ticket;
     DevBuf<unsigned long long> d_cursor;      // [2] line cursor for streamed pieces
     // options
-    int tile_kb = 16, blocks_per_cu = 0, prescan = 0, timing = 0;
+    int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0;
+    uint32_t debug_ablate = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
@@ -175,14 +177,15 @@ KFn pick_kernel(int tile_kb, int W, bool tassel) {
 }
 
 size_t lds_bytes(const td_handle *h, int tile_kb) {
-    size_t tile = (size_t)tile_kb * 1024;
-    return tile + h->halo + tile / 16 * 2 + tdk::RLIST_CAP * 2 + 256 + h->bblob_bytes;
+    // packed chunks (8 B per 16 bytes of tile + halo) | masks / line-start list | misc | barcode index
+    size_t tile_ch = (size_t)tile_kb * 1024 / 16, halo_ch = h->halo / 16;
+    return (tile_ch + halo_ch) * 8 + std::max<size_t>(tile_ch * 2, tdk::TLIST_CAP * 2) + 256 + h->bblob_bytes;
 }
 
 int zero_results(td_handle *h) {
     if (h->d_counts.p) HIPCHK(hipMemsetAsync(h->d_counts.p, 0, (size_t)h->barnum * h->ntags * 4, h->work_stream));
     if (h->d_counts64.p) HIPCHK(hipMemsetAsync(h->d_counts64.p, 0, (size_t)h->barnum * h->ntags * 8, h->work_stream));
-    HIPCHK(hipMemsetAsync(h->d_stats.p, 0, TD_STAT_NSTATS * 8, h->work_stream));
+    HIPCHK(hipMemsetAsync(h->d_stats.p, 0, STATS_SLOTS * 8, h->work_stream));
     HIPCHK(hipStreamSynchronize(h->work_stream));
     std::fill(h->host_acc.begin(), h->host_acc.end(), 0);
     h->bytes_since_flush = 0;
@@ -240,12 +243,13 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     p.state = h->d_state.p; p.ticket = h->d_ticket.p; p.ntiles = ntiles; p.halo = h->halo;
     p.bblob = h->d_bblob.p; p.bblob_bytes = h->bblob_bytes; p.off_bmeta = h->off_bmeta;
     p.off_bdir = h->off_bdir; p.off_bcand = h->off_bcand;
-    p.slots = h->d_slots.p; p.slot_mask = h->slot_mask; p.m_bases = h->m_bases;
+    p.buckets = h->d_slots.p; p.bucket_mask = h->bucket_mask; p.m_bases = h->m_bases;
     p.shorts = h->d_shorts.p; p.nshort = h->nshort;
     p.counts = h->bound_counts ? h->bound_counts : h->d_counts.p; p.counts64 = h->d_counts64.p;
     p.ncols = h->ntags; p.stats = h->d_stats.p; p.nch = h->nch; p.maxwo = h->maxwo;
     p.prefilled = h->prescan ? 1u : 0u;
     p.cursor_in = cursor_in; p.cursor_out = cursor_out;
+    p.dbg = h->debug_ablate;
 
     HIPCHK(hipMemsetAsync(h->d_ticket.p, 0, 4, stream));
     if (h->prescan) {
@@ -321,10 +325,10 @@ int td_create(td_handle **out, int device_id) {
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->work_stream, hipStreamNonBlocking));
-    int rc = h->d_stats.ensure(TD_STAT_NSTATS); if (rc) { delete h; return rc; }
+    int rc = h->d_stats.ensure(STATS_SLOTS); if (rc) { delete h; return rc; }
     rc = h->d_ticket.ensure(4); if (rc) { delete h; return rc; }
     rc = h->d_cursor.ensure(2); if (rc) { delete h; return rc; }
-    HIPCHK(hipMemset(h->d_stats.p, 0, TD_STAT_NSTATS * 8));
+    HIPCHK(hipMemset(h->d_stats.p, 0, STATS_SLOTS * 8));
     *out = h;
     return TD_OK;
 }
@@ -410,10 +414,16 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
     uint32_t m = 32;
     if (lens.size() > MAX_SHORT) m = std::min<uint32_t>(32, lens[MAX_SHORT]);
     m = std::max<uint32_t>(m, 1);
-    const int slot_u4 = (W + 2) / 2;
-    size_t nslots = 16;
-    while (nslots < 2 * rt.out.size()) nslots <<= 1;
-    std::vector<uint32_t> slots(nslots * slot_u4 * 4, 0);
+    // buckets: dword 0 = overflow flag, then SPB slots of {W x u64, u32 meta = col<<10 | len}
+    if (ntags >= (1u << 22)) return fail(TD_E_LIMIT, "more than 4M tags");
+    const int bucket_dw = W <= 3 ? 16 : 32;
+    const int slot_dw = 2 * W + 1;
+    const int spb = (bucket_dw - 1) / slot_dw;
+    size_t nlong = 0;
+    for (auto &t : rt.out) if (t.first.size() >= m) nlong++;
+    size_t nbuckets = 16;
+    while (nbuckets * spb < 2 * nlong) nbuckets <<= 1;
+    std::vector<uint32_t> slots(nbuckets * bucket_dw, 0);
     std::vector<uint32_t> shorts;
     std::vector<uint64_t> words(W);
     for (auto &t : rt.out) {
@@ -424,13 +434,24 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
             shorts.push_back(L); shorts.push_back(t.second);
             continue;
         }
-        size_t s = hash_key(words[0] >> (64 - 2 * m)) & (nslots - 1);
-        while (slots[s * slot_u4 * 4 + 2 * W] != 0) s = (s + 1) & (nslots - 1);
-        uint32_t *sp = &slots[s * slot_u4 * 4];
-        for (int w = 0; w < W; w++) { sp[2 * w] = (uint32_t)words[w]; sp[2 * w + 1] = (uint32_t)(words[w] >> 32); }
-        sp[2 * W] = L; sp[2 * W + 1] = t.second;
+        size_t b = hash_key(words[0] >> (64 - 2 * m)) & (nbuckets - 1);
+        for (;;) {
+            uint32_t *bp = &slots[b * bucket_dw];
+            int free_slot = -1;
+            for (int k = 0; k < spb; k++) if (bp[1 + k * slot_dw + 2 * W] == 0) { free_slot = k; break; }
+            if (free_slot >= 0) {
+                uint32_t *sp = bp + 1 + free_slot * slot_dw;
+                for (int w = 0; w < W; w++) { sp[2 * w] = (uint32_t)words[w]; sp[2 * w + 1] = (uint32_t)(words[w] >> 32); }
+                sp[2 * W] = (t.second << 10) | L;
+                break;
+            }
+            bp[0] |= 1u;                      // full: lookups that miss here must go on
+            b = (b + 1) & (nbuckets - 1);
+        }
     }
-    h->W = W; h->m_bases = m; h->slot_mask = (uint32_t)(nslots - 1); h->nshort = (uint32_t)(shorts.size() / 4);
+    const size_t nslots = nbuckets;           // (device buffer sized in uint4 below)
+    const int slot_u4 = bucket_dw / 4;
+    h->W = W; h->m_bases = m; h->bucket_mask = (uint32_t)(nbuckets - 1); h->nshort = (uint32_t)(shorts.size() / 4);
     h->maxwo = max_off >> 4;
     const uint32_t need = 15 + max_off + (uint32_t)maxlen;
     h->nch = std::min<uint32_t>(2 * W + 3, std::max<uint32_t>(3, (need + 15) / 16));
@@ -685,6 +706,14 @@ int td_get_counts(td_handle *h, uint64_t *out) {
     return TD_OK;
 }
 
+int td_debug_counters(td_handle *h, uint64_t out[24]) {
+    if (!h || !out) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, h->d_stats.p + 8, 24 * 8, hipMemcpyDeviceToHost));
+    return TD_OK;
+}
+
 int td_set_option(td_handle *h, const char *name, int64_t value) {
     if (!h || !name) return fail(TD_E_ARG, "NULL argument");
     std::string n(name);
@@ -695,6 +724,7 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     } else if (n == "blocks_per_cu") h->blocks_per_cu = (int)value;
     else if (n == "prescan") h->prescan = value ? 1 : 0;
     else if (n == "timing") h->timing = value ? 1 : 0;
+    else if (n == "debug_ablate") h->debug_ablate = (uint32_t)value;   // timing-only ablations, wrong results
     else return fail(TD_E_ARG, "unknown option " + n);
     return TD_OK;
 }

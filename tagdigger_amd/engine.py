@@ -179,6 +179,11 @@ class Engine:
         return np.frombuffer(flat, dtype=np.uint64, count=self.barnum * self.ntags).reshape(
             self.barnum, self.ntags).copy()
 
+    def debug_counters(self):
+        out = (C.c_uint64 * 24)()
+        B.check(self._L.td_debug_counters(self._h, out))
+        return list(out)
+
     def kernel_time_ms(self):
         ms = C.c_double(0)
         n = C.c_uint32(0)

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a tile's time go?  Runs the phase-stamp build
+(libtagdig_prof.so, `make -C tagdigger_amd/csrc prof`) over a synthetic library
+and prints each phase's share of workgroup time.  Shares only -- the stamped
+build's run time is never quoted as a result."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("TAGDIG_LIB", os.path.join(ROOT, "tagdigger_amd", "libtagdig_prof.so"))
+sys.path.insert(0, ROOT)
+
+NAMES = ["ticket", "load+masks+LDS store", "barrier after load", "block scan", "look-back",
+         "emission", "phase 2 (match)", "loop tail",
+         "  p2: fetch+convert", "  p2: barcode", "  p2: tag probes", "-"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=50_000_000)
+    ap.add_argument("--barcodes", type=int, default=384)
+    ap.add_argument("--markers", type=int, default=50_000)
+    ap.add_argument("--tile-kb", type=int, default=16)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--prescan", type=int, default=0)
+    a = ap.parse_args()
+    import tagdigger_amd
+    from tagdigger_amd.synth import SynthConfig
+    cfg = SynthConfig(nreads=a.reads, nbar=a.barcodes, nmarkers=a.markers, seed=3)
+    eng = tagdigger_amd.Engine(0)
+    d = eng.dev_alloc(cfg.nbytes())
+    cfg.fill_device(eng, d, 0, cfg.nreads)
+    eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+    eng.set_option("tile_kb", a.tile_kb)
+    eng.set_option("prescan", a.prescan)
+    if a.blocks_per_cu:
+        eng.set_option("blocks_per_cu", a.blocks_per_cu)
+    eng.count_device(d, cfg.nbytes())       # warm
+    eng.reset()
+    eng.set_option("timing", 1)
+    eng.count_device(d, cfg.nbytes())
+    ms, _ = eng.kernel_time_ms()
+    c = eng.debug_counters()[:12]
+    tot = float(sum(c[:8])) or 1.0
+    ntiles = (cfg.nbytes() + a.tile_kb * 1024 - 1) // (a.tile_kb * 1024)
+    print("tile_kb=%d blocks_per_cu=%s prescan=%d  kernel %.2f ms (stamped build)  tiles=%d" % (
+        a.tile_kb, a.blocks_per_cu or "auto", a.prescan, ms, ntiles))
+    for n, v in zip(NAMES, c):
+        print("  %-24s %6.2f %%   %8.0f cycles/tile" % (n, 100.0 * v / tot, v / ntiles))
+    print("  %-24s            %8.0f cycles/tile" % ("total", tot / ntiles))
+    eng.dev_free(d)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
