@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--stagger", type=int, default=-1)
     ap.add_argument("--debug-ablate", type=int, default=0, help="timing-only kernel ablation bits (implies --no-check)")
     args = ap.parse_args()
 
@@ -73,6 +74,8 @@ def main():
         eng.set_option("tile_kb", args.tile_kb)
     if args.blocks_per_cu:
         eng.set_option("blocks_per_cu", args.blocks_per_cu)
+    if args.stagger >= 0:
+        eng.set_option("stagger", args.stagger)
     if args.debug_ablate:
         eng.set_option("debug_ablate", args.debug_ablate)
         args.no_check = True
@@ -126,6 +129,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kms, klaunches = eng.kernel_time_ms()
+    fixups = eng.debug_counters()[12]
     eng.set_option("timing", 0)
 
     if world > 1:
@@ -166,7 +170,7 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "tdk::k_count", "kernel_ms": kms, "kernel_launches": klaunches,
+                         "kernel": "tdk::k_fast (+k_resolve, fix-up pass)", "kernel_ms": kms, "fixup_queue": fixups, "kernel_launches": klaunches,
                          "algorithmic_bytes_per_launch": algo_bytes},
             "check": check,
         }

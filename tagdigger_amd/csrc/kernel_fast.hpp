@@ -1,0 +1,428 @@
+// The free-running variant of the count kernel: no tickets, no look-back, no waiting.
+//
+// The only thing that couples one tile of FASTQ to the bytes before it is the line phase
+// (lineindex % 4 of reference tagdigger_fun.py:254).  k_count resolves it exactly in flight
+// (decoupled look-back); that makes every tile wait for the slowest of ~1000 predecessors.
+// Here each tile instead
+//   1. PREDICTS its phase from its own content: per line phase, how many lines open with eight
+//      valid bases -- sequence lines do, headers ('@'), '+' lines and quality strings do not;
+//   2. counts under that prediction, and records its terminator count and the prediction;
+// then k_resolve scans the per-tile terminator counts (a few hundred thousand words), derives
+// every tile's TRUE phase, and queues a correction for every tile whose prediction was wrong
+// (also for tiles that reach past the maxreads limit, and for tiles holding bytes >= 0x80);
+// finally k_fast runs again over that queue in fix-up mode, subtracting what was counted under
+// the wrong phase and adding the right one.  The result is bit-exact for ANY input; only the
+// speed depends on the prediction, and on well-formed FASTQ the queue is empty.
+//
+// Per tile (tile = CPT*4 KiB, one workgroup of 256 threads; the next tile's bytes are already
+// in flight into registers while this one is processed):
+//   A  masks (line terminators) + 2-bit packing of every 16-byte chunk, all lanes   -> LDS
+//   B  block scan of terminator counts: in-tile ordinal of every terminator
+//   C  phase vote (LDS counters), or the given phase in fix-up mode
+//   D  each thread matches the wanted lines that start in its own 16*CPT-byte span
+//      (match_line: barcode directory in LDS, tag buckets in L2) and commits with atomics
+#pragma once
+#include "kernels.hpp"
+
+namespace tdk {
+
+constexpr uint32_t TI_COUNT_MASK = 0xFFFFFFu;   // tile_info: terminators in the tile
+constexpr uint32_t TI_R0_SHIFT = 24;            //            phase (r0) the tile was counted under
+constexpr uint32_t TI_HI = 1u << 26;            //            tile holds a byte >= 0x80
+// fix-up queue entry: {tile, code, P lo, P hi}; code = r0 | flags
+constexpr uint32_t FX_NEG = 4;                  // subtract instead of add
+constexpr uint32_t FX_LIMIT = 8;                // apply the maxreads limit (needs P)
+constexpr uint32_t FX_HICHECK = 16;             // only look for bytes >= 0x80 inside counted sequence lines
+constexpr uint32_t FX_PREDICT = 32;             // (main pass) predict the phase
+
+struct FParams {
+    KParams k;
+    uint32_t *tile_info;     // [ntiles]
+    uint4 *fixlist;          // [fix_cap]
+    uint32_t *nfix;
+    uint32_t fix_cap;
+    uint32_t mode;           // 0 main pass over all tiles, 1 fix-up pass over the queue
+};
+
+template <int CPT, int W>
+__global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams fp) {
+    const KParams &p = fp.k;
+    constexpr int TILE_CH = CPT * BLOCK;
+    constexpr uint32_t TILE = TILE_CH * 16;
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t halo_ch = p.halo / 16u;
+    const uint32_t win_ch = TILE_CH + halo_ch;
+    uint2 *L_conv = reinterpret_cast<uint2 *>(lds);
+    uint16_t *L_mask = reinterpret_cast<uint16_t *>(lds + (size_t)win_ch * 8u);
+    uint32_t *L_misc = reinterpret_cast<uint32_t *>(lds + (size_t)win_ch * 8u + TILE_CH * 2u);   // 64 dwords
+    uint8_t *L_bidx = reinterpret_cast<uint8_t *>(L_misc + 64);
+    const TileCtx cx{L_conv, win_ch, reinterpret_cast<const unsigned long long *>(L_bidx),
+                     reinterpret_cast<const uint32_t *>(L_bidx + p.off_bmeta),
+                     reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir),
+                     reinterpret_cast<const uint16_t *>(L_bidx + p.off_bcand)};
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t i = tid; i < p.bblob_bytes / 4; i += BLOCK)
+        reinterpret_cast<uint32_t *>(L_bidx)[i] = p.bblob[i];
+    if (tid < 8) L_misc[16 + tid] = 0;              // vote counters (two banks of four)
+    if (tid == 0) L_misc[1] = 0;
+
+    long long st_reads = 0, st_bar = 0, st_tag = 0;
+#ifdef TD_PHASE_PROF
+    unsigned long long prof_acc[PROF_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#endif
+    const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
+    const uint64_t first_line = p.first_line + carried;
+    const uint32_t nwork = fp.mode ? min(*fp.nfix, fp.fix_cap) : p.ntiles;
+
+    // work item -> tile, code, P
+    uint32_t it = blockIdx.x;
+    uint32_t t = 0, code = FX_PREDICT;
+    uint64_t Pg = 0;
+    auto fetch_item = [&](uint32_t w, uint32_t &tt, uint32_t &cc, uint64_t &pp) {
+        if (w >= nwork) return;
+        if (fp.mode) { const uint4 e = fp.fixlist[w]; tt = e.x; cc = e.y; pp = ((uint64_t)e.w << 32) | e.z; }
+        else { tt = w; cc = FX_PREDICT; pp = 0; }
+    };
+    uint4 v[CPT];
+    uint4 vh = make_uint4(0u, 0u, 0u, 0u);
+    const bool has_halo = (uint32_t)tid < halo_ch;
+    // One uniform bounds test per tile: every tile but the buffer's last is loaded with plain,
+    // independent 16-byte loads (a per-chunk test makes the compiler serialise them).
+    auto fetch_tile = [&](uint32_t tile) {
+        const uint64_t b = (uint64_t)tile * TILE;
+        if (b + TILE + p.halo <= p.nbytes) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.buf + b);
+#pragma unroll
+            for (int j = 0; j < CPT; j++) v[j] = src[j * BLOCK + tid];
+            if (has_halo) vh = src[TILE_CH + tid];
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) v[j] = load_chunk(p, b + (uint64_t)(j * BLOCK + tid) * 16u);
+            if (has_halo) vh = load_chunk(p, b + (uint64_t)(TILE_CH + tid) * 16u);
+        }
+    };
+    fetch_item(it, t, code, Pg);
+    // Stagger the workgroups that share a CU so that their compute-bound (A) and latency-bound (D)
+    // phases interleave instead of marching in lockstep: co-resident workgroups are (observed, for
+    // speed only) blockIdx apart by the number of CUs.
+    if (p.stagger) {
+        const uint32_t slot = (blockIdx.x / p.stagger_div) & 3u;
+        for (uint32_t q = 0; q < slot * p.stagger; q++) __builtin_amdgcn_s_sleep(64);   // 64*64 cycles each
+    }
+    if (it < nwork) fetch_tile(t);
+    __syncthreads();
+
+    uint32_t parity = 0;                             // which bank of vote counters this tile uses
+    while (it < nwork) {
+        const uint64_t tbase = (uint64_t)t * TILE;
+        TD_STAMP(0);   // loop head
+
+        // ---------------- A: terminator masks + packing of every chunk, from registers.  A wave whose
+        // chunks are all inside the buffer, all ASCII and free of '\r' (the normal case) takes the
+        // short forms; any other wave redoes its chunks with the exact general forms.
+        {
+            uint32_t hiacc = 0;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) hiacc |= v[j].x | v[j].y | v[j].z | v[j].w;
+            const bool inside = tbase + TILE + p.halo <= p.nbytes;
+            uint32_t cr_absent = 0x80808080u;
+            bool general = !inside || __any((hiacc & 0x80808080u) != 0);
+            if (!general) {
+                uint32_t term[CPT];
+#pragma unroll
+                for (int j = 0; j < CPT; j++) term[j] = nl_mask16_ascii(v[j], cr_absent);
+                general = __any((cr_absent & 0x80808080u) != 0x80808080u);
+                if (!general) {
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        const uint32_t c = j * BLOCK + tid;
+                        L_mask[c] = (uint16_t)term[j];
+                        L_conv[c] = convert_chunk_ascii(v[j]);
+                    }
+                    if (has_halo) L_conv[TILE_CH + tid] = convert_chunk(vh);
+                }
+            }
+            if (general) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    const uint32_t c = j * BLOCK + tid;
+                    const uint64_t g = tbase + (uint64_t)c * 16u;
+                    uint32_t nl = eq_mask16(v[j], 0x0A0A0A0Au);
+                    uint32_t cr = eq_mask16(v[j], 0x0D0D0D0Du);
+                    uint32_t term = nl | (cr & ~(nl >> 1));
+                    if (cr & 0x8000u) {                    // \r in the chunk's last byte: \r\n across chunks?
+                        uint64_t nx = g + 16;
+                        if (nx < p.nbytes && p.buf[nx] == 0x0A) term &= 0x7FFFu;
+                    }
+                    if (g + 16 > p.nbytes) term &= g < p.nbytes ? ((1u << (uint32_t)(p.nbytes - g)) - 1u) : 0u;
+                    L_mask[c] = (uint16_t)term;
+                    L_conv[c] = convert_chunk(v[j]);
+                }
+                if (has_halo) L_conv[TILE_CH + tid] = convert_chunk(vh);
+                if (hiacc & 0x80808080u) L_misc[1] = 1;
+            }
+        }
+        // the next work item's bytes: in flight while this tile is finished
+        const uint32_t nit = it + gridDim.x;
+        uint32_t tn = 0, coden = FX_PREDICT;
+        uint64_t Pgn = 0;
+        TD_STAMP(1);   // A: wait for this tile's bytes, masks + packing
+        fetch_item(nit, tn, coden, Pgn);
+        if (nit < nwork) fetch_tile(tn);
+        lds_barrier();
+        TD_STAMP(2);   // barrier A
+        if (tid < 4) L_misc[16 + 4 * (parity ^ 1u) + tid] = 0;   // the previous tile's vote bank, for the tile after this
+
+        // ---------------- B: terminators of this thread's CPT consecutive chunks, block scan
+        const bool tile_has_hi = L_misc[1] != 0;
+        uint32_t mm[CPT / 2];
+#pragma unroll
+        for (int i = 0; i < CPT / 2; i++) mm[i] = reinterpret_cast<const uint32_t *>(L_mask)[tid * (CPT / 2) + i];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < CPT / 2; i++) cnt += __builtin_popcount(mm[i]);
+        const uint32_t incl = wave_incl_scan(cnt, lane);
+        if (lane == 63) L_misc[4 + wave] = incl;
+        const uint32_t span0 = tid * CPT * 16u;
+
+        // ---------------- C: phase.  One pass over this thread's terminators does two things by LOCAL
+        // ordinal class (ordinal within the thread, mod 4; the in-tile class follows once the scan
+        // gives the thread's exclusive prefix): it votes -- per class, lines opening with eight valid
+        // bases -- and it remembers, per class, the first line start and how many there are.
+        uint32_t r0 = code & 3u;
+        const bool predict = (code & FX_PREDICT) != 0 && t != 0;
+        uint32_t lv = 0;                 // 4 x 8-bit votes
+        uint32_t lcnt = 0;               // 4 x 8-bit line counts
+        uint32_t lfirst01 = 0, lfirst23 = 0;   // 4 x 16-bit first line start (relative to the tile)
+        {
+            uint32_t i = 0;
+#pragma unroll
+            for (int k = 0; k < CPT / 2; k++) {
+                uint32_t m = mm[k];
+                while (m) {
+                    const uint32_t bit = __builtin_ctz(m);
+                    m &= m - 1;
+                    const uint32_t srel = span0 + 32u * k + bit + 1u;
+                    const uint32_t sh8 = 8u * (i & 3u);
+                    if (tbase + srel < p.nbytes) {
+                        if (((lcnt >> sh8) & 0xFFu) == 0) {
+                            if (i & 2u) lfirst23 |= srel << (16u * (i & 1u)); else lfirst01 |= srel << (16u * (i & 1u));
+                        }
+                        lcnt += 1u << sh8;
+                        if (predict) {
+                            const uint32_t iv = L_conv[srel >> 4].y;
+                            const bool good = (((iv << (srel & 15u)) & 0xFF00u) == 0) && tbase + srel + 8 <= p.nbytes;
+                            lv += (good ? 1u : 0u) << sh8;
+                        }
+                    }
+                    i++;
+                }
+            }
+        }
+        lds_barrier();
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) { uint32_t x = L_misc[4 + w]; if (w < wave) wbase += x; total += x; }
+        const uint32_t excl = wbase + incl - cnt;
+        TD_STAMP(3);   // B: scan (+ local votes)
+        if (predict) {
+            uint32_t *bank = L_misc + 16 + 4 * parity;
+            // local class c is in-tile class (c + excl) & 3
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t n = (lv >> (8 * c)) & 0xFFu;
+                if (n) atomicAdd(&bank[(c + excl) & 3u], n);
+            }
+            lds_barrier();
+            const uint32_t a0 = bank[0], a1 = bank[1], a2 = bank[2], a3 = bank[3];
+            uint32_t best = a0; r0 = 0;
+            if (a1 > best) { best = a1; r0 = 1; }
+            if (a2 > best) { best = a2; r0 = 2; }
+            if (a3 > best) { best = a3; r0 = 3; }
+        } else if (code & FX_PREDICT) {
+            r0 = (4u - (uint32_t)(first_line & 3)) & 3u;      // tile 0: P = 0, the phase is known
+        }
+        TD_STAMP(4);   // C: vote
+        if (tid == 0 && !fp.mode)
+            fp.tile_info[t] = total | (r0 << TI_R0_SHIFT) | (tile_has_hi ? TI_HI : 0u);
+
+        const uint64_t P = Pg;                               // valid in fix-up mode only
+        const bool use_limit = (code & FX_LIMIT) != 0;
+        const long long sign = (code & FX_NEG) ? -1 : 1;
+
+        if (code & FX_HICHECK) {
+            // ------------ bytes >= 0x80 inside a counted sequence line?  (fix-up mode, true phase)
+            const uint64_t Lb = first_line + P + excl;
+            uint32_t seen = 0;
+#pragma unroll
+            for (int k = 0; k < CPT / 2; k++) {
+                const uint32_t m = mm[k];
+#pragma nounroll
+                for (uint32_t q = 0; q < 32u; q++) {
+                    const uint64_t g = tbase + span0 + 32u * k + q;
+                    if (g < p.nbytes && p.buf[g] >= 0x80u) {
+                        const uint64_t line = Lb + seen;
+                        if ((line & 3) == 1 && line <= p.limit_line) atomicOr(p.stats + ST_ERR, ERR_NONASCII);
+                    }
+                    seen += (m >> q) & 1u;
+                }
+            }
+        } else {
+            // ------------ D: the wanted lines that start in this thread's span: in-tile ordinal i is
+            // followed by a wanted line iff i == r0 (mod 4), i.e. local class (r0 - excl) & 3.  Tile 0
+            // also owns the buffer's first line (ordinal -1 == 3 mod 4).
+            const uint32_t lc = (r0 - excl) & 3u;
+            uint32_t nw = (lcnt >> (8u * lc)) & 0xFFu;
+            uint32_t w0 = ((lc & 2u) ? lfirst23 : lfirst01) >> (16u * (lc & 1u)) & 0xFFFFu;
+            const bool own_first = t == 0 && tid == 0 && p.nbytes > 0 && r0 == 3u;
+            // General enumeration of this thread's q-th wanted line (limit-aware); the common case
+            // -- no limit, at most one wanted line in the span -- never calls it.
+            auto nth_wanted = [&](uint32_t q, uint32_t &out) -> bool {
+                uint32_t seen = 0;
+                if (own_first && (!use_limit || first_line + P <= p.limit_line)) { if (q == 0) { out = 0; return true; } seen = 1; }
+                uint32_t i = excl;
+#pragma unroll
+                for (int k = 0; k < CPT / 2; k++) {
+                    uint32_t m = mm[k];
+                    while (m) {
+                        const uint32_t bit = __builtin_ctz(m);
+                        m &= m - 1;
+                        const uint32_t sr = span0 + 32u * k + bit + 1u;
+                        if ((i & 3u) == r0 && tbase + sr < p.nbytes &&
+                            (!use_limit || first_line + P + i + 1 <= p.limit_line)) {
+                            if (seen == q) { out = sr; return true; }
+                            seen++;
+                        }
+                        i++;
+                    }
+                }
+                return false;
+            };
+            const bool simple = !use_limit && !own_first && nw <= 1;
+            if (p.dbg & DBG_NO_PHASE2) nw = 0;
+            uint32_t ndefer = 0;
+#pragma nounroll
+            for (uint32_t q = 0; simple ? q < nw : true; q++) {
+                uint32_t srel = w0;
+                if (!simple && ((p.dbg & DBG_NO_PHASE2) || !nth_wanted(q, srel))) break;
+                const uint64_t res = match_line<W, ML_FAST>(p, cx, tbase + srel, srel, false);
+                const uint32_t kind = (uint32_t)(res >> 62);
+                if (kind == 3) { ndefer++; continue; }
+                st_reads += sign;
+                if (kind >= 1) st_bar += sign;
+                if (kind == 2) {
+                    st_tag += sign;
+                    if (!(p.dbg & DBG_NO_ATOMIC))
+                        __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), (uint32_t)sign, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // cold: lines that need their raw bytes (leading blanks to strip, a first byte that is
+            // not a base, a window beyond the staged chunks)
+            if (ndefer) {
+#pragma nounroll
+                for (uint32_t q = 0;; q++) {
+                    uint32_t srel = 0;
+                    if (!nth_wanted(q, srel)) break;
+                    const uint32_t c0f = srel >> 4;
+                    const bool deferred = c0f + p.nch > win_ch || ((L_conv[c0f].y >> (15u - (srel & 15u))) & 1u);
+                    if (!deferred) continue;
+                    // (a non-blank non-base first byte simply comes back as "no barcode")
+                    const uint64_t res = match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true);
+                    const uint32_t kind = (uint32_t)(res >> 62);
+                    st_reads += sign;
+                    if (kind >= 1) st_bar += sign;
+                    if (kind == 2) {
+                        st_tag += sign;
+                        if (!(p.dbg & DBG_NO_ATOMIC))
+                            __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), (uint32_t)sign, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+
+        TD_STAMP(6);   // D: match + commit (thread 0's share)
+        // ---------------- next work item
+        if (tid == 0) L_misc[1] = 0;
+        parity ^= 1u;
+        lds_barrier();                                    // LDS is reused by the next tile
+        TD_STAMP(7);   // end barrier (other waves' matching)
+        it = nit; t = tn; code = coden; Pg = Pgn;
+    }
+#ifdef TD_PHASE_PROF
+    if (tid == 0 && !fp.mode)
+        for (int i = 0; i < PROF_PHASES; i++) atomicAdd(p.stats + 8 + i, prof_acc[i]);
+#endif
+
+    // ---------------- statistics: one atomic per wave (two's complement carries the fix-up signs)
+    unsigned long long r = wave_sum64((unsigned long long)st_reads), b = wave_sum64((unsigned long long)st_bar),
+                       g = wave_sum64((unsigned long long)st_tag);
+    if (lane == 0) {
+        if (r) atomicAdd(p.stats + ST_READS, r);
+        if (b) atomicAdd(p.stats + ST_BARCUT, b);
+        if (g) atomicAdd(p.stats + ST_TAG, g);
+    }
+}
+
+// Single workgroup: exclusive scan of the per-tile terminator counts gives every tile's true
+// line phase; tiles counted under another phase, tiles reaching past the maxreads limit and tiles
+// holding bytes >= 0x80 are queued for the fix-up pass.  Also leaves the running line total.
+__global__ __launch_bounds__(1024) void k_resolve(const FParams fp) {
+    const KParams &p = fp.k;
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
+    const uint64_t first_line = p.first_line + carried;
+    const bool finite = p.limit_line < (~0ull - 16);
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    auto push = [&](uint32_t tile, uint32_t code, uint64_t P) {
+        const uint32_t slot = atomicAdd(fp.nfix, 1u);
+        if (slot < fp.fix_cap) fp.fixlist[slot] = make_uint4(tile, code, (uint32_t)P, (uint32_t)(P >> 32));
+        else atomicOr(p.stats + ST_ERR, ERR_SPIN);   // cannot happen: the queue holds 3 entries per tile
+    };
+    for (uint32_t base = 0; base < p.ntiles; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t info = i < p.ntiles ? fp.tile_info[i] : 0u;
+        const unsigned long long v = info & TI_COUNT_MASK;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { unsigned long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned long long off = carry;
+        for (int w = 0; w < wave; w++) off += wsum[w];
+        if (i < p.ntiles) {
+            const uint64_t P = off + inc - v;                          // terminators before tile i
+            const uint32_t truth = (4u - (uint32_t)((first_line + P) & 3)) & 3u;   // ordinals == truth (mod 4) precede sequence lines
+            const uint32_t pred = (info >> TI_R0_SHIFT) & 3u;
+            // lines of this tile: first_line+P (only tile 0's own first line) .. first_line+P+v
+            const bool beyond_all = finite && first_line + P + (i == 0 ? 0 : 1) > p.limit_line;
+            const bool beyond_some = finite && first_line + P + v > p.limit_line;
+            if (beyond_all) {
+                push(i, pred | FX_NEG, P);
+            } else if (beyond_some) {
+                push(i, pred | FX_NEG, P);
+                push(i, truth | FX_LIMIT, P);
+            } else if (pred != truth) {
+                push(i, pred | FX_NEG, P);
+                push(i, truth, P);
+            }
+            if ((info & TI_HI) && !beyond_all) push(i, truth | FX_HICHECK, P);
+        }
+        __syncthreads();
+        if (tid == 1023) carry = off + inc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        atomicAdd(p.stats + ST_LINES, carry);
+        if (p.cursor_out) *p.cursor_out = carried + carry;
+    }
+}
+
+}  // namespace tdk

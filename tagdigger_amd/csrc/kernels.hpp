@@ -87,6 +87,7 @@ struct KParams {
     // leave the running total for the next piece; both may be null
     const unsigned long long *cursor_in;
     unsigned long long *cursor_out;
+    uint32_t stagger, stagger_div;   // start-up stagger of co-resident workgroups (units of 4096 cycles; 0 = off)
     uint32_t dbg;            // timing-only ablations (results wrong when nonzero); see DBG_*
 };
 
@@ -145,6 +146,13 @@ __device__ __forceinline__ uint32_t hash_key(uint64_t key) {  // must match host
     return h;
 }
 
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, NOT for its
+// global loads (__syncthreads() adds s_waitcnt vmcnt(0), which would stall on the next tile's
+// bytes that are deliberately left in flight across the barrier).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // wave-level inclusive scan (64 lanes)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -195,7 +203,217 @@ __device__ __forceinline__ uint2 convert_chunk(const uint4 &v) {
     return make_uint2(cw, iw);
 }
 
+// The same two conversions for chunks known to hold only bytes < 0x80 (every FASTQ in practice):
+// "byte != 0" is then simply bit 7 of byte + 0x7F, with no carry between bytes.
+__device__ __forceinline__ uint2 convert_chunk_ascii(const uint4 &v) {
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t cw = 0, ihi = 0, ilo = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t code = (x[d] >> 1) & 0x03030303u;
+        uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, code);
+        uint32_t diff = (x[d] & 0xDFDFDFDFu) ^ expect;            // 0 where the byte is a base, < 0x80 otherwise
+        uint32_t nz = (diff + 0x7F7F7F7Fu) & 0x80808080u;
+        cw = (cw << 8) | udot4(code, 0x01041040u, 0u);
+        // 0x80 * (first byte -> weight 8 ... last -> 1), two dwords per accumulator
+        if (d == 0) ihi = udot4(nz, 0x10204080u, 0u);
+        else if (d == 1) ihi = udot4(nz, 0x01020408u, ihi);
+        else if (d == 2) ilo = udot4(nz, 0x10204080u, 0u);
+        else ilo = udot4(nz, 0x01020408u, ilo);
+    }
+    return make_uint2(cw, ((ihi >> 7) << 8) | (ilo >> 7));
+}
+// 16-bit mask of bytes equal to '\n' in an all-ASCII chunk, and whether it holds any '\r'
+__device__ __forceinline__ uint32_t nl_mask16_ascii(const uint4 &v, uint32_t &cr_absent_acc) {
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t y = x[d] ^ 0x0A0A0A0Au;
+        const uint32_t u = (y + 0x7F7F7F7Fu) | 0x7F7F7F7Fu;       // 0x7F where the byte is '\n', else 0xFF
+        cr_absent_acc &= (x[d] ^ 0x0D0D0D0Du) + 0x7F7F7F7Fu;      // bit 7 of a byte cleared iff it is '\r'
+        if (d == 0) lo = udot4(u, 0x08040201u, 0u);
+        else if (d == 1) lo = udot4(u, 0x80402010u, lo);
+        else if (d == 2) hi = udot4(u, 0x08040201u, 0u);
+        else hi = udot4(u, 0x80402010u, hi);
+    }
+    // dot = 255 * 255 - 128 * mask8
+    return ((65025u - lo) >> 7) | (((65025u - hi) >> 7) << 8);
+}
+
 // CPT: 16-byte chunks per thread per tile (tile = CPT*4 KiB); W: 64-bit words per packed tag
+// ---------------------------------------------------------------- per-line matcher (shared by both kernels)
+// What a workgroup has staged in LDS for its current tile, plus the index.
+struct TileCtx {
+    const uint2 *L_conv;                 // packed chunks of the tile + halo
+    uint32_t win_ch;                     // how many of them
+    const unsigned long long *L_bval;    // barcode index (LDS copy)
+    const uint32_t *L_bmeta;
+    const uint16_t *L_bdir, *L_bcand;
+};
+
+// gpos: absolute position of the line's first byte; srel: the same relative to the tile (fast mode).
+// Fast mode reads packed chunks from LDS; slow mode re-reads raw bytes from global memory (leading
+// blanks to strip, :256, or a window beyond what is staged).  Returns R_NONE (no barcode+site),
+// R_BAR (barcode+site only), R_TAG | cell, or -- fast mode with DEFER only -- R_DEFER when the raw
+// bytes are needed.  With DEFER false the fast mode falls through to the slow mode by itself.
+// No side effects: the caller commits.
+// MODE: ML_FAST  packed chunks only, returns R_DEFER when the raw bytes are needed (no global-memory code at all);
+//       ML_SLOW  raw bytes only;   ML_BOTH  chosen by `slow`, R_DEFER from the fast branch (exact kernel).
+enum { ML_FAST = 0, ML_SLOW = 1, ML_BOTH = 2 };
+template <int W, int MODE>
+__device__ __forceinline__ uint64_t match_line(const KParams &p, const TileCtx &cx, uint64_t gpos, uint32_t srel, bool slow) {
+    if (MODE == ML_FAST) slow = false;
+    if (MODE == ML_SLOW) slow = true;
+    constexpr int NCHMAX = 2 * W + 3;
+    constexpr int NS = 2 * W + 4;      // aligned 16-base words kept (zero padded)
+    constexpr int BUCKET_U4 = W <= 3 ? 4 : 8;          // 64- or 128-byte buckets
+    constexpr int SLOT_DW = 2 * W + 1;
+    constexpr int SPB = (BUCKET_U4 * 4 - 1) / SLOT_DW;  // slots per bucket
+    const uint2 *L_conv = cx.L_conv;
+    const uint32_t win_ch = cx.win_ch;
+    const unsigned long long *L_bval = cx.L_bval;
+    const uint32_t *L_bmeta = cx.L_bmeta;
+    const uint16_t *L_bdir = cx.L_bdir, *L_bcand = cx.L_bcand;
+    if (MODE != ML_SLOW && !slow) {
+        const uint32_t c0f = srel >> 4;
+        if (c0f + p.nch > win_ch) return R_DEFER;
+        // first byte is not a base: a blank to strip (slow path), or simply no match
+        if ((L_conv[c0f].y >> (15u - (srel & 15u))) & 1u) return R_DEFER;
+    }
+    if (MODE != ML_FAST && slow) {
+        while (gpos < p.nbytes && is_blank(p.buf[gpos])) gpos++;   // ends at the terminator at the latest
+    }
+    const uint32_t a = (uint32_t)(gpos & 15u);
+    const uint64_t g0 = gpos & ~15ull;             // slow path: first chunk (tile bases are 16-aligned)
+    const uint32_t c0 = srel >> 4;                 // fast path
+    uint32_t codes[NCHMAX + 1];
+    uint32_t inv[(NCHMAX + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (NCHMAX + 1) / 2; i++) inv[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NCHMAX; i++) {
+        uint2 e = make_uint2(0u, 0xFFFFu);
+        if (i < (int)p.nch) {
+            if (MODE == ML_FAST || (MODE == ML_BOTH && !slow)) e = L_conv[c0 + i];
+            else e = convert_chunk(load_chunk(p, g0 + 16ull * i));
+        }
+        codes[i] = e.x;
+        if (i & 1) inv[i >> 1] |= e.y; else inv[i >> 1] |= e.y << 16;
+    }
+    codes[NCHMAX] = 0;
+    if ((NCHMAX & 1)) inv[NCHMAX >> 1] |= 0xFFFFu;   // padding half-word is invalid
+    // number of leading valid bases of the read
+    inv[0] &= 0xFFFFFFFFu >> a;
+    uint32_t nvalid = 0;
+    {
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < (NCHMAX + 1) / 2; i++) {
+            if (!found) {
+                if (inv[i]) { nvalid += __builtin_clz(inv[i]); found = true; }
+                else nvalid += 32;
+            }
+        }
+        nvalid -= a;
+    }
+    // stream aligned to the read start: S[w] holds bases 16w..16w+15
+    uint32_t S[NS];
+#pragma unroll
+    for (int w = 0; w < NS; w++) {
+        if (w < NCHMAX) {
+            uint64_t pr = ((uint64_t)codes[w] << 32) | codes[w + 1];
+            S[w] = (uint32_t)(pr >> (32u - 2u * a));
+        } else S[w] = 0;
+    }
+        // (inside phase 2) fetch packed chunks + alignment
+    // ---- barcode + cut site (reference :257)
+    const uint64_t K = ((uint64_t)S[0] << 32) | S[1];
+    uint32_t ci = L_bdir[S[0] >> (32 - 2 * BDIR_BASES)];
+    uint32_t meta = 0;
+    bool bhit = false;
+    if (ci != 0xFFFFu) {
+        for (;;) {
+            uint32_t e = L_bcand[ci];
+            uint32_t m = L_bmeta[e & 0x7FFFu];
+            uint32_t len = m & 63u;
+            if (len <= nvalid && ((K ^ L_bval[e & 0x7FFFu]) >> (64u - 2u * len)) == 0) { meta = m; bhit = true; break; }
+            if (e & 0x8000u) break;
+            ci++;
+        }
+    }
+        // barcode directory walk
+    if (!bhit) return R_NONE;
+    const uint32_t off = (meta >> 6) & 1023u, row = meta >> 16;
+    if (nvalid <= off) return R_BAR;
+    const uint32_t nrem = nvalid - off;
+    // ---- tag (reference :260): bases off.. of the read, as 64-bit words
+    const uint32_t wo = off >> 4, sh = 2u * (off & 15u);
+    for (uint32_t t = 0; t < p.maxwo; t++) {
+        if (wo > t) {
+#pragma unroll
+            for (int w = 0; w < NS - 1; w++) S[w] = S[w + 1];
+            S[NS - 1] = 0;
+        }
+    }
+    uint64_t R[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        uint64_t hi = ((uint64_t)S[2 * w] << 32) | S[2 * w + 1];
+        uint64_t lo = ((uint64_t)S[2 * w + 1] << 32) | S[2 * w + 2];
+        uint32_t top = (uint32_t)(((hi << sh) >> 32));
+        uint32_t bot = (uint32_t)(((lo << sh) >> 32));
+        R[w] = ((uint64_t)top << 32) | bot;
+    }
+    auto prefix_eq = [&](const uint64_t *T, uint32_t len) -> bool {
+        bool ok = true;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            int nb = (int)len - 32 * w;
+            uint64_t mask = nb <= 0 ? 0ull : nb >= 32 ? ~0ull : (~0ull << (64 - 2 * nb));
+            ok = ok && (((R[w] ^ T[w]) & mask) == 0);
+        }
+        return ok;
+    };
+    bool thit = false;
+    uint32_t col = 0;
+    if (nrem >= p.m_bases && !(p.dbg & DBG_NO_PROBE)) {
+        uint32_t bk = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
+        for (uint32_t probes = 0; probes <= p.bucket_mask; probes++) {
+            const uint4 *bp = p.buckets + (size_t)bk * BUCKET_U4;
+            uint32_t raw[BUCKET_U4 * 4];
+#pragma unroll
+            for (int q = 0; q < BUCKET_U4; q++) {
+                uint4 v = bp[q];
+                raw[4 * q] = v.x; raw[4 * q + 1] = v.y; raw[4 * q + 2] = v.z; raw[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int sl = 0; sl < SPB; sl++) {
+                const uint32_t meta2 = raw[1 + sl * SLOT_DW + 2 * W];
+                const uint32_t len = meta2 & 1023u;
+                uint64_t T[W];
+#pragma unroll
+                for (int w = 0; w < W; w++)
+                    T[w] = ((uint64_t)raw[1 + sl * SLOT_DW + 2 * w + 1] << 32) | raw[1 + sl * SLOT_DW + 2 * w];
+                if (len != 0 && len <= nrem && prefix_eq(T, len)) { thit = true; col = meta2 >> 10; }
+            }
+            if (thit || !(raw[0] & 1u)) break;      // found, or the bucket never overflowed
+            bk = (bk + 1) & p.bucket_mask;
+        }
+    }
+    if (!thit) {
+        for (uint32_t e = 0; e < p.nshort; e++) {
+            uint4 v = p.shorts[e];
+            uint64_t tv = ((uint64_t)v.y << 32) | v.x;
+            uint32_t len = v.z;
+            if (len <= nrem && ((R[0] ^ tv) >> (64u - 2u * len)) == 0) { thit = true; col = v.w; break; }
+        }
+    }
+       // tag hash probes (+ short list)
+    if (!thit) return R_BAR;
+    return R_TAG | ((uint64_t)row * p.ncols + col);
+}
+
 #ifndef TD_WAVES_PER_SIMD
 #define TD_WAVES_PER_SIMD 4   // register budget: 4 workgroups of 256 threads per CU
 #endif
@@ -203,12 +421,6 @@ template <int CPT, int W, bool TASSEL>
 __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_count(const KParams p) {
     constexpr int TILE_CH = CPT * BLOCK;
     constexpr uint32_t TILE = TILE_CH * 16;
-    constexpr int NCHMAX = 2 * W + 3;
-    constexpr int NS = 2 * W + 4;      // aligned 16-base words kept (zero padded)
-    constexpr int BUCKET_U4 = W <= 3 ? 4 : 8;          // 64- or 128-byte buckets
-    constexpr int SLOT_DW = 2 * W + 1;
-    constexpr int SPB = (BUCKET_U4 * 4 - 1) / SLOT_DW;  // slots per bucket
-
     // LDS: packed chunks of the tile + halo | terminator masks (later: line-start list) | misc | barcode index
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t halo_ch = p.halo / 16u;
@@ -239,151 +451,10 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_count(const KParam
     const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
     const uint64_t first_line = p.first_line + carried;
 
-    // ------------------------------------------------------------ per-read matcher
-    // srel: offset of the line's first byte relative to the tile start (may lie in the halo).
-    // Fast path: packed chunks from LDS.  Slow path (`slow`, or decided here): raw bytes from
-    // global memory -- leading blanks to skip (:256) or a window beyond what is staged.
-    // Returns R_NONE (no barcode+site), R_BAR (barcode+site only), R_TAG | cell, or -- fast mode
-    // only -- R_DEFER when the raw bytes are needed.  No side effects: the caller commits.
-    // gpos: absolute position of the line's first byte; srel: the same relative to the tile (fast mode)
+    // ------------------------------------------------------------ per-read matcher (match_line above)
+    const TileCtx cx{L_conv, win_ch, L_bval, L_bmeta, L_bdir, L_bcand};
     auto match_read = [&](uint64_t gpos, uint32_t srel, bool slow) -> uint64_t {
-        if (!slow) {
-            const uint32_t c0f = srel >> 4;
-            if (c0f + p.nch > win_ch) return R_DEFER;
-            // first byte is not a base: a blank to strip (slow path), or simply no match
-            if ((L_conv[c0f].y >> (15u - (srel & 15u))) & 1u) return R_DEFER;
-        }
-        if (slow) {
-            while (gpos < p.nbytes && is_blank(p.buf[gpos])) gpos++;   // ends at the terminator at the latest
-        }
-        const uint32_t a = (uint32_t)(gpos & 15u);
-        const uint64_t g0 = gpos & ~15ull;             // slow path: first chunk (tile bases are 16-aligned)
-        const uint32_t c0 = srel >> 4;                 // fast path
-        uint32_t codes[NCHMAX + 1];
-        uint32_t inv[(NCHMAX + 1) / 2];
-#pragma unroll
-        for (int i = 0; i < (NCHMAX + 1) / 2; i++) inv[i] = 0;
-#pragma unroll
-        for (int i = 0; i < NCHMAX; i++) {
-            uint2 e = make_uint2(0u, 0xFFFFu);
-            if (i < (int)p.nch) {
-                if (!slow) e = L_conv[c0 + i];
-                else e = convert_chunk(load_chunk(p, g0 + 16ull * i));
-            }
-            codes[i] = e.x;
-            if (i & 1) inv[i >> 1] |= e.y; else inv[i >> 1] |= e.y << 16;
-        }
-        codes[NCHMAX] = 0;
-        if ((NCHMAX & 1)) inv[NCHMAX >> 1] |= 0xFFFFu;   // padding half-word is invalid
-        // number of leading valid bases of the read
-        inv[0] &= 0xFFFFFFFFu >> a;
-        uint32_t nvalid = 0;
-        {
-            bool found = false;
-#pragma unroll
-            for (int i = 0; i < (NCHMAX + 1) / 2; i++) {
-                if (!found) {
-                    if (inv[i]) { nvalid += __builtin_clz(inv[i]); found = true; }
-                    else nvalid += 32;
-                }
-            }
-            nvalid -= a;
-        }
-        // stream aligned to the read start: S[w] holds bases 16w..16w+15
-        uint32_t S[NS];
-#pragma unroll
-        for (int w = 0; w < NS; w++) {
-            if (w < NCHMAX) {
-                uint64_t pr = ((uint64_t)codes[w] << 32) | codes[w + 1];
-                S[w] = (uint32_t)(pr >> (32u - 2u * a));
-            } else S[w] = 0;
-        }
-        TD_STAMP(8);    // (inside phase 2) fetch packed chunks + alignment
-        // ---- barcode + cut site (reference :257)
-        const uint64_t K = ((uint64_t)S[0] << 32) | S[1];
-        uint32_t ci = L_bdir[S[0] >> (32 - 2 * BDIR_BASES)];
-        uint32_t meta = 0;
-        bool bhit = false;
-        if (ci != 0xFFFFu) {
-            for (;;) {
-                uint32_t e = L_bcand[ci];
-                uint32_t m = L_bmeta[e & 0x7FFFu];
-                uint32_t len = m & 63u;
-                if (len <= nvalid && ((K ^ L_bval[e & 0x7FFFu]) >> (64u - 2u * len)) == 0) { meta = m; bhit = true; break; }
-                if (e & 0x8000u) break;
-                ci++;
-            }
-        }
-        TD_STAMP(9);    // barcode directory walk
-        if (!bhit) return R_NONE;
-        const uint32_t off = (meta >> 6) & 1023u, row = meta >> 16;
-        if (nvalid <= off) return R_BAR;
-        const uint32_t nrem = nvalid - off;
-        // ---- tag (reference :260): bases off.. of the read, as 64-bit words
-        const uint32_t wo = off >> 4, sh = 2u * (off & 15u);
-        for (uint32_t t = 0; t < p.maxwo; t++) {
-            if (wo > t) {
-#pragma unroll
-                for (int w = 0; w < NS - 1; w++) S[w] = S[w + 1];
-                S[NS - 1] = 0;
-            }
-        }
-        uint64_t R[W];
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-            uint64_t hi = ((uint64_t)S[2 * w] << 32) | S[2 * w + 1];
-            uint64_t lo = ((uint64_t)S[2 * w + 1] << 32) | S[2 * w + 2];
-            uint32_t top = (uint32_t)(((hi << sh) >> 32));
-            uint32_t bot = (uint32_t)(((lo << sh) >> 32));
-            R[w] = ((uint64_t)top << 32) | bot;
-        }
-        auto prefix_eq = [&](const uint64_t *T, uint32_t len) -> bool {
-            bool ok = true;
-#pragma unroll
-            for (int w = 0; w < W; w++) {
-                int nb = (int)len - 32 * w;
-                uint64_t mask = nb <= 0 ? 0ull : nb >= 32 ? ~0ull : (~0ull << (64 - 2 * nb));
-                ok = ok && (((R[w] ^ T[w]) & mask) == 0);
-            }
-            return ok;
-        };
-        bool thit = false;
-        uint32_t col = 0;
-        if (nrem >= p.m_bases && !(p.dbg & DBG_NO_PROBE)) {
-            uint32_t bk = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
-            for (uint32_t probes = 0; probes <= p.bucket_mask; probes++) {
-                const uint4 *bp = p.buckets + (size_t)bk * BUCKET_U4;
-                uint32_t raw[BUCKET_U4 * 4];
-#pragma unroll
-                for (int q = 0; q < BUCKET_U4; q++) {
-                    uint4 v = bp[q];
-                    raw[4 * q] = v.x; raw[4 * q + 1] = v.y; raw[4 * q + 2] = v.z; raw[4 * q + 3] = v.w;
-                }
-#pragma unroll
-                for (int sl = 0; sl < SPB; sl++) {
-                    const uint32_t meta2 = raw[1 + sl * SLOT_DW + 2 * W];
-                    const uint32_t len = meta2 & 1023u;
-                    uint64_t T[W];
-#pragma unroll
-                    for (int w = 0; w < W; w++)
-                        T[w] = ((uint64_t)raw[1 + sl * SLOT_DW + 2 * w + 1] << 32) | raw[1 + sl * SLOT_DW + 2 * w];
-                    if (len != 0 && len <= nrem && prefix_eq(T, len)) { thit = true; col = meta2 >> 10; }
-                }
-                if (thit || !(raw[0] & 1u)) break;      // found, or the bucket never overflowed
-                bk = (bk + 1) & p.bucket_mask;
-            }
-        }
-        if (!thit) {
-            for (uint32_t e = 0; e < p.nshort; e++) {
-                uint4 v = p.shorts[e];
-                uint64_t tv = ((uint64_t)v.y << 32) | v.x;
-                uint32_t len = v.z;
-                if (len <= nrem && ((R[0] ^ tv) >> (64u - 2u * len)) == 0) { thit = true; col = v.w; break; }
-            }
-        }
-        TD_STAMP(10);   // tag hash probes (+ short list)
-        if (!thit) return R_BAR;
-        return R_TAG | ((uint64_t)row * p.ncols + col);
+        return match_line<W, ML_BOTH>(p, cx, gpos, srel, slow);
     };
 
     // tassel_tagcount (reference :251-253): hrel = start of a header line.  Parses

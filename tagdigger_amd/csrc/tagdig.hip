@@ -16,6 +16,7 @@
 #include "../../include/tagdig.h"
 #include "../../include/td_synth_spec.h"
 #include "kernels.hpp"
+#include "kernel_fast.hpp"
 
 namespace {
 
@@ -149,9 +150,12 @@ struct td_handle {
     DevBuf<uint64_t> d_state, d_tilecounts;
     DevBuf<uint32_t> d_ticket;
     DevBuf<unsigned long long> d_cursor;      // [2] line cursor for streamed pieces
+    DevBuf<uint32_t> d_tileinfo, d_nfix;      // fast path: per-tile count+phase, fix-up queue length
+    DevBuf<uint4> d_fixlist;
     // options
-    int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0;
+    int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1;
     uint32_t debug_ablate = 0;
+    int stagger = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
@@ -174,6 +178,24 @@ template <int CPT, bool TASSEL> KFn pick_w(int W) {
 KFn pick_kernel(int tile_kb, int W, bool tassel) {
     if (tassel) return pick_w<4, true>(W);
     return tile_kb == 32 ? pick_w<8, false>(W) : pick_w<4, false>(W);
+}
+
+using FFn = void (*)(const tdk::FParams);
+template <int CPT> FFn pick_fast_w(int W) {
+    switch (W) {
+    case 1: return tdk::k_fast<CPT, 1>;
+    case 2: return tdk::k_fast<CPT, 2>;
+    case 3: return tdk::k_fast<CPT, 3>;
+    case 4: return tdk::k_fast<CPT, 4>;
+    case 6: return tdk::k_fast<CPT, 6>;
+    default: return tdk::k_fast<CPT, 10>;
+    }
+}
+FFn pick_fast(int tile_kb, int W) { return tile_kb == 32 ? pick_fast_w<8>(W) : pick_fast_w<4>(W); }
+
+size_t lds_bytes_fast(const td_handle *h, int tile_kb) {
+    size_t tile_ch = (size_t)tile_kb * 1024 / 16, halo_ch = h->halo / 16;
+    return (tile_ch + halo_ch) * 8 + tile_ch * 2 + 256 + h->bblob_bytes;
 }
 
 size_t lds_bytes(const td_handle *h, int tile_kb) {
@@ -211,7 +233,7 @@ int flush_counts(td_handle *h) {
 // the line index between streamed pieces without a host round trip.
 int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, uint64_t max_reads,
                  int weights, hipStream_t stream, const unsigned long long *cursor_in = nullptr,
-                 unsigned long long *cursor_out = nullptr) {
+                 unsigned long long *cursor_out = nullptr, uint64_t first_line_ub = 0) {
     if (!h->have_index) return fail(TD_E_STATE, "td_set_index has not been called");
     if (((uintptr_t)d_fastq & 15) != 0) return fail(TD_E_ARG, "device FASTQ pointer must be 16-byte aligned");
     if (nbytes == 0) return TD_OK;
@@ -250,6 +272,54 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     p.prefilled = h->prescan ? 1u : 0u;
     p.cursor_in = cursor_in; p.cursor_out = cursor_out;
     p.dbg = h->debug_ablate;
+    p.stagger = (uint32_t)h->stagger; p.stagger_div = (uint32_t)h->num_cu;
+
+    // ---- fast path: free-running tiles with a predicted line phase, exact resolve, fix-up pass.
+    // Chosen when the maxreads limit cannot bite early (it is still applied exactly, by fix-ups).
+    // (streamed pieces carry their true first line on the device; first_line_ub bounds it from above)
+    const uint64_t fl_ub = std::max(first_line, first_line_ub);
+    const bool limit_far = p.limit_line >= ~0ull - 16 || p.limit_line - std::min(p.limit_line, fl_ub) >= nbytes / 16;
+    if (h->fastpath && !tassel && !h->prescan && limit_far) {
+        int rc = h->d_tileinfo.ensure(ntiles); if (rc) return rc;
+        const uint32_t fix_cap = 3u * ntiles + 8u;
+        rc = h->d_fixlist.ensure(fix_cap); if (rc) return rc;
+        rc = h->d_nfix.ensure(4); if (rc) return rc;
+        tdk::FParams fp{};
+        fp.k = p; fp.tile_info = h->d_tileinfo.p; fp.fixlist = h->d_fixlist.p; fp.nfix = h->d_nfix.p; fp.fix_cap = fix_cap;
+        HIPCHK(hipMemsetAsync(h->d_nfix.p, 0, 4, stream));
+        FFn ffn = pick_fast(tile_kb, h->W);
+        const size_t flds = lds_bytes_fast(h, tile_kb);
+        if (flds > 48 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+        int bpc = h->blocks_per_cu;
+        if (bpc <= 0) {
+            if (h->occ_fn != (const void *)ffn || h->occ_lds != flds) {
+                int occ = 0;
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)ffn, tdk::BLOCK, flds));
+                h->occ_fn = (const void *)ffn; h->occ_lds = flds; h->occ_val = std::max(1, occ);
+            }
+            bpc = h->occ_val;
+        }
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)h->num_cu * bpc);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->timing) {
+            if (h->ev_used == h->ev_pool.size()) {
+                hipEvent_t a, b;
+                HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+                h->ev_pool.emplace_back(a, b);
+            }
+            e0 = h->ev_pool[h->ev_used].first; e1 = h->ev_pool[h->ev_used].second; h->ev_used++;
+            HIPCHK(hipEventRecord(e0, stream));
+        }
+        fp.mode = 0;
+        hipLaunchKernelGGL(ffn, dim3(grid), dim3(tdk::BLOCK), flds, stream, fp);
+        hipLaunchKernelGGL(tdk::k_resolve, dim3(1), dim3(1024), 0, stream, fp);
+        fp.mode = 1;
+        hipLaunchKernelGGL(ffn, dim3(std::min<uint32_t>(grid, (uint32_t)h->num_cu * 2)), dim3(tdk::BLOCK), flds, stream, fp);
+        HIPCHK(hipGetLastError());
+        if (h->timing) HIPCHK(hipEventRecord(e1, stream));
+        return TD_OK;
+    }
 
     HIPCHK(hipMemsetAsync(h->d_ticket.p, 0, 4, stream));
     if (h->prescan) {
@@ -339,7 +409,7 @@ void td_destroy(td_handle *h) {
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
-    h->d_ticket.release(); h->d_cursor.release();
+    h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_fixlist.release();
     for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->work_stream) (void)hipStreamDestroy(h->work_stream);
@@ -532,6 +602,7 @@ struct Stager {
     bool busy[NB] = {false, false, false};
     int cur = 0;
     uint64_t first_line = 0;
+    uint64_t bytes_submitted = 0;             // every line holds >= 1 byte: bounds the line index from above
     unsigned pieces = 0;
     int init(td_handle *hh, size_t capacity, uint64_t first) {
         h = hh; cap = capacity; first_line = first;
@@ -566,8 +637,10 @@ struct Stager {
         HIPCHK(hipEventRecord(copied[cur], h->copy_stream));
         HIPCHK(hipStreamWaitEvent(h->work_stream, copied[cur], 0));
         int rc = launch_count(h, dev[cur], n, first_line, max_reads, weights, h->work_stream,
-                              h->d_cursor.p + (pieces & 1), h->d_cursor.p + ((pieces + 1) & 1));
+                              h->d_cursor.p + (pieces & 1), h->d_cursor.p + ((pieces + 1) & 1),
+                              first_line + bytes_submitted);
         if (rc) return rc;
+        bytes_submitted += n;
         HIPCHK(hipEventRecord(done[cur], h->work_stream));
         busy[cur] = true;
         pieces++;
@@ -711,6 +784,11 @@ int td_debug_counters(td_handle *h, uint64_t out[24]) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, h->d_stats.p + 8, 24 * 8, hipMemcpyDeviceToHost));
+    if (h->d_nfix.p) {          // [12]: length of the fast path's fix-up queue in the last launch
+        uint32_t nf = 0;
+        HIPCHK(hipMemcpy(&nf, h->d_nfix.p, 4, hipMemcpyDeviceToHost));
+        out[11] = nf;
+    }
     return TD_OK;
 }
 
@@ -724,6 +802,8 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     } else if (n == "blocks_per_cu") h->blocks_per_cu = (int)value;
     else if (n == "prescan") h->prescan = value ? 1 : 0;
     else if (n == "timing") h->timing = value ? 1 : 0;
+    else if (n == "fastpath") h->fastpath = value ? 1 : 0;
+    else if (n == "stagger") h->stagger = (int)value;
     else if (n == "debug_ablate") h->debug_ablate = (uint32_t)value;   // timing-only ablations, wrong results
     else return fail(TD_E_ARG, "unknown option " + n);
     return TD_OK;

@@ -11,9 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("TAGDIG_LIB", os.path.join(ROOT, "tagdigger_amd", "libtagdig_prof.so"))
 sys.path.insert(0, ROOT)
 
-NAMES = ["ticket", "load+masks+LDS store", "barrier after load", "block scan", "look-back",
+NAMES_EXACT = ["ticket", "load+masks+LDS store", "barrier after load", "block scan", "look-back",
          "emission", "phase 2 (match)", "loop tail",
          "  p2: fetch+convert", "  p2: barcode", "  p2: tag probes", "-"]
+
+
+NAMES = ["loop head", "A: wait bytes + masks + pack", "barrier A", "B: scan + local votes", "C: vote",
+         "-", "D: match + commit (thread 0)", "end barrier (others matching)", "-", "-", "-", "-"]
 
 
 def main():
