@@ -28,3 +28,356 @@ def find_tags_fastq(fqfile, barcodes, tags, cutsite="TGCAG", maxreads=5e9, tasse
     eng.set_index(barcodes, tags, cutsite)          # asserts + index, before the file is opened (:198-233)
     eng.count_file(fqfile, maxreads, tassel_tagcount)
     return eng.counts(signed=bool(tassel_tagcount))
+
+
+# =============================================================================
+# Periphery of the counting path: plain host
+# Python, no acceleration -- kept so that the reference's command line stays a
+# drop-in.  Same return values, same printed messages, same files written.
+# =============================================================================
+import bisect as _bisect
+import csv as _csv
+import gzip as _gzip
+
+
+def isFastq(filename):
+    """1 for a plain FASTQ file, 2 for a gzipped one (chosen by name), 0 otherwise or if it
+    cannot be opened -- judged from the first three lines only (reference tagdigger_fun.py:279-307)."""
+    gz = filename[-2:].lower() == 'gz'
+    try:
+        con = _gzip.open(filename, 'rt') if gz else open(filename, 'r')
+    except IOError:
+        return 0
+    verdict = 2 if gz else 1
+    try:
+        header = con.readline()
+        if header[0] != '@':
+            verdict = 0
+        if not set(con.readline().strip()) <= set('ACGTNacgtn'):
+            verdict = 0
+        if con.readline()[0] != '+':
+            verdict = 0
+    finally:
+        con.close()
+    return verdict
+
+
+def readBarcodeKeyfile(filename, forSplitter=False):
+    """Key file (CSV with File/Barcode/Sample columns, any order) -> {file: [[barcodes], [samples]]},
+    or None after printing what is wrong (reference tagdigger_fun.py:309-374)."""
+    cols = ("Input File", "Barcode", "Output File") if forSplitter else ("File", "Barcode", "Sample")
+    try:
+        result = {}
+        with open(filename, 'r', newline='') as con:
+            where = None
+            rownum = 1                                         # the reference's row numbers skip blank lines
+            for row in _csv.reader(con):
+                if where is None:
+                    where = [row.index(c) for c in cols]      # ValueError if a column is missing
+                    continue
+                f, b, s = row[where[0]].strip(), row[where[1]].strip().upper(), row[where[2]].strip()
+                if f == "" and b == "" and s == "":
+                    continue
+                rownum += 1
+                if f == "":
+                    raise Exception("Blank cell found where file name should be in row {}.".format(rownum))
+                if s == "":
+                    raise Exception("Blank cell found where sample name should be in row {}.".format(rownum))
+                if not set(b) <= set('ACGT'):
+                    raise Exception("{0} in row {1} is not a valid barcode.".format(b, rownum))
+                entry = result.setdefault(f, [[], []])
+                if b in entry[0]:
+                    raise Exception("Each barcode can only be present once for each file.")
+                entry[0].append(b)
+                entry[1].append(s)
+        if forSplitter:
+            outs = [s for v in result.values() for s in v[1]]
+            if len(set(outs)) < len(outs):
+                raise Exception("All output files must have unique names for barcode splitter.")
+    except IOError:
+        print("Could not read file {}.".format(filename))
+        return None
+    except ValueError:
+        print("File header needed containing '{}', '{}', and '{}'.".format(*cols))
+        return None
+    except Exception as err:
+        print(err.args[0])
+        return None
+    return result
+
+
+def readMarkerNames(filename):
+    """List of marker names to keep: commas and surrounding whitespace dropped, empty lines
+    skipped (reference tagdigger_fun.py:921-934)."""
+    try:
+        with open(filename, mode='r') as con:
+            lines = con.readlines()
+    except IOError:
+        print("File {} not readable.".format(filename))
+        return None
+    cleaned = [ln.replace(",", "").strip() for ln in lines]
+    return [x for x in cleaned if x != ""]
+
+
+def compareTags(taglist, trim=True):
+    """Variable sites among tags of one locus: [(position, [base per tag]), ...]
+    (reference tagdigger_fun.py:376-393)."""
+    assert type(taglist) is list, "taglist must be list."
+    assert all([set(t) <= set('ATCG') for t in taglist]), "taglist must be a list of ACGT strings."
+    lengths = set(len(t) for t in taglist)
+    if len(lengths) > 1:
+        if trim:
+            taglist = [t[:min(lengths)] for t in taglist]
+        else:
+            taglist = [t.ljust(max(lengths), 'N') for t in taglist]
+    out = []
+    for i in range(len(taglist[0])):
+        col = [t[i] for t in taglist]
+        if len(set(c for c in col if c != 'N')) > 1:
+            out.append((i, col))
+    return out
+
+
+def _read_tag_table(filename, needed, header_msg, handle_row):
+    """Shared skeleton of the CSV tag readers: header check, per-row callback, error printing."""
+    names, seqs = [], []
+    try:
+        with open(filename, mode='r') as con:
+            where = None
+            for rownum, row in enumerate(_csv.reader(con), start=1):
+                if where is None:
+                    if not set(needed) <= set(row):
+                        raise Exception(header_msg)
+                    where = [row.index(c) for c in needed]
+                else:
+                    handle_row(row, where, rownum, names, seqs)
+    except IOError:
+        print("File {} not readable.".format(filename))
+        return None
+    except Exception as err:
+        print(err.args[0])
+        return None
+    return [names, seqs]
+
+
+def readTags_Merged(filename, toKeep=None, allowDuplicates=False):
+    """Merged format: marker name + tag with the variable region as [A/C] (reference
+    tagdigger_fun.py:563-618).  Names come out as marker_allele_index."""
+    def row_fn(row, where, rownum, names, seqs):
+        cell = row[where[1]]
+        if not set('[/]') < set(cell):
+            raise Exception("Characters '[/]' not found in row {}.".format(rownum))
+        marker = row[where[0]].strip()
+        if '_' in marker:
+            raise Exception("Marker {}: marker names cannot contain underscores.".format(row[where[0]]))
+        if toKeep != None and marker not in toKeep:
+            return
+        left, right = cell.find('['), cell.find(']')
+        alleles = [a.strip().upper() for a in cell[left + 1:right].split('/')]
+        tags = [(cell[:left] + a + cell[right + 1:]).upper().strip().replace('-', '') for a in alleles]
+        if not allowDuplicates and any([t in seqs for t in tags]):
+            print("Non-unique sequence found: line {0}.".format(rownum))
+            print("Marker {} skipped.".format(marker))
+            return
+        seqs.extend(tags)
+        if not all([set(t) <= set('ACGT') for t in tags]):
+            raise Exception("Tag sequence not formatted correctly in row {}.".format(rownum))
+        names.extend(["{}_{}_{}".format(marker, alleles[i], i) for i in range(len(tags))])
+    return _read_tag_table(filename, ("Marker name", "Tag sequence"),
+                           "Need 'Marker name' and 'Tag sequence' in header row.", row_fn)
+
+
+def readTags_Rows(filename, toKeep=None):
+    """One row per allele: marker name, allele name, tag (reference tagdigger_fun.py:475-514)."""
+    def row_fn(row, where, rownum, names, seqs):
+        marker = row[where[0]].strip()
+        if '_' in marker:
+            raise Exception("Marker {}: marker names cannot contain underscores.".format(marker))
+        if toKeep != None and marker not in toKeep:
+            return
+        allele = row[where[1]].strip()
+        tag = row[where[2]].upper().strip()
+        if not set(tag) <= set('ACGT'):
+            raise Exception("Tag sequence not formatted as ACGT in row {}.".format(rownum))
+        if tag in seqs:
+            raise Exception("Non-unique sequence found: line {0}.".format(rownum))
+        names.append(marker + '_' + allele)
+        seqs.append(tag)
+    return _read_tag_table(filename, ("Marker name", "Allele name", "Tag sequence"),
+                           "Need 'Marker name', 'Allele name', and 'Tag sequence' in header row.", row_fn)
+
+
+def readTags_Columns(filename, toKeep=None):
+    """One row per marker with two tags (reference tagdigger_fun.py:516-561)."""
+    def row_fn(row, where, rownum, names, seqs):
+        marker = row[where[0]].strip()
+        if '_' in marker:
+            raise Exception("Marker {}: marker names cannot contain underscores.".format(marker))
+        if toKeep != None and marker not in toKeep:
+            return
+        tag0, tag1 = row[where[1]].upper().strip(), row[where[2]].upper().strip()
+        if not set(tag0 + tag1) <= set('ACGT'):
+            raise Exception("Tag sequence not formatted as ACGT in row {}.".format(rownum))
+        if tag0 in seqs or tag1 in seqs:
+            raise Exception("Non-unique sequence found: line {0}.".format(rownum))
+        seqs.extend([tag0, tag1])
+        diff = compareTags([tag0, tag1])
+        names.append(marker + '_' + ''.join(d[1][0] for d in diff) + '_0')
+        names.append(marker + '_' + ''.join(d[1][1] for d in diff) + '_1')
+    return _read_tag_table(filename, ("Marker name", "Tag sequence 0", "Tag sequence 1"),
+                           "Need 'Marker name', 'Tag sequence 0', and 'Tag sequence 1' in header row.", row_fn)
+
+
+def readTags_UNEAK_FASTA(filename, toKeep=None):
+    """Tag pairs from a TASSEL-UNEAK FASTA: four lines per pair, '>TPn_query_len' / sequence /
+    '>TPn_hit_len' / sequence (reference tagdigger_fun.py:395-473)."""
+    names, seqs = [], []
+    try:
+        with open(filename, mode='r') as con:
+            name1 = name2 = seq1 = seq2 = None
+            len1 = len2 = 0
+            for n, line in enumerate(con):
+                part = n % 4
+                if part in (0, 2):
+                    if line[:3] != ">TP":
+                        raise Exception("Line {0} of {1} does not start with '>TP'.".format(n + 1, filename))
+                    cut = line.rfind("_")
+                    if part == 0:
+                        name1 = line[1:cut]
+                        len1 = int(line[cut + 1:].strip())     # real tag length (some are padded with A's)
+                    else:
+                        name2 = line[1:cut]
+                        if name1[:name1.find("_")] != name2[:name2.find("_")]:
+                            raise Exception("Tag name in line {0} does not match tag name in line {1}.".format(n + 1, n - 1))
+                        len2 = int(line[cut + 1:].strip())
+                    continue
+                seq = line.strip().upper()
+                seq = seq[:len1] if part == 1 else seq[:len2]
+                if not set(seq) <= set('ACGT'):
+                    raise Exception("Line {0} is not ACGT sequence.".format(n + 1))
+                if seq in seqs:
+                    raise Exception("Non-unique sequence found: line {0}.".format(n + 1))
+                if part == 1:
+                    seq1 = seq
+                    continue
+                seq2 = seq
+                marker = name1[:name1.find("_")]
+                if toKeep != None and marker not in toKeep:
+                    continue
+                shortest = min(len1, len2)
+                if len1 != len2 and seq1[:shortest] == seq2[:shortest]:
+                    print("{} skipped because tags cannot be distinguished.".format(marker))
+                    continue
+                diff = compareTags([seq1, seq2])
+                base1, base2 = diff[0][1][0], diff[0][1][1]
+                first_is_0 = base1 < base2                       # alphabetical, to match hapMap2numeric
+                names.extend([name1 + "_" + base1 + ("_0" if first_is_0 else "_1"),
+                              name2 + "_" + base2 + ("_1" if first_is_0 else "_0")])
+                seqs.extend([seq1[:shortest], seq2[:shortest]])
+    except IOError:
+        print("File {} not readable.".format(filename))
+        return None
+    except Exception as err:
+        print(err.args[0])
+        return None
+    return [names, seqs]
+
+
+def sanitizeTags(taglist):
+    """Drop every marker one of whose tags is a prefix of (or equal to) another tag, so that the
+    tag set handed to find_tags_fastq is prefix-free (reference tagdigger_fun.py:1030-1058).
+    Mutates and returns taglist.  Marker membership is a NAME-PREFIX test, as in the reference:
+    removing 'TP27' also removes 'TP276...'."""
+    assert len(taglist) == 2, "'taglist' should have two elements."
+    assert len(taglist[0]) == len(taglist[1]), \
+        "List of tag names should be the same as list of tag sequences."
+    print("\nSanitizing tags...")
+    names, seqs = taglist
+    ordered = sorted(seqs)
+    for k in range(len(ordered) - 1):
+        short = ordered[k]
+        if not ordered[k + 1].startswith(short) or short not in seqs:
+            continue
+        owner = names[seqs.index(short)]
+        marker = owner[:owner.find("_")]
+        print("Removing " + marker + " for overlap with another marker.")
+        for j in sorted((j for j in range(len(seqs)) if names[j].startswith(marker)), reverse=True):
+            print(names.pop(j))
+            print(seqs.pop(j))
+    return taglist
+
+
+def combineReadCounts(countsdict, bckeys):
+    """Per-barcode rows of every library -> per-sample rows: files in sorted order, samples in
+    order of first appearance, equal names summed (reference tagdigger_fun.py:1061-1098).
+    This is also what a multi-GPU run must equal after its all-reduce."""
+    files = sorted(bckeys.keys())
+    order, totals = [], []
+    slot = {}
+    for f in files:
+        for row, sample in enumerate(bckeys[f][1]):
+            if sample in slot:
+                k = slot[sample]
+                totals[k] = [a + b for a, b in zip(countsdict[f][row], totals[k])]
+            else:
+                slot[sample] = len(order)
+                order.append(sample)
+                totals.append(countsdict[f][row])
+    return [order, totals]
+
+
+def writeCounts(filename, counts, samnames, tagnames):
+    """Samples x tags CSV, csv.writer defaults (CRLF rows) (reference tagdigger_fun.py:1100-1111)."""
+    assert len(samnames) == len(counts), "Length of samnames should be the same as length of counts."
+    assert len(tagnames) == len(counts[0]), "Length of tagnames should be length of second dimension of counts."
+    with open(filename, mode='w', newline='') as fh:
+        out = _csv.writer(fh)
+        out.writerow([""] + tagnames)
+        for name, row in zip(samnames, counts):
+            out.writerow([name] + row)
+
+
+def extractMarkers(tagnames):
+    """[marker names in first-seen order, per marker [[allele names], [tag indices]]]
+    (reference tagdigger_fun.py:1113-1142)."""
+    if len(tagnames) != len(set(tagnames)):
+        raise Exception("Non-unique tag names found.")
+    markers, alleles, where = [], [], {}
+    for k, t in enumerate(tagnames):
+        m = t[:t.find('_')]
+        if m not in where:
+            where[m] = len(markers)
+            markers.append(m)
+            alleles.append([[], []])
+        alleles[where[m]][0].append(t[t.rfind('_') + 1:])
+        alleles[where[m]][1].append(k)
+    return [markers, alleles]
+
+
+def writeDiploidGeno(filename, counts, samnames, tagnames):
+    """0 / 1 / 2 / blank genotype calls from the allele-0 and allele-1 counts of every marker
+    (reference tagdigger_fun.py:1144-1180)."""
+    assert len(samnames) == len(counts), "Length of samnames should be the same as length of counts."
+    assert len(tagnames) == len(counts[0]), "Length of tagnames should be length of second dimension of counts."
+    markers, alleles = extractMarkers(tagnames)
+    try:
+        if not all(set(a[0]) <= {'0', '1'} for a in alleles):
+            raise Exception("All allele names must be '0' or '1'.")
+        rows = []
+        for s in range(len(samnames)):
+            calls = []
+            for a in alleles:
+                c0 = counts[s][a[1][a[0].index('0')]]
+                c1 = counts[s][a[1][a[0].index('1')]]
+                calls.append('1' if c0 > 0 and c1 > 0 else '0' if c0 > 0 else '2' if c1 > 0 else '')
+            rows.append(calls)
+        with open(filename, mode='w', newline='') as fh:
+            out = _csv.writer(fh)
+            out.writerow([""] + markers)
+            for name, calls in zip(samnames, rows):
+                out.writerow([name] + calls)
+    except IOError:
+        print("Could not write file {}.".format(filename))
+    except Exception as err:
+        print(err.args[0])
+    return None
