@@ -55,12 +55,12 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
     const uint32_t win_ch = TILE_CH + halo_ch;
     uint2 *L_conv = reinterpret_cast<uint2 *>(lds);
     uint16_t *L_mask = reinterpret_cast<uint16_t *>(lds + (size_t)win_ch * 8u);
-    uint32_t *L_misc = reinterpret_cast<uint32_t *>(lds + (size_t)win_ch * 8u + TILE_CH * 2u);   // 64 dwords
+    uint16_t *L_inv = L_mask + TILE_CH;                  // per chunk: which bytes are not bases (for the phase vote)
+    uint32_t *L_misc = reinterpret_cast<uint32_t *>(lds + (size_t)win_ch * 8u + TILE_CH * 4u);   // 64 dwords
     uint8_t *L_bidx = reinterpret_cast<uint8_t *>(L_misc + 64);
     const TileCtx cx{L_conv, win_ch, reinterpret_cast<const unsigned long long *>(L_bidx),
                      reinterpret_cast<const uint32_t *>(L_bidx + p.off_bmeta),
-                     reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir),
-                     reinterpret_cast<const uint16_t *>(L_bidx + p.off_bcand)};
+                     reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir)};
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (uint32_t i = tid; i < p.bblob_bytes / 4; i += BLOCK)
@@ -139,8 +139,10 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
 #pragma unroll
                     for (int j = 0; j < CPT; j++) {
                         const uint32_t c = j * BLOCK + tid;
+                        const uint2 pk = convert_chunk_ascii(v[j]);
                         L_mask[c] = (uint16_t)term[j];
-                        L_conv[c] = convert_chunk_ascii(v[j]);
+                        L_inv[c] = (uint16_t)pk.y;
+                        L_conv[c] = pk;
                     }
                     if (has_halo) L_conv[TILE_CH + tid] = convert_chunk(vh);
                 }
@@ -158,8 +160,10 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                         if (nx < p.nbytes && p.buf[nx] == 0x0A) term &= 0x7FFFu;
                     }
                     if (g + 16 > p.nbytes) term &= g < p.nbytes ? ((1u << (uint32_t)(p.nbytes - g)) - 1u) : 0u;
+                    const uint2 pk = convert_chunk(v[j]);
                     L_mask[c] = (uint16_t)term;
-                    L_conv[c] = convert_chunk(v[j]);
+                    L_inv[c] = (uint16_t)pk.y;
+                    L_conv[c] = pk;
                 }
                 if (has_halo) L_conv[TILE_CH + tid] = convert_chunk(vh);
                 if (hiacc & 0x80808080u) L_misc[1] = 1;
@@ -181,6 +185,10 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         uint32_t mm[CPT / 2];
 #pragma unroll
         for (int i = 0; i < CPT / 2; i++) mm[i] = reinterpret_cast<const uint32_t *>(L_mask)[tid * (CPT / 2) + i];
+        uint32_t ivw[CPT / 2 + 1];                           // invalid-byte bitmap of the span, 32 bytes per word
+#pragma unroll
+        for (int i = 0; i < CPT / 2; i++) ivw[i] = reinterpret_cast<const uint32_t *>(L_inv)[tid * (CPT / 2) + i];
+        ivw[CPT / 2] = 0;                                    // (bytes past the span count as bases: votes only)
         uint32_t cnt = 0;
 #pragma unroll
         for (int i = 0; i < CPT / 2; i++) cnt += __builtin_popcount(mm[i]);
@@ -212,11 +220,9 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                             if (i & 2u) lfirst23 |= srel << (16u * (i & 1u)); else lfirst01 |= srel << (16u * (i & 1u));
                         }
                         lcnt += 1u << sh8;
-                        if (predict) {
-                            const uint32_t iv = L_conv[srel >> 4].y;
-                            const bool good = (((iv << (srel & 15u)) & 0xFF00u) == 0) && tbase + srel + 8 <= p.nbytes;
-                            lv += (good ? 1u : 0u) << sh8;
-                        }
+                        // the line's first eight bytes are all bases?  (bit+1 <= 32: a 64-bit funnel)
+                        const uint64_t win = (((uint64_t)ivw[k + 1] << 32) | ivw[k]) >> (bit + 1u);
+                        lv += ((win & 0xFFu) == 0 ? 1u : 0u) << sh8;
                     }
                     i++;
                 }
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                     uint32_t srel = 0;
                     if (!nth_wanted(q, srel)) break;
                     const uint32_t c0f = srel >> 4;
-                    const bool deferred = c0f + p.nch > win_ch || ((L_conv[c0f].y >> (15u - (srel & 15u))) & 1u);
+                    const bool deferred = c0f + p.nch > win_ch || ((L_conv[c0f].y >> (srel & 15u)) & 1u);
                     if (!deferred) continue;
                     // (a non-blank non-base first byte simply comes back as "no barcode")
                     const uint64_t res = match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true);

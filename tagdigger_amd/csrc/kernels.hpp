@@ -44,6 +44,7 @@ constexpr uint64_t FLAG_INC = 2ull << 62;  // tile state: inclusive prefix publi
 constexpr uint64_t VAL_MASK = (1ull << 62) - 1;
 constexpr uint32_t BDIR_BASES = 5;         // barcode directory is keyed on the first 5 bases
 constexpr uint32_t BDIR_SIZE = 1u << (2 * BDIR_BASES);
+constexpr uint32_t BMETA_LAST = 1u << 12;  // bmeta: len (6 bits) | tag offset (6 bits) << 6 | last-of-bucket | row << 16
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
 // per-line result of the matcher (top two bits) | count-matrix cell
 constexpr uint64_t R_NONE = 0, R_BAR = 1ull << 62, R_TAG = 2ull << 62, R_DEFER = 3ull << 62, R_CELL = (1ull << 62) - 1;
@@ -66,7 +67,8 @@ struct KParams {
     uint32_t *ticket;        // tile dispenser
     uint32_t ntiles;
     uint32_t halo;           // bytes after the tile also staged in LDS (multiple of 16)
-    // barcode index blob (copied to LDS): bval u64[nent] | bmeta u32[nent] | bdir u16[1024] | bcand u16[ncand]
+    // barcode index blob (copied to LDS): bval u64[nent] | bmeta u32[nent] | bdir u16[1024]; entries are stored
+    // bucket by bucket (an entry shorter than the directory key is repeated in every bucket it covers)
     const uint32_t *bblob;
     uint32_t bblob_bytes, off_bmeta, off_bdir, off_bcand;
     // tag hash table: buckets of 64 B (W<=3) or 128 B; dword 0 = overflow flag, then slots of
@@ -153,6 +155,13 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Between LDS stores by some lanes of a wave and LDS loads of the same locations by other lanes of
+// the SAME wave: the hardware runs one wave's LDS operations in order; this keeps the compiler from
+// reordering them (the accesses use different element types) and drains the stores.
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // wave-level inclusive scan (64 lanes)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -186,7 +195,7 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 constexpr int PROF_PHASES = 12;
 
 // ---------------------------------------------------------------- the kernel
-// 2-bit codes (first base in the top bits) and per-base invalid flags (bit 15 = first base)
+// 2-bit codes (first base in the top bits) and per-base invalid flags (bit k = byte k of the chunk)
 // of one 16-byte chunk.  A 0, C 1, T 2, G 3 = (byte >> 1) & 3; [ACGTacgt] are the valid bytes.
 __device__ __forceinline__ uint2 convert_chunk(const uint4 &v) {
     const uint32_t x[4] = {v.x, v.y, v.z, v.w};
@@ -198,7 +207,7 @@ __device__ __forceinline__ uint2 convert_chunk(const uint4 &v) {
         uint32_t diff = (x[d] & 0xDFDFDFDFu) ^ expect;            // 0 where the byte is a base
         uint32_t nz = ((((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) >> 7) & 0x01010101u;
         cw = (cw << 8) | udot4(code, 0x01041040u, 0u);
-        iw = (iw << 4) | udot4(nz, 0x01020408u, 0u);
+        iw |= udot4(nz, 0x08040201u, 0u) << (4 * d);
     }
     return make_uint2(cw, iw);
 }
@@ -215,13 +224,13 @@ __device__ __forceinline__ uint2 convert_chunk_ascii(const uint4 &v) {
         uint32_t diff = (x[d] & 0xDFDFDFDFu) ^ expect;            // 0 where the byte is a base, < 0x80 otherwise
         uint32_t nz = (diff + 0x7F7F7F7Fu) & 0x80808080u;
         cw = (cw << 8) | udot4(code, 0x01041040u, 0u);
-        // 0x80 * (first byte -> weight 8 ... last -> 1), two dwords per accumulator
-        if (d == 0) ihi = udot4(nz, 0x10204080u, 0u);
-        else if (d == 1) ihi = udot4(nz, 0x01020408u, ihi);
-        else if (d == 2) ilo = udot4(nz, 0x10204080u, 0u);
-        else ilo = udot4(nz, 0x01020408u, ilo);
+        // 0x80 * (first byte -> weight 1 ... ), two dwords per accumulator
+        if (d == 0) ilo = udot4(nz, 0x08040201u, 0u);
+        else if (d == 1) ilo = udot4(nz, 0x80402010u, ilo);
+        else if (d == 2) ihi = udot4(nz, 0x08040201u, 0u);
+        else ihi = udot4(nz, 0x80402010u, ihi);
     }
-    return make_uint2(cw, ((ihi >> 7) << 8) | (ilo >> 7));
+    return make_uint2(cw, ((ihi >> 7) << 8) | (ilo >> 7));   // each accumulator is 128 * (8 flag bits)
 }
 // 16-bit mask of bytes equal to '\n' in an all-ASCII chunk, and whether it holds any '\r'
 __device__ __forceinline__ uint32_t nl_mask16_ascii(const uint4 &v, uint32_t &cr_absent_acc) {
@@ -249,7 +258,7 @@ struct TileCtx {
     uint32_t win_ch;                     // how many of them
     const unsigned long long *L_bval;    // barcode index (LDS copy)
     const uint32_t *L_bmeta;
-    const uint16_t *L_bdir, *L_bcand;
+    const uint16_t *L_bdir;
 };
 
 // gpos: absolute position of the line's first byte; srel: the same relative to the tile (fast mode).
@@ -274,12 +283,12 @@ __device__ __forceinline__ uint64_t match_line(const KParams &p, const TileCtx &
     const uint32_t win_ch = cx.win_ch;
     const unsigned long long *L_bval = cx.L_bval;
     const uint32_t *L_bmeta = cx.L_bmeta;
-    const uint16_t *L_bdir = cx.L_bdir, *L_bcand = cx.L_bcand;
+    const uint16_t *L_bdir = cx.L_bdir;
     if (MODE != ML_SLOW && !slow) {
         const uint32_t c0f = srel >> 4;
         if (c0f + p.nch > win_ch) return R_DEFER;
         // first byte is not a base: a blank to strip (slow path), or simply no match
-        if ((L_conv[c0f].y >> (15u - (srel & 15u))) & 1u) return R_DEFER;
+        if ((L_conv[c0f].y >> (srel & 15u)) & 1u) return R_DEFER;
     }
     if (MODE != ML_FAST && slow) {
         while (gpos < p.nbytes && is_blank(p.buf[gpos])) gpos++;   // ends at the terminator at the latest
@@ -299,19 +308,19 @@ __device__ __forceinline__ uint64_t match_line(const KParams &p, const TileCtx &
             else e = convert_chunk(load_chunk(p, g0 + 16ull * i));
         }
         codes[i] = e.x;
-        if (i & 1) inv[i >> 1] |= e.y; else inv[i >> 1] |= e.y << 16;
+        if (i & 1) inv[i >> 1] |= e.y << 16; else inv[i >> 1] |= e.y;       // 32 bases per word, first base in bit 0
     }
     codes[NCHMAX] = 0;
-    if ((NCHMAX & 1)) inv[NCHMAX >> 1] |= 0xFFFFu;   // padding half-word is invalid
+    if ((NCHMAX & 1)) inv[NCHMAX >> 1] |= 0xFFFF0000u;   // padding half-word is invalid
     // number of leading valid bases of the read
-    inv[0] &= 0xFFFFFFFFu >> a;
+    inv[0] &= 0xFFFFFFFFu << a;
     uint32_t nvalid = 0;
     {
         bool found = false;
 #pragma unroll
         for (int i = 0; i < (NCHMAX + 1) / 2; i++) {
             if (!found) {
-                if (inv[i]) { nvalid += __builtin_clz(inv[i]); found = true; }
+                if (inv[i]) { nvalid += __builtin_ctz(inv[i]); found = true; }
                 else nvalid += 32;
             }
         }
@@ -329,22 +338,20 @@ __device__ __forceinline__ uint64_t match_line(const KParams &p, const TileCtx &
         // (inside phase 2) fetch packed chunks + alignment
     // ---- barcode + cut site (reference :257)
     const uint64_t K = ((uint64_t)S[0] << 32) | S[1];
-    uint32_t ci = L_bdir[S[0] >> (32 - 2 * BDIR_BASES)];
+    uint32_t ci = L_bdir[S[0] >> (32 - 2 * BDIR_BASES)];     // entries of a bucket are contiguous
     uint32_t meta = 0;
     bool bhit = false;
     if (ci != 0xFFFFu) {
         for (;;) {
-            uint32_t e = L_bcand[ci];
-            uint32_t m = L_bmeta[e & 0x7FFFu];
-            uint32_t len = m & 63u;
-            if (len <= nvalid && ((K ^ L_bval[e & 0x7FFFu]) >> (64u - 2u * len)) == 0) { meta = m; bhit = true; break; }
-            if (e & 0x8000u) break;
+            const uint32_t m = L_bmeta[ci];
+            const uint32_t len = m & 63u;
+            if (len <= nvalid && ((K ^ L_bval[ci]) >> (64u - 2u * len)) == 0) { meta = m; bhit = true; break; }
+            if (m & BMETA_LAST) break;
             ci++;
         }
     }
-        // barcode directory walk
     if (!bhit) return R_NONE;
-    const uint32_t off = (meta >> 6) & 1023u, row = meta >> 16;
+    const uint32_t off = (meta >> 6) & 63u, row = meta >> 16;
     if (nvalid <= off) return R_BAR;
     const uint32_t nrem = nvalid - off;
     // ---- tag (reference :260): bases off.. of the read, as 64-bit words
@@ -435,7 +442,6 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_count(const KParam
     const unsigned long long *L_bval = reinterpret_cast<const unsigned long long *>(L_bidx);
     const uint32_t *L_bmeta = reinterpret_cast<const uint32_t *>(L_bidx + p.off_bmeta);
     const uint16_t *L_bdir = reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir);
-    const uint16_t *L_bcand = reinterpret_cast<const uint16_t *>(L_bidx + p.off_bcand);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_count(const KParam
     const uint64_t first_line = p.first_line + carried;
 
     // ------------------------------------------------------------ per-read matcher (match_line above)
-    const TileCtx cx{L_conv, win_ch, L_bval, L_bmeta, L_bdir, L_bcand};
+    const TileCtx cx{L_conv, win_ch, L_bval, L_bmeta, L_bdir};
     auto match_read = [&](uint64_t gpos, uint32_t srel, bool slow) -> uint64_t {
         return match_line<W, ML_BOTH>(p, cx, gpos, srel, slow);
     };

@@ -195,7 +195,7 @@ FFn pick_fast(int tile_kb, int W) { return tile_kb == 32 ? pick_fast_w<8>(W) : p
 
 size_t lds_bytes_fast(const td_handle *h, int tile_kb) {
     size_t tile_ch = (size_t)tile_kb * 1024 / 16, halo_ch = h->halo / 16;
-    return (tile_ch + halo_ch) * 8 + tile_ch * 2 + 256 + h->bblob_bytes;
+    return (tile_ch + halo_ch) * 8 + tile_ch * 4 + 256 + h->bblob_bytes;
 }
 
 size_t lds_bytes(const td_handle *h, int tile_kb) {
@@ -432,46 +432,48 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
     rc = rt.run();
     if (rc) { g_bad = rt.bad; return fail(rc, rc == TD_E_OVERLAP ? "overlapping tags" : "tag index build failed"); }
 
-    // ---- barcode blob: bval u64[n] | bmeta u32[n] | bdir u16[1024] | bcand u16[ncand]
+    // ---- barcode blob: bval u64[ne] | bmeta u32[ne] | bdir u16[1024]; entries bucket by bucket
     const size_t nb = rb.out.size();
-    if (nb > 32767) return fail(TD_E_LIMIT, "more than 32767 barcode+cutsite entries");
     if (barnum > 65535) return fail(TD_E_LIMIT, "more than 65535 barcodes");
     uint32_t max_off = 0;
-    std::vector<uint64_t> bval(nb);
-    std::vector<uint32_t> bmeta(nb);
-    std::vector<std::vector<uint16_t>> buckets(tdk::BDIR_SIZE);
+    std::vector<std::vector<uint32_t>> buckets(tdk::BDIR_SIZE);
+    std::vector<uint64_t> eval(nb);
+    std::vector<uint32_t> emeta(nb);
     for (size_t e = 0; e < nb; e++) {
         const std::string &s = rb.out[e].first;
         const uint32_t row = rb.out[e].second;
         if (s.size() > 32) return fail(TD_E_LIMIT, "barcode+cutsite longer than 32 bases");
         const uint32_t off = tagoff[row];
-        if (off > 1023) return fail(TD_E_LIMIT, "tag offset beyond 1023 bases");
+        if (off > 63) return fail(TD_E_LIMIT, "tag offset beyond 63 bases");
         max_off = std::max(max_off, off);
-        pack_bases(s, &bval[e], 1);
-        bmeta[e] = (uint32_t)s.size() | (off << 6) | (row << 16);
+        pack_bases(s, &eval[e], 1);
+        emeta[e] = (uint32_t)s.size() | (off << 6) | (row << 16);
         const uint32_t L = (uint32_t)s.size();
-        const uint32_t base = (uint32_t)(bval[e] >> (64 - 2 * tdk::BDIR_BASES));
+        const uint32_t base = (uint32_t)(eval[e] >> (64 - 2 * tdk::BDIR_BASES));
         const uint32_t span = L >= tdk::BDIR_BASES ? 1u : 1u << (2 * (tdk::BDIR_BASES - L));
-        for (uint32_t k = 0; k < span; k++) buckets[base + k].push_back((uint16_t)e);
+        for (uint32_t k = 0; k < span; k++) buckets[base + k].push_back((uint32_t)e);
     }
-    std::vector<uint16_t> bdir(tdk::BDIR_SIZE, 0xFFFF), bcand;
+    std::vector<uint16_t> bdir(tdk::BDIR_SIZE, 0xFFFF);
+    std::vector<uint64_t> bval;
+    std::vector<uint32_t> bmeta;
     for (uint32_t b = 0; b < tdk::BDIR_SIZE; b++) {
         if (buckets[b].empty()) continue;
-        if (bcand.size() + buckets[b].size() > 65534) return fail(TD_E_LIMIT, "barcode directory too large");
-        bdir[b] = (uint16_t)bcand.size();
-        for (size_t k = 0; k < buckets[b].size(); k++)
-            bcand.push_back(buckets[b][k] | (k + 1 == buckets[b].size() ? 0x8000u : 0u));
+        if (bval.size() + buckets[b].size() > 65534) return fail(TD_E_LIMIT, "barcode directory too large");
+        bdir[b] = (uint16_t)bval.size();
+        for (size_t k = 0; k < buckets[b].size(); k++) {
+            bval.push_back(eval[buckets[b][k]]);
+            bmeta.push_back(emeta[buckets[b][k]] | (k + 1 == buckets[b].size() ? tdk::BMETA_LAST : 0u));
+        }
     }
-    if (bcand.size() & 1) bcand.push_back(0x8000);
-    h->off_bmeta = (uint32_t)(nb * 8);
-    h->off_bdir = h->off_bmeta + (uint32_t)((nb * 4 + 7) / 8 * 8);
-    h->off_bcand = h->off_bdir + tdk::BDIR_SIZE * 2;
-    h->bblob_bytes = (h->off_bcand + (uint32_t)bcand.size() * 2 + 15) / 16 * 16;
+    const size_t ne = bval.size();
+    h->off_bmeta = (uint32_t)(ne * 8);
+    h->off_bdir = h->off_bmeta + (uint32_t)((ne * 4 + 7) / 8 * 8);
+    h->off_bcand = 0;
+    h->bblob_bytes = (h->off_bdir + tdk::BDIR_SIZE * 2 + 15) / 16 * 16;
     std::vector<uint8_t> blob(h->bblob_bytes, 0);
-    memcpy(blob.data(), bval.data(), nb * 8);
-    memcpy(blob.data() + h->off_bmeta, bmeta.data(), nb * 4);
+    memcpy(blob.data(), bval.data(), ne * 8);
+    memcpy(blob.data() + h->off_bmeta, bmeta.data(), ne * 4);
     memcpy(blob.data() + h->off_bdir, bdir.data(), tdk::BDIR_SIZE * 2);
-    memcpy(blob.data() + h->off_bcand, bcand.data(), bcand.size() * 2);
 
     // ---- tag table
     size_t maxlen = 0;

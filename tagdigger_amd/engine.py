@@ -129,8 +129,14 @@ class Engine:
         n = len(data)
         lines = C.c_uint64(0)
         if n:
-            buf = (C.c_char * n).from_buffer_copy(data) if not isinstance(data, (C.Array,)) else data
-            B.check(self._L.td_count_host(self._h, buf, n, first_line, effective_maxreads(maxreads),
+            # no copy: bytes objects and ctypes arrays are passed by address, numpy arrays by .ctypes.data
+            if isinstance(data, (bytes, C.Array)):
+                ptr = data
+            elif hasattr(data, "ctypes"):
+                ptr = C.c_void_p(data.ctypes.data)
+            else:
+                ptr = (C.c_char * n).from_buffer_copy(data)
+            B.check(self._L.td_count_host(self._h, ptr, n, first_line, effective_maxreads(maxreads),
                                           1 if tassel_tagcount else 0, C.byref(lines)))
         return lines.value
 

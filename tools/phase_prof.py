@@ -16,8 +16,8 @@ NAMES_EXACT = ["ticket", "load+masks+LDS store", "barrier after load", "block sc
          "  p2: fetch+convert", "  p2: barcode", "  p2: tag probes", "-"]
 
 
-NAMES = ["loop head", "A: wait bytes + masks + pack", "barrier A", "B: scan + local votes", "C: vote",
-         "-", "D: match + commit (thread 0)", "end barrier (others matching)", "-", "-", "-", "-"]
+NAMES = ["loop head", "A: wait bytes + masks + pack", "-", "B: scan + local votes", "C: vote",
+         "-", "D: match + commit", "-", "-", "-", "-", "-"]
 
 
 def main():

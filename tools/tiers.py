@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Throughput tiers T2/T3 of SURVEY section 8d (never the bench `value`, which is T1 = HBM-resident):
+T2 host buffer -> pinned staging -> hipMemcpyAsync overlapped with counting (td_count_host);
+T3 end to end from a file, plain and gzip (td_count_file: fread / zlib inflate on one host thread)."""
+import gzip, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import tagdigger_amd
+from tagdigger_amd.synth import SynthConfig
+from helpers import synth_expected
+
+reads = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
+cfg = SynthConfig(nreads=reads, nbar=384, nmarkers=50_000, seed=3)
+eng = tagdigger_amd.Engine(0)
+nb = cfg.nbytes()
+d = eng.dev_alloc(nb)
+cfg.fill_device(eng, d, 0, reads)
+host = eng.d2h(d, nb)
+eng.dev_free(d)
+want, _ = synth_expected(cfg, 0, reads)
+eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+
+def check():
+    assert (eng.counts_numpy() == want).all()
+
+eng.count_bytes(host); check(); eng.reset()
+t0 = time.perf_counter(); eng.count_bytes(host); eng.sync(); dt = time.perf_counter() - t0; check()
+print("T2 host buffer   : %6.2f Mreads/s  %6.2f GB/s  (%.2f GB, includes one host->pinned memcpy)" % (reads / dt / 1e6, nb / dt / 1e9, nb / 1e9))
+tmp = os.environ.get("TMPDIR", "/tmp")
+plain = os.path.join(tmp, "tiers_lib.fq")
+open(plain, "wb").write(host)
+eng.reset(); t0 = time.perf_counter(); eng.count_file(plain); eng.sync(); dt = time.perf_counter() - t0; check()
+print("T3 plain file    : %6.2f Mreads/s  %6.2f GB/s  (page cache warm)" % (reads / dt / 1e6, nb / dt / 1e9))
+gzp = plain + ".gz"
+t0 = time.perf_counter()
+with gzip.open(gzp, "wb", compresslevel=1) as fh:
+    fh.write(host)
+tz = time.perf_counter() - t0
+eng.reset(); t0 = time.perf_counter(); eng.count_file(gzp); eng.sync(); dt = time.perf_counter() - t0; check()
+print("T3 gzip file     : %6.2f Mreads/s  %6.2f GB/s uncompressed (single-thread zlib inflate; %.2f GB gz, made in %.1f s)" % (
+    reads / dt / 1e6, nb / dt / 1e9, os.path.getsize(gzp) / 1e9, tz))
+os.remove(plain); os.remove(gzp)
