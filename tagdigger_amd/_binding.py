@@ -1,8 +1,8 @@
 """ctypes binding of libtagdig.so (include/tagdig.h).
 
 There is no fallback: if the library or a HIP runtime cannot be loaded, or no
-GPU is present, importing/using this module raises.  The CPU oracle under
-oracle/ is test infrastructure and is never imported from here.
+GPU is present, importing/using this module raises.  The CPU checker kept elsewhere in the
+repository is test infrastructure and is never imported from here.
 
 One HIP runtime per process: libtagdig.so carries no NEEDED entry for
 libamdhip64, so this module first loads exactly one runtime with RTLD_GLOBAL --
