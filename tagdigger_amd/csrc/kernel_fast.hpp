@@ -196,51 +196,36 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         if (lane == 63) L_misc[4 + wave] = incl;
         const uint32_t span0 = tid * CPT * 16u;
 
-        // ---------------- C: phase.  One pass over this thread's terminators does two things by LOCAL
-        // ordinal class (ordinal within the thread, mod 4; the in-tile class follows once the scan
-        // gives the thread's exclusive prefix): it votes -- per class, lines opening with eight valid
-        // bases -- and it remembers, per class, the first line start and how many there are.
+        // ---------------- C: phase.  Each thread votes with the FIRST line that starts in its span
+        // (256 samples per tile are plenty): does it open with eight valid bases?  No loop: first set
+        // bit of the span's terminator mask, an 8-bit window of the invalid-byte bitmap.
         uint32_t r0 = code & 3u;
         const bool predict = (code & FX_PREDICT) != 0 && t != 0;
-        uint32_t lv = 0;                 // 4 x 8-bit votes
-        uint32_t lcnt = 0;               // 4 x 8-bit line counts
-        uint32_t lfirst01 = 0, lfirst23 = 0;   // 4 x 16-bit first line start (relative to the tile)
+        bool vote_good = false;
         {
-            uint32_t i = 0;
+            uint32_t fpos = 0, lo = 0, hi = 0;
+            bool found = false;
 #pragma unroll
-            for (int k = 0; k < CPT / 2; k++) {
-                uint32_t m = mm[k];
-                while (m) {
-                    const uint32_t bit = __builtin_ctz(m);
-                    m &= m - 1;
-                    const uint32_t srel = span0 + 32u * k + bit + 1u;
-                    const uint32_t sh8 = 8u * (i & 3u);
-                    if (tbase + srel < p.nbytes) {
-                        if (((lcnt >> sh8) & 0xFFu) == 0) {
-                            if (i & 2u) lfirst23 |= srel << (16u * (i & 1u)); else lfirst01 |= srel << (16u * (i & 1u));
-                        }
-                        lcnt += 1u << sh8;
-                        // the line's first eight bytes are all bases?  (bit+1 <= 32: a 64-bit funnel)
-                        const uint64_t win = (((uint64_t)ivw[k + 1] << 32) | ivw[k]) >> (bit + 1u);
-                        lv += ((win & 0xFFu) == 0 ? 1u : 0u) << sh8;
-                    }
-                    i++;
-                }
+            for (int k = CPT / 2 - 1; k >= 0; k--) {
+                if (mm[k]) { fpos = 32u * k + __builtin_ctz(mm[k]); lo = ivw[k]; hi = ivw[k + 1]; found = true; }
             }
+            // line start = fpos + 1 (<= 32 past the word's base): a 64-bit funnel
+            const uint64_t win = (((uint64_t)hi << 32) | lo) >> ((fpos & 31u) + 1u);
+            vote_good = found && (win & 0xFFu) == 0 && tbase + span0 + fpos + 9u <= p.nbytes;
         }
         lds_barrier();
         uint32_t wbase = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; w++) { uint32_t x = L_misc[4 + w]; if (w < wave) wbase += x; total += x; }
         const uint32_t excl = wbase + incl - cnt;
-        TD_STAMP(3);   // B: scan (+ local votes)
+        TD_STAMP(3);   // B: scan
         if (predict) {
             uint32_t *bank = L_misc + 16 + 4 * parity;
-            // local class c is in-tile class (c + excl) & 3
+            // the first line of the span follows in-tile ordinal excl: its class is excl & 3
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const uint32_t n = (lv >> (8 * c)) & 0xFFu;
-                if (n) atomicAdd(&bank[(c + excl) & 3u], n);
+                const uint64_t bl = __ballot(vote_good && (excl & 3u) == (uint32_t)c);
+                if (lane == 0 && bl) atomicAdd(&bank[c], (uint32_t)__builtin_popcountll(bl));
             }
             lds_barrier();
             const uint32_t a0 = bank[0], a1 = bank[1], a2 = bank[2], a3 = bank[3];
@@ -280,9 +265,23 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
             // ------------ D: the wanted lines that start in this thread's span: in-tile ordinal i is
             // followed by a wanted line iff i == r0 (mod 4), i.e. local class (r0 - excl) & 3.  Tile 0
             // also owns the buffer's first line (ordinal -1 == 3 mod 4).
+            // The thread's wanted lines follow its local terminators number lc, lc+4, ... : their count
+            // is a closed form and the first one is the lc-th set bit of the span mask (no loop).
             const uint32_t lc = (r0 - excl) & 3u;
-            uint32_t nw = (lcnt >> (8u * lc)) & 0xFFu;
-            uint32_t w0 = ((lc & 2u) ? lfirst23 : lfirst01) >> (16u * (lc & 1u)) & 0xFFFFu;
+            uint32_t nw = cnt > lc ? (cnt - lc + 3u) >> 2 : 0u;
+            uint32_t w0 = 0;
+            {
+                uint32_t r = lc, kbase = 0, m = mm[0];
+#pragma unroll
+                for (int k = 0; k < CPT / 2 - 1; k++) {
+                    const uint32_t c = __builtin_popcount(mm[k]);
+                    const bool next = kbase == 32u * k && r >= c;      // still in word k and it holds fewer than r+1 bits
+                    if (next) { r -= c; kbase = 32u * (k + 1); m = mm[k + 1]; }
+                }
+                const uint32_t m1 = m & (m - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
+                const uint32_t sel = r == 0 ? m : r == 1 ? m1 : r == 2 ? m2 : m3;
+                w0 = span0 + kbase + (sel ? __builtin_ctz(sel) : 0u) + 1u;
+            }
             const bool own_first = t == 0 && tid == 0 && p.nbytes > 0 && r0 == 3u;
             // General enumeration of this thread's q-th wanted line (limit-aware); the common case
             // -- no limit, at most one wanted line in the span -- never calls it.
@@ -307,7 +306,8 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                 }
                 return false;
             };
-            const bool simple = !use_limit && !own_first && nw <= 1;
+            // (closed forms assume every terminator's successor lies inside the buffer: not in its last tile)
+            const bool simple = !use_limit && !own_first && nw <= 1 && tbase + TILE + p.halo <= p.nbytes;
             if (p.dbg & DBG_NO_PHASE2) nw = 0;
             uint32_t ndefer = 0;
 #pragma nounroll
