@@ -270,15 +270,26 @@ struct TileCtx {
 // MODE: ML_FAST  packed chunks only, returns R_DEFER when the raw bytes are needed (no global-memory code at all);
 //       ML_SLOW  raw bytes only;   ML_BOTH  chosen by `slow`, R_DEFER from the fast branch (exact kernel).
 enum { ML_FAST = 0, ML_SLOW = 1, ML_BOTH = 2 };
+// The matcher comes in two halves so that a caller can put other work between them:
+//   match_prepare  everything up to the tag hash and the load of the first 16 bytes of the tag
+//                  bucket (left in flight); returns R_NONE / R_BAR / R_DEFER, or R_PEND with `pd` filled
+//   match_finish   the rest of the bucket, the masked compares, the short list -> R_BAR or R_TAG | cell
+template <int W> struct Pending {
+    uint64_t R[W];          // the read from the tag offset on, packed
+    uint32_t nrem;          // valid bases there
+    uint32_t row;           // count-matrix row (barcode)
+    uint32_t bk;            // tag bucket to probe, or ~0u: short list only
+    uint4 b0;               // first 16 bytes of that bucket
+};
+constexpr uint64_t R_PEND = 1ull << 61;   // (kind bits 0) match_prepare: finish with match_finish
+
 template <int W, int MODE>
-__device__ __forceinline__ uint64_t match_line(const KParams &p, const TileCtx &cx, uint64_t gpos, uint32_t srel, bool slow) {
+__device__ __forceinline__ uint64_t match_prepare(const KParams &p, const TileCtx &cx, uint64_t gpos, uint32_t srel, bool slow,
+                                                  Pending<W> &pd) {
     if (MODE == ML_FAST) slow = false;
     if (MODE == ML_SLOW) slow = true;
     constexpr int NCHMAX = 2 * W + 3;
     constexpr int NS = 2 * W + 4;      // aligned 16-base words kept (zero padded)
-    constexpr int BUCKET_U4 = W <= 3 ? 4 : 8;          // 64- or 128-byte buckets
-    constexpr int SLOT_DW = 2 * W + 1;
-    constexpr int SPB = (BUCKET_U4 * 4 - 1) / SLOT_DW;  // slots per bucket
     const uint2 *L_conv = cx.L_conv;
     const uint32_t win_ch = cx.win_ch;
     const unsigned long long *L_bval = cx.L_bval;
@@ -372,6 +383,27 @@ __device__ __forceinline__ uint64_t match_line(const KParams &p, const TileCtx &
         uint32_t bot = (uint32_t)(((lo << sh) >> 32));
         R[w] = ((uint64_t)top << 32) | bot;
     }
+    constexpr int BUCKET_U4_ = W <= 3 ? 4 : 8;
+#pragma unroll
+    for (int w = 0; w < W; w++) pd.R[w] = R[w];
+    pd.nrem = nrem; pd.row = row; pd.bk = ~0u;
+    pd.b0 = make_uint4(0u, 0u, 0u, 0u);
+    if (nrem >= p.m_bases && !(p.dbg & DBG_NO_PROBE)) {
+        pd.bk = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
+        pd.b0 = p.buckets[(size_t)pd.bk * BUCKET_U4_];       // in flight: first used by match_finish
+    } else if (p.nshort == 0) {
+        return R_BAR;
+    }
+    return R_PEND;
+}
+
+template <int W>
+__device__ __forceinline__ uint64_t match_finish(const KParams &p, const Pending<W> &pd) {
+    constexpr int BUCKET_U4 = W <= 3 ? 4 : 8;          // 64- or 128-byte buckets
+    constexpr int SLOT_DW = 2 * W + 1;
+    constexpr int SPB = (BUCKET_U4 * 4 - 1) / SLOT_DW;  // slots per bucket
+    const uint64_t *R = pd.R;
+    const uint32_t nrem = pd.nrem;
     auto prefix_eq = [&](const uint64_t *T, uint32_t len) -> bool {
         bool ok = true;
 #pragma unroll
@@ -384,14 +416,14 @@ __device__ __forceinline__ uint64_t match_line(const KParams &p, const TileCtx &
     };
     bool thit = false;
     uint32_t col = 0;
-    if (nrem >= p.m_bases && !(p.dbg & DBG_NO_PROBE)) {
-        uint32_t bk = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
+    if (pd.bk != ~0u) {
+        uint32_t bk = pd.bk;
         for (uint32_t probes = 0; probes <= p.bucket_mask; probes++) {
             const uint4 *bp = p.buckets + (size_t)bk * BUCKET_U4;
             uint32_t raw[BUCKET_U4 * 4];
 #pragma unroll
             for (int q = 0; q < BUCKET_U4; q++) {
-                uint4 v = bp[q];
+                uint4 v = (q == 0 && probes == 0) ? pd.b0 : bp[q];
                 raw[4 * q] = v.x; raw[4 * q + 1] = v.y; raw[4 * q + 2] = v.z; raw[4 * q + 3] = v.w;
             }
 #pragma unroll
@@ -416,9 +448,16 @@ __device__ __forceinline__ uint64_t match_line(const KParams &p, const TileCtx &
             if (len <= nrem && ((R[0] ^ tv) >> (64u - 2u * len)) == 0) { thit = true; col = v.w; break; }
         }
     }
-       // tag hash probes (+ short list)
     if (!thit) return R_BAR;
-    return R_TAG | ((uint64_t)row * p.ncols + col);
+    return R_TAG | ((uint64_t)pd.row * p.ncols + col);
+}
+
+// both halves back to back
+template <int W, int MODE>
+__device__ __forceinline__ uint64_t match_line(const KParams &p, const TileCtx &cx, uint64_t gpos, uint32_t srel, bool slow) {
+    Pending<W> pd;
+    const uint64_t r = match_prepare<W, MODE>(p, cx, gpos, srel, slow, pd);
+    return r == R_PEND ? match_finish<W>(p, pd) : r;
 }
 
 #ifndef TD_WAVES_PER_SIMD
