@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--stagger", type=int, default=-1)
+    ap.add_argument("--slabs", type=int, default=0)
+    ap.add_argument("--split", type=int, default=-1)
     ap.add_argument("--debug-ablate", type=int, default=0, help="timing-only kernel ablation bits (implies --no-check)")
     args = ap.parse_args()
 
@@ -76,6 +78,10 @@ def main():
         eng.set_option("blocks_per_cu", args.blocks_per_cu)
     if args.stagger >= 0:
         eng.set_option("stagger", args.stagger)
+    if args.slabs:
+        eng.set_option("slabs", args.slabs)
+    if args.split >= 0:
+        eng.set_option("split", args.split)
     if args.debug_ablate:
         eng.set_option("debug_ablate", args.debug_ablate)
         args.no_check = True
@@ -129,7 +135,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kms, klaunches = eng.kernel_time_ms()
-    fixups = eng.debug_counters()[12]
+    fixups = eng.debug_counters()[11]
     eng.set_option("timing", 0)
 
     if world > 1:

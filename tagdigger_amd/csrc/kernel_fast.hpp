@@ -29,6 +29,7 @@ namespace tdk {
 constexpr uint32_t TI_COUNT_MASK = 0xFFFFFFu;   // tile_info: terminators in the tile
 constexpr uint32_t TI_R0_SHIFT = 24;            //            phase (r0) the tile was counted under
 constexpr uint32_t TI_HI = 1u << 26;            //            tile holds a byte >= 0x80
+constexpr uint32_t TI_DIRECT_BIT = 1u << 27;    //            (split path) nothing was counted for this tile yet
 // fix-up queue entry: {tile, code, P lo, P hi}; code = r0 | flags
 constexpr uint32_t FX_NEG = 4;                  // subtract instead of add
 constexpr uint32_t FX_LIMIT = 8;                // apply the maxreads limit (needs P)
@@ -392,34 +393,49 @@ __global__ __launch_bounds__(1024) void k_resolve(const FParams fp) {
         if (slot < fp.fix_cap) fp.fixlist[slot] = make_uint4(tile, code, (uint32_t)P, (uint32_t)(P >> 32));
         else atomicOr(p.stats + ST_ERR, ERR_SPIN);   // cannot happen: the queue holds 3 entries per tile
     };
-    for (uint32_t base = 0; base < p.ntiles; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint32_t info = i < p.ntiles ? fp.tile_info[i] : 0u;
-        const unsigned long long v = info & TI_COUNT_MASK;
-        unsigned long long inc = v;
+    constexpr uint32_t IPT = 16;                          // tiles per thread per step
+    for (uint32_t base = 0; base < p.ntiles; base += 1024 * IPT) {
+        const uint32_t i0 = base + tid * IPT;
+        uint32_t info[IPT];
+        unsigned long long local = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < IPT; k++) {
+            info[k] = i0 + k < p.ntiles ? fp.tile_info[i0 + k] : 0u;
+            local += info[k] & TI_COUNT_MASK;
+        }
+        unsigned long long inc = local;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { unsigned long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
         unsigned long long off = carry;
         for (int w = 0; w < wave; w++) off += wsum[w];
-        if (i < p.ntiles) {
-            const uint64_t P = off + inc - v;                          // terminators before tile i
+        unsigned long long run = off + inc - local;      // terminators before this thread's first tile
+#pragma unroll
+        for (uint32_t k = 0; k < IPT; k++) {
+            const uint32_t i = i0 + k;
+            if (i >= p.ntiles) break;
+            const unsigned long long v = info[k] & TI_COUNT_MASK;
+            const uint64_t P = run;                                        // terminators before tile i
+            run += v;
             const uint32_t truth = (4u - (uint32_t)((first_line + P) & 3)) & 3u;   // ordinals == truth (mod 4) precede sequence lines
-            const uint32_t pred = (info >> TI_R0_SHIFT) & 3u;
+            const uint32_t pred = (info[k] >> TI_R0_SHIFT) & 3u;
             // lines of this tile: first_line+P (only tile 0's own first line) .. first_line+P+v
             const bool beyond_all = finite && first_line + P + (i == 0 ? 0 : 1) > p.limit_line;
             const bool beyond_some = finite && first_line + P + v > p.limit_line;
+            const bool direct = (info[k] & TI_DIRECT_BIT) != 0;      // counted nowhere yet: add only
             if (beyond_all) {
-                push(i, pred | FX_NEG, P);
+                if (!direct) push(i, pred | FX_NEG, P);
             } else if (beyond_some) {
-                push(i, pred | FX_NEG, P);
+                if (!direct) push(i, pred | FX_NEG, P);
                 push(i, truth | FX_LIMIT, P);
+            } else if (direct) {
+                push(i, truth, P);
             } else if (pred != truth) {
                 push(i, pred | FX_NEG, P);
                 push(i, truth, P);
             }
-            if ((info & TI_HI) && !beyond_all) push(i, truth | FX_HICHECK, P);
+            if ((info[k] & TI_HI) && !beyond_all) push(i, truth | FX_HICHECK, P);
         }
         __syncthreads();
         if (tid == 1023) carry = off + inc;

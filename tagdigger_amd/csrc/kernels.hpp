@@ -283,18 +283,18 @@ template <int W> struct Pending {
 };
 constexpr uint64_t R_PEND = 1ull << 61;   // (kind bits 0) match_prepare: finish with match_finish
 
+// Stage 1 of the matcher: the read as a stream of 16-base words aligned to its first base
+// (S[w] = bases 16w..16w+15, first base in the top bits; zero padded) and the number of leading
+// valid bases.  Returns R_DEFER (fast mode: raw bytes needed) or 0.
 template <int W, int MODE>
-__device__ __forceinline__ uint64_t match_prepare(const KParams &p, const TileCtx &cx, uint64_t gpos, uint32_t srel, bool slow,
-                                                  Pending<W> &pd) {
+__device__ __forceinline__ uint64_t fetch_stream(const KParams &p, const TileCtx &cx, uint64_t gpos, uint32_t srel, bool slow,
+                                                 uint32_t (&S)[2 * W + 4], uint32_t &nvalid) {
     if (MODE == ML_FAST) slow = false;
     if (MODE == ML_SLOW) slow = true;
     constexpr int NCHMAX = 2 * W + 3;
     constexpr int NS = 2 * W + 4;      // aligned 16-base words kept (zero padded)
     const uint2 *L_conv = cx.L_conv;
     const uint32_t win_ch = cx.win_ch;
-    const unsigned long long *L_bval = cx.L_bval;
-    const uint32_t *L_bmeta = cx.L_bmeta;
-    const uint16_t *L_bdir = cx.L_bdir;
     if (MODE != ML_SLOW && !slow) {
         const uint32_t c0f = srel >> 4;
         if (c0f + p.nch > win_ch) return R_DEFER;
@@ -325,7 +325,7 @@ __device__ __forceinline__ uint64_t match_prepare(const KParams &p, const TileCt
     if ((NCHMAX & 1)) inv[NCHMAX >> 1] |= 0xFFFF0000u;   // padding half-word is invalid
     // number of leading valid bases of the read
     inv[0] &= 0xFFFFFFFFu << a;
-    uint32_t nvalid = 0;
+    nvalid = 0;
     {
         bool found = false;
 #pragma unroll
@@ -338,7 +338,6 @@ __device__ __forceinline__ uint64_t match_prepare(const KParams &p, const TileCt
         nvalid -= a;
     }
     // stream aligned to the read start: S[w] holds bases 16w..16w+15
-    uint32_t S[NS];
 #pragma unroll
     for (int w = 0; w < NS; w++) {
         if (w < NCHMAX) {
@@ -347,6 +346,18 @@ __device__ __forceinline__ uint64_t match_prepare(const KParams &p, const TileCt
         } else S[w] = 0;
     }
         // (inside phase 2) fetch packed chunks + alignment
+    return 0;
+}
+
+// Stage 2: barcode+site lookup (reference :257), the read from the tag offset on (:260), tag hash,
+// first 16 bytes of the tag bucket put in flight.  Returns R_NONE / R_BAR, or R_PEND with `pd` filled.
+template <int W>
+__device__ __forceinline__ uint64_t match_stream(const KParams &p, const TileCtx &cx, uint32_t (&S)[2 * W + 4], uint32_t nvalid,
+                                                 Pending<W> &pd) {
+    constexpr int NS = 2 * W + 4;
+    const unsigned long long *L_bval = cx.L_bval;
+    const uint32_t *L_bmeta = cx.L_bmeta;
+    const uint16_t *L_bdir = cx.L_bdir;
     // ---- barcode + cut site (reference :257)
     const uint64_t K = ((uint64_t)S[0] << 32) | S[1];
     uint32_t ci = L_bdir[S[0] >> (32 - 2 * BDIR_BASES)];     // entries of a bucket are contiguous
@@ -395,6 +406,16 @@ __device__ __forceinline__ uint64_t match_prepare(const KParams &p, const TileCt
         return R_BAR;
     }
     return R_PEND;
+}
+
+template <int W, int MODE>
+__device__ __forceinline__ uint64_t match_prepare(const KParams &p, const TileCtx &cx, uint64_t gpos, uint32_t srel, bool slow,
+                                                  Pending<W> &pd) {
+    uint32_t S[2 * W + 4];
+    uint32_t nvalid;
+    const uint64_t r = fetch_stream<W, MODE>(p, cx, gpos, srel, slow, S, nvalid);
+    if (r) return r;
+    return match_stream<W>(p, cx, S, nvalid, pd);
 }
 
 template <int W>
