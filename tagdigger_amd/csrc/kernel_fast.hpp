@@ -96,8 +96,17 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         const uint64_t b = (uint64_t)tile * TILE;
         if (b + TILE + p.halo <= p.nbytes) {
             const uint4 *src = reinterpret_cast<const uint4 *>(p.buf + b);
+            if (p.nt_loads) {
 #pragma unroll
-            for (int j = 0; j < CPT; j++) v[j] = src[j * BLOCK + tid];
+                for (int j = 0; j < CPT; j++) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + j * BLOCK + tid));
+                    v[j] = make_uint4(q.x, q.y, q.z, q.w);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CPT; j++) v[j] = src[j * BLOCK + tid];
+            }
             if (has_halo) vh = src[TILE_CH + tid];
         } else {
 #pragma unroll
@@ -116,7 +125,6 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
     if (it < nwork) fetch_tile(t);
     __syncthreads();
 
-    uint32_t parity = 0;                             // which bank of vote counters this tile uses
     while (it < nwork) {
         const uint64_t tbase = (uint64_t)t * TILE;
         TD_STAMP(0);   // loop head
@@ -179,7 +187,6 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         if (nit < nwork) fetch_tile(tn);
         lds_barrier();
         TD_STAMP(2);   // barrier A
-        if (tid < 4) L_misc[16 + 4 * (parity ^ 1u) + tid] = 0;   // the previous tile's vote bank, for the tile after this
 
         // ---------------- B: terminators of this thread's CPT consecutive chunks, block scan
         const bool tile_has_hi = L_misc[1] != 0;
@@ -194,15 +201,15 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
 #pragma unroll
         for (int i = 0; i < CPT / 2; i++) cnt += __builtin_popcount(mm[i]);
         const uint32_t incl = wave_incl_scan(cnt, lane);
-        if (lane == 63) L_misc[4 + wave] = incl;
         const uint32_t span0 = tid * CPT * 16u;
 
         // ---------------- C: phase.  Each thread votes with the FIRST line that starts in its span
-        // (256 samples per tile are plenty): does it open with eight valid bases?  No loop: first set
-        // bit of the span's terminator mask, an 8-bit window of the invalid-byte bitmap.
+        // (256 samples per tile are plenty): does it open with eight valid bases?  The line follows the
+        // terminator with in-tile ordinal wave_base + (incl - cnt); the wave base is only known after
+        // the barrier, so each wave publishes its four counts by WAVE-LOCAL class next to its total and
+        // every thread rotates them afterwards: one barrier serves both the scan and the vote.
         uint32_t r0 = code & 3u;
         const bool predict = (code & FX_PREDICT) != 0 && t != 0;
-        bool vote_good = false;
         {
             uint32_t fpos = 0, lo = 0, hi = 0;
             bool found = false;
@@ -212,28 +219,36 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
             }
             // line start = fpos + 1 (<= 32 past the word's base): a 64-bit funnel
             const uint64_t win = (((uint64_t)hi << 32) | lo) >> ((fpos & 31u) + 1u);
-            vote_good = found && (win & 0xFFu) == 0 && tbase + span0 + fpos + 9u <= p.nbytes;
+            const bool vote_good = found && (win & 0xFFu) == 0 && tbase + span0 + fpos + 9u <= p.nbytes;
+            const uint32_t lclass = (incl - cnt) & 3u;
+            uint32_t packed = 0;                         // 4 x 8-bit counts (<= 64 each)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                packed |= (uint32_t)__builtin_popcountll(__ballot(vote_good && lclass == (uint32_t)c)) << (8 * c);
+            if (lane == 63) { L_misc[4 + wave] = incl; L_misc[8 + wave] = packed; }
         }
         lds_barrier();
         uint32_t wbase = 0, total = 0;
+        uint32_t v02 = 0, v13 = 0;                       // 16-bit fields: votes of in-tile classes 0,2 and 1,3
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) { uint32_t x = L_misc[4 + w]; if (w < wave) wbase += x; total += x; }
+        for (int w = 0; w < BLOCK / 64; w++) {
+            const uint32_t x = L_misc[4 + w], pk = L_misc[8 + w];
+            // wave w's local class c is in-tile class (c + total-so-far) & 3: rotate its four byte fields
+            const uint32_t rot = 8u * (total & 3u);
+            const uint32_t r = rot ? ((pk << rot) | (pk >> (32u - rot))) : pk;
+            v02 += r & 0x00FF00FFu;
+            v13 += (r >> 8) & 0x00FF00FFu;
+            if (w < wave) wbase += x;
+            total += x;
+        }
+        const uint32_t votes[4] = {v02 & 0xFFFFu, v13 & 0xFFFFu, v02 >> 16, v13 >> 16};
         const uint32_t excl = wbase + incl - cnt;
-        TD_STAMP(3);   // B: scan
+        TD_STAMP(3);   // B: scan + vote
         if (predict) {
-            uint32_t *bank = L_misc + 16 + 4 * parity;
-            // the first line of the span follows in-tile ordinal excl: its class is excl & 3
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const uint64_t bl = __ballot(vote_good && (excl & 3u) == (uint32_t)c);
-                if (lane == 0 && bl) atomicAdd(&bank[c], (uint32_t)__builtin_popcountll(bl));
-            }
-            lds_barrier();
-            const uint32_t a0 = bank[0], a1 = bank[1], a2 = bank[2], a3 = bank[3];
-            uint32_t best = a0; r0 = 0;
-            if (a1 > best) { best = a1; r0 = 1; }
-            if (a2 > best) { best = a2; r0 = 2; }
-            if (a3 > best) { best = a3; r0 = 3; }
+            uint32_t best = votes[0]; r0 = 0;
+            if (votes[1] > best) { best = votes[1]; r0 = 1; }
+            if (votes[2] > best) { best = votes[2]; r0 = 2; }
+            if (votes[3] > best) { best = votes[3]; r0 = 3; }
         } else if (code & FX_PREDICT) {
             r0 = (4u - (uint32_t)(first_line & 3)) & 3u;      // tile 0: P = 0, the phase is known
         }
@@ -355,7 +370,6 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         TD_STAMP(6);   // D: match + commit (thread 0's share)
         // ---------------- next work item
         if (tid == 0) L_misc[1] = 0;
-        parity ^= 1u;
         lds_barrier();                                    // LDS is reused by the next tile
         TD_STAMP(7);   // end barrier (other waves' matching)
         it = nit; t = tn; code = coden; Pg = Pgn;
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(1024) void k_resolve(const FParams fp) {
 #pragma unroll
         for (uint32_t k = 0; k < IPT; k++) {
             const uint32_t i = i0 + k;
-            if (i >= p.ntiles) break;
+            if (i >= p.ntiles) continue;
             const unsigned long long v = info[k] & TI_COUNT_MASK;
             const uint64_t P = run;                                        // terminators before tile i
             run += v;

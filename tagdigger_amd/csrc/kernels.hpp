@@ -89,6 +89,7 @@ struct KParams {
     // leave the running total for the next piece; both may be null
     const unsigned long long *cursor_in;
     unsigned long long *cursor_out;
+    uint32_t nt_loads;       // stream the FASTQ with non-temporal loads (keeps the tag table in L2)
     uint32_t stagger, stagger_div;   // start-up stagger of co-resident workgroups (units of 4096 cycles; 0 = off)
     uint32_t dbg;            // timing-only ablations (results wrong when nonzero); see DBG_*
 };

@@ -159,8 +159,9 @@ struct td_handle {
     DevBuf<unsigned long long> d_slow;        //             positions of lines that need raw bytes
     uint32_t max_need = 0;                    // bases from a read's start that the matcher may look at
     // options
-    int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1, split = 0, slabs = 2;
+    int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1, split = 0, slabs = 2, nt_loads = 1;
     uint32_t debug_ablate = 0;
+    double table_load = 0.5;
     int stagger = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -317,6 +318,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     p.cursor_in = cursor_in; p.cursor_out = cursor_out;
     p.dbg = h->debug_ablate;
     p.stagger = (uint32_t)h->stagger; p.stagger_div = (uint32_t)h->num_cu;
+    p.nt_loads = (uint32_t)h->nt_loads;
 
     // ---- fast path: free-running tiles with a predicted line phase, exact resolve, fix-up pass.
     // Chosen when the maxreads limit cannot bite early (it is still applied exactly, by fix-ups).
@@ -599,7 +601,9 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
     size_t nlong = 0;
     for (auto &t : rt.out) if (t.first.size() >= m) nlong++;
     size_t nbuckets = 16;
-    while (nbuckets * spb < 2 * nlong) nbuckets <<= 1;
+    // load: at most half of the slots (measured: a denser, smaller table loses more to second
+    // fetches on full buckets than it gains in L2 hits)
+    while ((double)nbuckets * spb * h->table_load < (double)nlong) nbuckets <<= 1;
     std::vector<uint32_t> slots(nbuckets * bucket_dw, 0);
     std::vector<uint32_t> shorts;
     std::vector<uint64_t> words(W);
@@ -913,6 +917,8 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     else if (n == "fastpath") h->fastpath = value ? 1 : 0;
     else if (n == "stagger") h->stagger = (int)value;
     else if (n == "split") h->split = value ? 1 : 0;
+    else if (n == "table_load_pct") h->table_load = std::max<int64_t>(10, std::min<int64_t>(value, 95)) / 100.0;
+    else if (n == "nt_loads") h->nt_loads = value ? 1 : 0;
     else if (n == "slabs") h->slabs = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
     else if (n == "debug_ablate") h->debug_ablate = (uint32_t)value;   // timing-only ablations, wrong results
     else return fail(TD_E_ARG, "unknown option " + n);
