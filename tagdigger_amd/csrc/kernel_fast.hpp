@@ -42,10 +42,11 @@ struct FParams {
     uint4 *fixlist;          // [fix_cap]
     uint32_t *nfix;
     uint32_t fix_cap;
-    uint32_t mode;           // 0 main pass over all tiles, 1 fix-up pass over the queue
 };
 
-template <int CPT, int W>
+// FIX = false: the main pass over all tiles (phase predicted, nothing to subtract, no limit);
+// FIX = true: the fix-up pass over the queue k_resolve left.
+template <int CPT, int W, bool FIX>
 __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams fp) {
     const KParams &p = fp.k;
     constexpr int TILE_CH = CPT * BLOCK;
@@ -66,7 +67,6 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (uint32_t i = tid; i < p.bblob_bytes / 4; i += BLOCK)
         reinterpret_cast<uint32_t *>(L_bidx)[i] = p.bblob[i];
-    if (tid < 8) L_misc[16 + tid] = 0;              // vote counters (two banks of four)
     if (tid == 0) L_misc[1] = 0;
 
     long long st_reads = 0, st_bar = 0, st_tag = 0;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
 #endif
     const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
     const uint64_t first_line = p.first_line + carried;
-    const uint32_t nwork = fp.mode ? min(*fp.nfix, fp.fix_cap) : p.ntiles;
+    const uint32_t nwork = FIX ? min(*fp.nfix, fp.fix_cap) : p.ntiles;
 
     // work item -> tile, code, P
     uint32_t it = blockIdx.x;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
     uint64_t Pg = 0;
     auto fetch_item = [&](uint32_t w, uint32_t &tt, uint32_t &cc, uint64_t &pp) {
         if (w >= nwork) return;
-        if (fp.mode) { const uint4 e = fp.fixlist[w]; tt = e.x; cc = e.y; pp = ((uint64_t)e.w << 32) | e.z; }
+        if (FIX) { const uint4 e = fp.fixlist[w]; tt = e.x; cc = e.y; pp = ((uint64_t)e.w << 32) | e.z; }
         else { tt = w; cc = FX_PREDICT; pp = 0; }
     };
     uint4 v[CPT];
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
 
     while (it < nwork) {
         const uint64_t tbase = (uint64_t)t * TILE;
+        const uint32_t codeq = FIX ? code : (uint32_t)FX_PREDICT;
         TD_STAMP(0);   // loop head
 
         // ---------------- A: terminator masks + packing of every chunk, from registers.  A wave whose
@@ -208,8 +209,8 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         // terminator with in-tile ordinal wave_base + (incl - cnt); the wave base is only known after
         // the barrier, so each wave publishes its four counts by WAVE-LOCAL class next to its total and
         // every thread rotates them afterwards: one barrier serves both the scan and the vote.
-        uint32_t r0 = code & 3u;
-        const bool predict = (code & FX_PREDICT) != 0 && t != 0;
+        uint32_t r0 = codeq & 3u;
+        const bool predict = (codeq & FX_PREDICT) != 0 && t != 0;
         {
             uint32_t fpos = 0, lo = 0, hi = 0;
             bool found = false;
@@ -249,18 +250,18 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
             if (votes[1] > best) { best = votes[1]; r0 = 1; }
             if (votes[2] > best) { best = votes[2]; r0 = 2; }
             if (votes[3] > best) { best = votes[3]; r0 = 3; }
-        } else if (code & FX_PREDICT) {
+        } else if (codeq & FX_PREDICT) {
             r0 = (4u - (uint32_t)(first_line & 3)) & 3u;      // tile 0: P = 0, the phase is known
         }
         TD_STAMP(4);   // C: vote
-        if (tid == 0 && !fp.mode)
+        if (tid == 0 && !FIX)
             fp.tile_info[t] = total | (r0 << TI_R0_SHIFT) | (tile_has_hi ? TI_HI : 0u);
 
-        const uint64_t P = Pg;                               // valid in fix-up mode only
-        const bool use_limit = (code & FX_LIMIT) != 0;
-        const long long sign = (code & FX_NEG) ? -1 : 1;
+        const uint64_t P = FIX ? Pg : 0;                            // valid in fix-up mode only
+        const bool use_limit = (codeq & FX_LIMIT) != 0;
+        const long long sign = (codeq & FX_NEG) ? -1 : 1;
 
-        if (code & FX_HICHECK) {
+        if (codeq & FX_HICHECK) {
             // ------------ bytes >= 0x80 inside a counted sequence line?  (fix-up mode, true phase)
             const uint64_t Lb = first_line + P + excl;
             uint32_t seen = 0;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         it = nit; t = tn; code = coden; Pg = Pgn;
     }
 #ifdef TD_PHASE_PROF
-    if (tid == 0 && !fp.mode)
+    if (tid == 0 && !FIX)
         for (int i = 0; i < PROF_PHASES; i++) atomicAdd(p.stats + 8 + i, prof_acc[i]);
 #endif
 
@@ -389,75 +390,83 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
     }
 }
 
-// Single workgroup: exclusive scan of the per-tile terminator counts gives every tile's true
-// line phase; tiles counted under another phase, tiles reaching past the maxreads limit and tiles
-// holding bytes >= 0x80 are queued for the fix-up pass.  Also leaves the running line total.
-__global__ __launch_bounds__(1024) void k_resolve(const FParams fp) {
+// An exclusive scan of the per-tile terminator counts gives every tile's true line phase; tiles
+// counted under another phase, tiles reaching past the maxreads limit and tiles holding bytes
+// >= 0x80 are queued for the fix-up pass.  Also leaves the running line total.
+// k_resolve runs as ceil(ntiles / 1024) blocks of 1024 threads, one tile per thread.  A block needs
+// the number of terminators before its first tile: k_resolve_sums reduces every block's 1024 tile
+// counts into super[block] first, and each k_resolve block adds up the super sums before its own.
+constexpr uint32_t RESOLVE_SPAN = 1024;
+
+__global__ __launch_bounds__(256) void k_resolve_sums(const FParams fp, unsigned long long *super) {
+    __shared__ unsigned long long wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t i0 = blockIdx.x * RESOLVE_SPAN + tid * 4;
+    unsigned long long local = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+        if (i0 + k < fp.k.ntiles) local += fp.tile_info[i0 + k] & TI_COUNT_MASK;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d, 64);
+    if (lane == 0) wsum[wave] = local;
+    __syncthreads();
+    if (tid == 0) super[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(1024) void k_resolve(const FParams fp, const unsigned long long *super) {
     const KParams &p = fp.k;
     __shared__ unsigned long long wsum[16];
-    __shared__ unsigned long long carry;
+    __shared__ unsigned long long wpre[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
     const uint64_t first_line = p.first_line + carried;
     const bool finite = p.limit_line < (~0ull - 16);
-    if (tid == 0) carry = 0;
-    __syncthreads();
     auto push = [&](uint32_t tile, uint32_t code, uint64_t P) {
         const uint32_t slot = atomicAdd(fp.nfix, 1u);
         if (slot < fp.fix_cap) fp.fixlist[slot] = make_uint4(tile, code, (uint32_t)P, (uint32_t)(P >> 32));
         else atomicOr(p.stats + ST_ERR, ERR_SPIN);   // cannot happen: the queue holds 3 entries per tile
     };
-    constexpr uint32_t IPT = 16;                          // tiles per thread per step
-    for (uint32_t base = 0; base < p.ntiles; base += 1024 * IPT) {
-        const uint32_t i0 = base + tid * IPT;
-        uint32_t info[IPT];
-        unsigned long long local = 0;
+    // terminators before this block's first tile
+    unsigned long long pre = 0;
+    for (uint32_t b = tid; b < blockIdx.x; b += 1024) pre += super[b];
 #pragma unroll
-        for (uint32_t k = 0; k < IPT; k++) {
-            info[k] = i0 + k < p.ntiles ? fp.tile_info[i0 + k] : 0u;
-            local += info[k] & TI_COUNT_MASK;
+    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
+    const uint32_t i = blockIdx.x * RESOLVE_SPAN + tid;
+    const uint32_t info = i < p.ntiles ? fp.tile_info[i] : 0u;
+    const unsigned long long v = info & TI_COUNT_MASK;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { unsigned long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) wsum[wave] = inc;
+    if (lane == 0) wpre[wave] = pre;
+    __syncthreads();
+    unsigned long long off = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { off += wpre[w]; if (w < wave) off += wsum[w]; }
+    const uint64_t P = off + inc - v;                                  // terminators before tile i
+    if (i < p.ntiles) {
+        const uint32_t truth = (4u - (uint32_t)((first_line + P) & 3)) & 3u;   // ordinals == truth (mod 4) precede sequence lines
+        const uint32_t pred = (info >> TI_R0_SHIFT) & 3u;
+        // lines of this tile: first_line+P (only tile 0's own first line) .. first_line+P+v
+        const bool beyond_all = finite && first_line + P + (i == 0 ? 0 : 1) > p.limit_line;
+        const bool beyond_some = finite && first_line + P + v > p.limit_line;
+        const bool direct = (info & TI_DIRECT_BIT) != 0;      // counted nowhere yet: add only
+        if (beyond_all) {
+            if (!direct) push(i, pred | FX_NEG, P);
+        } else if (beyond_some) {
+            if (!direct) push(i, pred | FX_NEG, P);
+            push(i, truth | FX_LIMIT, P);
+        } else if (direct) {
+            push(i, truth, P);
+        } else if (pred != truth) {
+            push(i, pred | FX_NEG, P);
+            push(i, truth, P);
         }
-        unsigned long long inc = local;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { unsigned long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        unsigned long long off = carry;
-        for (int w = 0; w < wave; w++) off += wsum[w];
-        unsigned long long run = off + inc - local;      // terminators before this thread's first tile
-#pragma unroll
-        for (uint32_t k = 0; k < IPT; k++) {
-            const uint32_t i = i0 + k;
-            if (i >= p.ntiles) continue;
-            const unsigned long long v = info[k] & TI_COUNT_MASK;
-            const uint64_t P = run;                                        // terminators before tile i
-            run += v;
-            const uint32_t truth = (4u - (uint32_t)((first_line + P) & 3)) & 3u;   // ordinals == truth (mod 4) precede sequence lines
-            const uint32_t pred = (info[k] >> TI_R0_SHIFT) & 3u;
-            // lines of this tile: first_line+P (only tile 0's own first line) .. first_line+P+v
-            const bool beyond_all = finite && first_line + P + (i == 0 ? 0 : 1) > p.limit_line;
-            const bool beyond_some = finite && first_line + P + v > p.limit_line;
-            const bool direct = (info[k] & TI_DIRECT_BIT) != 0;      // counted nowhere yet: add only
-            if (beyond_all) {
-                if (!direct) push(i, pred | FX_NEG, P);
-            } else if (beyond_some) {
-                if (!direct) push(i, pred | FX_NEG, P);
-                push(i, truth | FX_LIMIT, P);
-            } else if (direct) {
-                push(i, truth, P);
-            } else if (pred != truth) {
-                push(i, pred | FX_NEG, P);
-                push(i, truth, P);
-            }
-            if ((info[k] & TI_HI) && !beyond_all) push(i, truth | FX_HICHECK, P);
-        }
-        __syncthreads();
-        if (tid == 1023) carry = off + inc;
-        __syncthreads();
+        if ((info & TI_HI) && !beyond_all) push(i, truth | FX_HICHECK, P);
     }
-    if (tid == 0) {
-        atomicAdd(p.stats + ST_LINES, carry);
-        if (p.cursor_out) *p.cursor_out = carried + carry;
+    if (i == p.ntiles - 1) {
+        atomicAdd(p.stats + ST_LINES, P + v);
+        if (p.cursor_out) *p.cursor_out = carried + P + v;
     }
 }
 

@@ -189,17 +189,20 @@ KFn pick_kernel(int tile_kb, int W, bool tassel) {
 }
 
 using FFn = void (*)(const tdk::FParams);
-template <int CPT> FFn pick_fast_w(int W) {
+template <int CPT, bool FIX> FFn pick_fast_w(int W) {
     switch (W) {
-    case 1: return tdk::k_fast<CPT, 1>;
-    case 2: return tdk::k_fast<CPT, 2>;
-    case 3: return tdk::k_fast<CPT, 3>;
-    case 4: return tdk::k_fast<CPT, 4>;
-    case 6: return tdk::k_fast<CPT, 6>;
-    default: return tdk::k_fast<CPT, 10>;
+    case 1: return tdk::k_fast<CPT, 1, FIX>;
+    case 2: return tdk::k_fast<CPT, 2, FIX>;
+    case 3: return tdk::k_fast<CPT, 3, FIX>;
+    case 4: return tdk::k_fast<CPT, 4, FIX>;
+    case 6: return tdk::k_fast<CPT, 6, FIX>;
+    default: return tdk::k_fast<CPT, 10, FIX>;
     }
 }
-FFn pick_fast(int tile_kb, int W) { return tile_kb == 32 ? pick_fast_w<8>(W) : pick_fast_w<4>(W); }
+FFn pick_fast(int tile_kb, int W, bool fix) {
+    if (fix) return tile_kb == 32 ? pick_fast_w<8, true>(W) : pick_fast_w<4, true>(W);
+    return tile_kb == 32 ? pick_fast_w<8, false>(W) : pick_fast_w<4, false>(W);
+}
 
 using SFn = void (*)(const tdk::SParams);
 template <int CPT> SFn pick_emit_w(int W) {
@@ -333,10 +336,12 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
         tdk::FParams fp{};
         fp.k = p; fp.tile_info = h->d_tileinfo.p; fp.fixlist = h->d_fixlist.p; fp.nfix = h->d_nfix.p; fp.fix_cap = fix_cap;
         HIPCHK(hipMemsetAsync(h->d_nfix.p, 0, 4, stream));
-        FFn ffn = pick_fast(tile_kb, h->W);
+        FFn ffn = pick_fast(tile_kb, h->W, false), fixfn = pick_fast(tile_kb, h->W, true);
         const size_t flds = lds_bytes_fast(h, tile_kb);
-        if (flds > 48 * 1024)
+        if (flds > 48 * 1024) {
             HIPCHK(hipFuncSetAttribute((const void *)ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+            HIPCHK(hipFuncSetAttribute((const void *)fixfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+        }
         int bpc = h->blocks_per_cu;
         if (bpc <= 0) {
             if (h->occ_fn != (const void *)ffn || h->occ_lds != flds) {
@@ -357,7 +362,6 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
             e0 = h->ev_pool[h->ev_used].first; e1 = h->ev_pool[h->ev_used].second; h->ev_used++;
             HIPCHK(hipEventRecord(e0, stream));
         }
-        fp.mode = 0;
         if (h->split) {
             // main pass cut in two: k_emit (stream, pack, vote, one record per wanted line) + k_match
             // (one lane per record) + k_slow (lines that need raw bytes)
@@ -417,9 +421,13 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
         } else {
             hipLaunchKernelGGL(ffn, dim3(grid), dim3(tdk::BLOCK), flds, stream, fp);
         }
-        hipLaunchKernelGGL(tdk::k_resolve, dim3(1), dim3(1024), 0, stream, fp);
-        fp.mode = 1;
-        hipLaunchKernelGGL(ffn, dim3(std::min<uint32_t>(grid, (uint32_t)h->num_cu * 2)), dim3(tdk::BLOCK), flds, stream, fp);
+        {   // exact line phase of every tile (d_state is free on this path: it holds the block sums)
+            const uint32_t rblocks = (ntiles + tdk::RESOLVE_SPAN - 1) / tdk::RESOLVE_SPAN;
+            unsigned long long *super = reinterpret_cast<unsigned long long *>(h->d_state.p);
+            hipLaunchKernelGGL(tdk::k_resolve_sums, dim3(rblocks), dim3(256), 0, stream, fp, super);
+            hipLaunchKernelGGL(tdk::k_resolve, dim3(rblocks), dim3(1024), 0, stream, fp, super);
+        }
+        hipLaunchKernelGGL(fixfn, dim3(std::min<uint32_t>(grid, (uint32_t)h->num_cu * 2)), dim3(tdk::BLOCK), flds, stream, fp);
         HIPCHK(hipGetLastError());
         if (h->timing) HIPCHK(hipEventRecord(e1, stream));
         return TD_OK;
