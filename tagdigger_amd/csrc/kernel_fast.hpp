@@ -60,19 +60,38 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
     uint16_t *L_inv = L_mask + TILE_CH;                  // per chunk: which bytes are not bases (for the phase vote)
     uint32_t *L_misc = reinterpret_cast<uint32_t *>(lds + (size_t)win_ch * 8u + TILE_CH * 4u);   // 64 dwords
     uint8_t *L_bidx = reinterpret_cast<uint8_t *>(L_misc + 64);
-    const TileCtx cx{L_conv, win_ch, reinterpret_cast<const unsigned long long *>(L_bidx),
-                     reinterpret_cast<const uint32_t *>(L_bidx + p.off_bmeta),
-                     reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir)};
+    TileCtx cx{L_conv, win_ch, reinterpret_cast<const unsigned long long *>(L_bidx),
+               reinterpret_cast<const uint32_t *>(L_bidx + p.off_bmeta),
+               reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir)};
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (uint32_t i = tid; i < p.bblob_bytes / 4; i += BLOCK)
         reinterpret_cast<uint32_t *>(L_bidx)[i] = p.bblob[i];
     if (tid == 0) L_misc[1] = 0;
 
-    long long st_reads = 0, st_bar = 0, st_tag = 0;
+    int st_reads = 0, st_bar = 0, st_tag = 0;       // per thread and launch: far below 2^31 (signed: the fix-up pass subtracts)
+    // Main pass, 64-byte buckets: a thread's (single) wanted line is matched up to the tag-bucket loads
+    // in its own tile and finished -- compares, count -- in the NEXT tile's phase D, so the probe's
+    // latency runs under that tile's phases A-C instead of stalling the wave.
+    constexpr bool PIPE = !FIX && W <= 3;
+    Pending<W> pd;
+    bool pd_valid = false;
+    auto finish_pending = [&]() {
+        vm_settled();           // (the bucket has had a whole phase A to arrive; nothing younger is in flight)
+        const uint64_t res = match_finish<W>(p, pd);
+        const uint32_t kind = (uint32_t)(res >> 62);
+        st_reads += 1;
+        if (kind >= 1) st_bar += 1;
+        if (kind == 2) {
+            st_tag += 1;
+            if (!(p.dbg & DBG_NO_ATOMIC))
+                __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
 #ifdef TD_PHASE_PROF
-    unsigned long long prof_acc[PROF_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_acc[PROF_PHASES] = {};
     unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+    cx.pacc = prof_acc; cx.plast = &prof_last;
 #endif
     const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
     const uint64_t first_line = p.first_line + carried;
@@ -88,30 +107,26 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         else { tt = w; cc = FX_PREDICT; pp = 0; }
     };
     uint4 v[CPT];
-    uint4 vh = make_uint4(0u, 0u, 0u, 0u);
     const bool has_halo = (uint32_t)tid < halo_ch;
-    // One uniform bounds test per tile: every tile but the buffer's last is loaded with plain,
-    // independent 16-byte loads (a per-chunk test makes the compiler serialise them).
+    auto tile_src = [&](uint32_t tile) -> const uint4 * {
+        const uint8_t *base = tile >= p.tail_tile ? p.tail_buf + (uint64_t)(tile - p.tail_tile) * TILE
+                                                  : p.buf + (uint64_t)tile * TILE;
+        return reinterpret_cast<const uint4 *>(base);
+    };
+    // Every tile is loaded with plain, independent 16-byte loads: the tiles whose window crosses the
+    // buffer's end come from the zero-padded copy the host made of the buffer's tail.
     auto fetch_tile = [&](uint32_t tile) {
-        const uint64_t b = (uint64_t)tile * TILE;
-        if (b + TILE + p.halo <= p.nbytes) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(p.buf + b);
-            if (p.nt_loads) {
+        const uint4 *src = tile_src(tile);
+        if (p.nt_loads) {
 #pragma unroll
-                for (int j = 0; j < CPT; j++) {
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + j * BLOCK + tid));
-                    v[j] = make_uint4(q.x, q.y, q.z, q.w);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < CPT; j++) v[j] = src[j * BLOCK + tid];
+            for (int j = 0; j < CPT; j++) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + j * BLOCK + tid));
+                v[j] = make_uint4(q.x, q.y, q.z, q.w);
             }
-            if (has_halo) vh = src[TILE_CH + tid];
         } else {
 #pragma unroll
-            for (int j = 0; j < CPT; j++) v[j] = load_chunk(p, b + (uint64_t)(j * BLOCK + tid) * 16u);
-            if (has_halo) vh = load_chunk(p, b + (uint64_t)(TILE_CH + tid) * 16u);
+            for (int j = 0; j < CPT; j++) v[j] = src[j * BLOCK + tid];
         }
     };
     fetch_item(it, t, code, Pg);
@@ -128,12 +143,20 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
     while (it < nwork) {
         const uint64_t tbase = (uint64_t)t * TILE;
         const uint32_t codeq = FIX ? code : (uint32_t)FX_PREDICT;
+        const uint32_t tile_rem = (uint32_t)min(p.nbytes - tbase, (uint64_t)(TILE + 4096u));   // bytes from the tile's base to the buffer's end (capped)
         TD_STAMP(0);   // loop head
 
         // ---------------- A: terminator masks + packing of every chunk, from registers.  A wave whose
         // chunks are all inside the buffer, all ASCII and free of '\r' (the normal case) takes the
         // short forms; any other wave redoes its chunks with the exact general forms.
         {
+            // the halo (the first chunks of the next tile) is fetched now and packed at the end of A:
+            // it is not carried across the rest of the loop like the tile's own prefetched bytes
+            uint4 vh = make_uint4(0u, 0u, 0u, 0u);
+            if (has_halo) vh = tile_src(t)[TILE_CH + tid];
+            // (phase A ends by consuming vh unconditionally -- halo_seen -- so that the compiler knows
+            // the load has landed and does not guard later writes of these registers with waits)
+            auto halo_seen = [&]() { asm volatile("" ::"v"(vh.x), "v"(vh.y), "v"(vh.z), "v"(vh.w)); };
             uint32_t hiacc = 0;
 #pragma unroll
             for (int j = 0; j < CPT; j++) hiacc |= v[j].x | v[j].y | v[j].z | v[j].w;
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                     if (has_halo) L_conv[TILE_CH + tid] = convert_chunk(vh);
                 }
             }
-            if (general) {
+            if (__builtin_expect(general, 0)) {
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
                     const uint32_t c = j * BLOCK + tid;
@@ -178,12 +201,17 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                 if (has_halo) L_conv[TILE_CH + tid] = convert_chunk(vh);
                 if (hiacc & 0x80808080u) L_misc[1] = 1;
             }
+            halo_seen();
         }
         // the next work item's bytes: in flight while this tile is finished
         const uint32_t nit = it + gridDim.x;
         uint32_t tn = 0, coden = FX_PREDICT;
         uint64_t Pgn = 0;
         TD_STAMP(1);   // A: wait for this tile's bytes, masks + packing
+        // the line this thread left pending in the previous tile: its bucket has had phase A to arrive,
+        // and nothing younger is in flight yet
+        if (PIPE && pd_valid) { finish_pending(); pd_valid = false; }
+        TD_STAMP(5);   // pending line finished
         fetch_item(nit, tn, coden, Pgn);
         if (nit < nwork) fetch_tile(tn);
         lds_barrier();
@@ -220,7 +248,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
             }
             // line start = fpos + 1 (<= 32 past the word's base): a 64-bit funnel
             const uint64_t win = (((uint64_t)hi << 32) | lo) >> ((fpos & 31u) + 1u);
-            const bool vote_good = found && (win & 0xFFu) == 0 && tbase + span0 + fpos + 9u <= p.nbytes;
+            const bool vote_good = found && (win & 0xFFu) == 0 && span0 + fpos + 9u <= tile_rem;
             const uint32_t lclass = (incl - cnt) & 3u;
             uint32_t packed = 0;                         // 4 x 8-bit counts (<= 64 each)
 #pragma unroll
@@ -259,9 +287,9 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
 
         const uint64_t P = FIX ? Pg : 0;                            // valid in fix-up mode only
         const bool use_limit = (codeq & FX_LIMIT) != 0;
-        const long long sign = (codeq & FX_NEG) ? -1 : 1;
+        const int sign = (codeq & FX_NEG) ? -1 : 1;
 
-        if (codeq & FX_HICHECK) {
+        if (__builtin_expect((codeq & FX_HICHECK) != 0, 0)) {
             // ------------ bytes >= 0x80 inside a counted sequence line?  (fix-up mode, true phase)
             const uint64_t Lb = first_line + P + excl;
             uint32_t seen = 0;
@@ -326,14 +354,8 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
             // (closed forms assume every terminator's successor lies inside the buffer: not in its last tile)
             const bool simple = !use_limit && !own_first && nw <= 1 && tbase + TILE + p.halo <= p.nbytes;
             if (p.dbg & DBG_NO_PHASE2) nw = 0;
-            uint32_t ndefer = 0;
-#pragma nounroll
-            for (uint32_t q = 0; simple ? q < nw : true; q++) {
-                uint32_t srel = w0;
-                if (!simple && ((p.dbg & DBG_NO_PHASE2) || !nth_wanted(q, srel))) break;
-                const uint64_t res = match_line<W, ML_FAST>(p, cx, tbase + srel, srel, false);
+            auto commit = [&](uint64_t res) {
                 const uint32_t kind = (uint32_t)(res >> 62);
-                if (kind == 3) { ndefer++; continue; }
                 st_reads += sign;
                 if (kind >= 1) st_bar += sign;
                 if (kind == 2) {
@@ -342,29 +364,40 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                         __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), (uint32_t)sign, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
                 }
+            };
+            TD_MSTAMP(cx, 12, 0);   // wanted-line selection
+            // hot: the thread's single wanted line, matched from the packed chunks.  No loop and no
+            // other memory access here: in the pipelined form the bucket loads stay in flight.
+            bool general = !simple && !(p.dbg & DBG_NO_PHASE2);
+            if (simple && nw) {
+                // (a 32-bit status: 1 pending, 0 no barcode, 2 barcode only, 6 raw bytes needed)
+                const uint32_t k = (uint32_t)(match_prepare<W, ML_FAST>(p, cx, tbase + w0, w0, false, pd) >> 61);
+                if (k == 1u) {
+                    if (PIPE) pd_valid = true;
+                    else commit(match_finish<W>(p, pd));
+                } else if (k == 6u) {
+                    general = true;             // needs its raw bytes
+                } else {
+                    st_reads += sign;
+                    if (k == 2u) st_bar += sign;
+                }
             }
-            // cold: lines that need their raw bytes (leading blanks to strip, a first byte that is
-            // not a base, a window beyond the staged chunks)
-            if (ndefer) {
+            TD_STAMP(15);           // hot part done
+            // cold: threads with several wanted lines, the buffer's ends, the maxreads limit (fix-up
+            // pass), and lines that need their raw bytes (leading blanks to strip, a first byte that
+            // is not a base, a window beyond the staged chunks)
+            if (__builtin_expect(general, 0)) {
 #pragma nounroll
                 for (uint32_t q = 0;; q++) {
                     uint32_t srel = 0;
                     if (!nth_wanted(q, srel)) break;
                     const uint32_t c0f = srel >> 4;
                     const bool deferred = c0f + p.nch > win_ch || ((L_conv[c0f].y >> (srel & 15u)) & 1u);
-                    if (!deferred) continue;
+                    if (simple && !deferred) continue;
                     // (a non-blank non-base first byte simply comes back as "no barcode")
-                    const uint64_t res = match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true);
-                    const uint32_t kind = (uint32_t)(res >> 62);
-                    st_reads += sign;
-                    if (kind >= 1) st_bar += sign;
-                    if (kind == 2) {
-                        st_tag += sign;
-                        if (!(p.dbg & DBG_NO_ATOMIC))
-                            __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), (uint32_t)sign, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    commit(match_line<W, ML_BOTH>(p, cx, tbase + srel, srel, deferred));
                 }
+                vm_settled();
             }
         }
 
@@ -375,14 +408,15 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         TD_STAMP(7);   // end barrier (other waves' matching)
         it = nit; t = tn; code = coden; Pg = Pgn;
     }
+    if (PIPE && pd_valid) finish_pending();         // lines left pending by the last tile
 #ifdef TD_PHASE_PROF
     if (tid == 0 && !FIX)
         for (int i = 0; i < PROF_PHASES; i++) atomicAdd(p.stats + 8 + i, prof_acc[i]);
 #endif
 
     // ---------------- statistics: one atomic per wave (two's complement carries the fix-up signs)
-    unsigned long long r = wave_sum64((unsigned long long)st_reads), b = wave_sum64((unsigned long long)st_bar),
-                       g = wave_sum64((unsigned long long)st_tag);
+    unsigned long long r = wave_sum64((unsigned long long)(long long)st_reads), b = wave_sum64((unsigned long long)(long long)st_bar),
+                       g = wave_sum64((unsigned long long)(long long)st_tag);
     if (lane == 0) {
         if (r) atomicAdd(p.stats + ST_READS, r);
         if (b) atomicAdd(p.stats + ST_BARCUT, b);

@@ -90,6 +90,10 @@ struct KParams {
     const unsigned long long *cursor_in;
     unsigned long long *cursor_out;
     uint32_t nt_loads;       // stream the FASTQ with non-temporal loads (keeps the tag table in L2)
+    // fast path: tiles >= tail_tile (the last one or two, whose window would cross the buffer's end)
+    // are loaded from a zero-padded copy, so that every tile is fetched with plain unconditional loads
+    const uint8_t *tail_buf;
+    uint32_t tail_tile;
     uint32_t stagger, stagger_div;   // start-up stagger of co-resident workgroups (units of 4096 cycles; 0 = off)
     uint32_t dbg;            // timing-only ablations (results wrong when nonzero); see DBG_*
 };
@@ -190,10 +194,22 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
             prof_last = now_;                                               \
         }                                                                   \
     } while (0)
+// inside the matcher (wave 0, whatever lanes are active): drains LDS / memory first so that the
+// latency lands in the phase that waits for it
+#define TD_MSTAMP(cx, i, drain)                                              \
+    do {                                                                    \
+        if ((cx).pacc && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) { \
+            if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+            unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+            (cx).pacc[i] += now_ - *(cx).plast;                             \
+            *(cx).plast = now_;                                             \
+        }                                                                   \
+    } while (0)
 #else
 #define TD_STAMP(i) do {} while (0)
+#define TD_MSTAMP(cx, i, drain) do {} while (0)
 #endif
-constexpr int PROF_PHASES = 12;
+constexpr int PROF_PHASES = 16;
 
 // ---------------------------------------------------------------- the kernel
 // 2-bit codes (first base in the top bits) and per-base invalid flags (bit k = byte k of the chunk)
@@ -252,6 +268,12 @@ __device__ __forceinline__ uint32_t nl_mask16_ascii(const uint4 &v, uint32_t &cr
 }
 
 // CPT: 16-byte chunks per thread per tile (tile = CPT*4 KiB); W: 64-bit words per packed tag
+// s_waitcnt vmcnt(0) the compiler's own wait-count bookkeeping can see.  Placed at the end of rare
+// blocks that load from memory (overflow buckets, the short-tag list, the cold matcher): without
+// it the compiler assumes those loads may still be pending where the rare block rejoins the hot
+// path, and guards later register writes there with waits that would stall on the prefetch.
+__device__ __forceinline__ void vm_settled() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // ---------------------------------------------------------------- per-line matcher (shared by both kernels)
 // What a workgroup has staged in LDS for its current tile, plus the index.
 struct TileCtx {
@@ -260,6 +282,9 @@ struct TileCtx {
     const unsigned long long *L_bval;    // barcode index (LDS copy)
     const uint32_t *L_bmeta;
     const uint16_t *L_bdir;
+#ifdef TD_PHASE_PROF
+    unsigned long long *pacc = nullptr, *plast = nullptr;
+#endif
 };
 
 // gpos: absolute position of the line's first byte; srel: the same relative to the tile (fast mode).
@@ -272,16 +297,15 @@ struct TileCtx {
 //       ML_SLOW  raw bytes only;   ML_BOTH  chosen by `slow`, R_DEFER from the fast branch (exact kernel).
 enum { ML_FAST = 0, ML_SLOW = 1, ML_BOTH = 2 };
 // The matcher comes in two halves so that a caller can put other work between them:
-//   match_prepare  everything up to the tag hash and the load of the first 16 bytes of the tag
-//                  bucket (left in flight); returns R_NONE / R_BAR / R_DEFER, or R_PEND with `pd` filled
-//   match_finish   the rest of the bucket, the masked compares, the short list -> R_BAR or R_TAG | cell
+//   match_prepare  everything up to the tag hash and the loads of the tag bucket (left in flight);
+//                  returns R_NONE / R_BAR / R_DEFER, or R_PEND with `pd` filled
+//   match_finish   the masked compares, overflow buckets, the short list -> R_BAR or R_TAG | cell
 template <int W> struct Pending {
     uint64_t R[W];          // the read from the tag offset on, packed
-    uint32_t nrem;          // valid bases there
-    uint32_t row;           // count-matrix row (barcode)
-    uint32_t bk;            // tag bucket to probe, or ~0u: short list only
-    uint4 b0;               // first 16 bytes of that bucket
+    uint32_t nr;            // valid bases there (bits 0..14), PD_PROBE: a bucket was fetched, row << 16 (count-matrix row)
+    uint4 b[W <= 3 ? 4 : 8];   // that bucket (loads left in flight by match_prepare)
 };
+constexpr uint32_t PD_PROBE = 1u << 15;
 constexpr uint64_t R_PEND = 1ull << 61;   // (kind bits 0) match_prepare: finish with match_finish
 
 // Stage 1 of the matcher: the read as a stream of 16-base words aligned to its first base
@@ -346,7 +370,6 @@ __device__ __forceinline__ uint64_t fetch_stream(const KParams &p, const TileCtx
             S[w] = (uint32_t)(pr >> (32u - 2u * a));
         } else S[w] = 0;
     }
-        // (inside phase 2) fetch packed chunks + alignment
     return 0;
 }
 
@@ -373,6 +396,7 @@ __device__ __forceinline__ uint64_t match_stream(const KParams &p, const TileCtx
             ci++;
         }
     }
+    TD_MSTAMP(cx, 9, 1);    // barcode directory walk
     if (!bhit) return R_NONE;
     const uint32_t off = (meta >> 6) & 63u, row = meta >> 16;
     if (nvalid <= off) return R_BAR;
@@ -396,16 +420,20 @@ __device__ __forceinline__ uint64_t match_stream(const KParams &p, const TileCtx
         R[w] = ((uint64_t)top << 32) | bot;
     }
     constexpr int BUCKET_U4_ = W <= 3 ? 4 : 8;
+    TD_MSTAMP(cx, 10, 0);   // tag words
 #pragma unroll
     for (int w = 0; w < W; w++) pd.R[w] = R[w];
-    pd.nrem = nrem; pd.row = row; pd.bk = ~0u;
-    pd.b0 = make_uint4(0u, 0u, 0u, 0u);
+    pd.nr = min(nrem, 0x7FFFu) | (row << 16);      // (tags are at most 32 W <= 320 bases: the cap loses nothing)
     if (nrem >= p.m_bases && !(p.dbg & DBG_NO_PROBE)) {
-        pd.bk = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
-        pd.b0 = p.buckets[(size_t)pd.bk * BUCKET_U4_];       // in flight: first used by match_finish
+        pd.nr |= PD_PROBE;
+        const uint32_t bk = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
+        const uint4 *bp = p.buckets + (size_t)bk * BUCKET_U4_;
+#pragma unroll
+        for (int q = 0; q < BUCKET_U4_; q++) pd.b[q] = bp[q];   // in flight: first used by match_finish
     } else if (p.nshort == 0) {
         return R_BAR;
     }
+    TD_MSTAMP(cx, 14, 0);   // hash + bucket loads issued
     return R_PEND;
 }
 
@@ -416,6 +444,7 @@ __device__ __forceinline__ uint64_t match_prepare(const KParams &p, const TileCt
     uint32_t nvalid;
     const uint64_t r = fetch_stream<W, MODE>(p, cx, gpos, srel, slow, S, nvalid);
     if (r) return r;
+    TD_MSTAMP(cx, 8, 1);    // packed chunks from LDS + alignment
     return match_stream<W>(p, cx, S, nvalid, pd);
 }
 
@@ -425,7 +454,7 @@ __device__ __forceinline__ uint64_t match_finish(const KParams &p, const Pending
     constexpr int SLOT_DW = 2 * W + 1;
     constexpr int SPB = (BUCKET_U4 * 4 - 1) / SLOT_DW;  // slots per bucket
     const uint64_t *R = pd.R;
-    const uint32_t nrem = pd.nrem;
+    const uint32_t nrem = pd.nr & 0x7FFFu;
     auto prefix_eq = [&](const uint64_t *T, uint32_t len) -> bool {
         bool ok = true;
 #pragma unroll
@@ -438,16 +467,14 @@ __device__ __forceinline__ uint64_t match_finish(const KParams &p, const Pending
     };
     bool thit = false;
     uint32_t col = 0;
-    if (pd.bk != ~0u) {
-        uint32_t bk = pd.bk;
-        for (uint32_t probes = 0; probes <= p.bucket_mask; probes++) {
-            const uint4 *bp = p.buckets + (size_t)bk * BUCKET_U4;
-            uint32_t raw[BUCKET_U4 * 4];
+    if (pd.nr & PD_PROBE) {
+        uint32_t bk = 0;        // (recomputed from the read only if the bucket overflowed)
+        uint32_t raw[BUCKET_U4 * 4];
 #pragma unroll
-            for (int q = 0; q < BUCKET_U4; q++) {
-                uint4 v = (q == 0 && probes == 0) ? pd.b0 : bp[q];
-                raw[4 * q] = v.x; raw[4 * q + 1] = v.y; raw[4 * q + 2] = v.z; raw[4 * q + 3] = v.w;
-            }
+        for (int q = 0; q < BUCKET_U4; q++) {
+            raw[4 * q] = pd.b[q].x; raw[4 * q + 1] = pd.b[q].y; raw[4 * q + 2] = pd.b[q].z; raw[4 * q + 3] = pd.b[q].w;
+        }
+        for (uint32_t probes = 0;;) {
 #pragma unroll
             for (int sl = 0; sl < SPB; sl++) {
                 const uint32_t meta2 = raw[1 + sl * SLOT_DW + 2 * W];
@@ -458,20 +485,29 @@ __device__ __forceinline__ uint64_t match_finish(const KParams &p, const Pending
                     T[w] = ((uint64_t)raw[1 + sl * SLOT_DW + 2 * w + 1] << 32) | raw[1 + sl * SLOT_DW + 2 * w];
                 if (len != 0 && len <= nrem && prefix_eq(T, len)) { thit = true; col = meta2 >> 10; }
             }
-            if (thit || !(raw[0] & 1u)) break;      // found, or the bucket never overflowed
+            if (__builtin_expect(thit || !(raw[0] & 1u) || ++probes > p.bucket_mask, 1)) break;   // found, or the bucket never overflowed
+            if (probes == 1) bk = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
             bk = (bk + 1) & p.bucket_mask;
+            const uint4 *bp = p.buckets + (size_t)bk * BUCKET_U4;
+#pragma unroll
+            for (int q = 0; q < BUCKET_U4; q++) {
+                const uint4 v = bp[q];
+                raw[4 * q] = v.x; raw[4 * q + 1] = v.y; raw[4 * q + 2] = v.z; raw[4 * q + 3] = v.w;
+            }
+            vm_settled();
         }
     }
     if (!thit) {
         for (uint32_t e = 0; e < p.nshort; e++) {
             uint4 v = p.shorts[e];
+            vm_settled();
             uint64_t tv = ((uint64_t)v.y << 32) | v.x;
             uint32_t len = v.z;
             if (len <= nrem && ((R[0] ^ tv) >> (64u - 2u * len)) == 0) { thit = true; col = v.w; break; }
         }
     }
     if (!thit) return R_BAR;
-    return R_TAG | ((uint64_t)pd.row * p.ncols + col);
+    return R_TAG | ((uint64_t)(pd.nr >> 16) * p.ncols + col);
 }
 
 // both halves back to back
@@ -479,7 +515,10 @@ template <int W, int MODE>
 __device__ __forceinline__ uint64_t match_line(const KParams &p, const TileCtx &cx, uint64_t gpos, uint32_t srel, bool slow) {
     Pending<W> pd;
     const uint64_t r = match_prepare<W, MODE>(p, cx, gpos, srel, slow, pd);
-    return r == R_PEND ? match_finish<W>(p, pd) : r;
+    if (r != R_PEND) return r;
+    const uint64_t r2 = match_finish<W>(p, pd);
+    TD_MSTAMP(cx, 5, 1);    // rest of the bucket + compares
+    return r2;
 }
 
 #ifndef TD_WAVES_PER_SIMD
@@ -512,7 +551,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_count(const KParam
     uint32_t st_reads = 0, st_bar = 0, st_tag = 0;
     unsigned long long st_lines = 0;
 #ifdef TD_PHASE_PROF
-    unsigned long long prof_acc[PROF_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_acc[PROF_PHASES] = {};
     unsigned long long prof_last = __builtin_amdgcn_s_memtime();
 #endif
     const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;

@@ -152,6 +152,7 @@ struct td_handle {
     DevBuf<uint32_t> d_ticket;
     DevBuf<unsigned long long> d_cursor;      // [2] line cursor for streamed pieces
     DevBuf<uint32_t> d_tileinfo, d_nfix;      // fast path: per-tile count+phase, fix-up queue length
+    DevBuf<uint8_t> d_tail;                   // fast path: zero-padded copy of the buffer's last tiles
     DevBuf<uint4> d_fixlist;
     DevBuf<uint32_t> d_rec, d_region_count;   // split path: packed read records per wave region (two slab buffers)
     hipStream_t side_stream = nullptr;        //             k_match runs here, beside the next slab's k_emit
@@ -333,6 +334,18 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
         const uint32_t fix_cap = 3u * ntiles + 8u;
         rc = h->d_fixlist.ensure(fix_cap); if (rc) return rc;
         rc = h->d_nfix.ensure(4); if (rc) return rc;
+        {   // the tiles whose window (tile + halo) crosses the end of the buffer: a zero-padded copy
+            const uint64_t TILE = (uint64_t)tile_kb * 1024;
+            const uint64_t inside = nbytes >= TILE + h->halo ? (nbytes - h->halo) / TILE : 0;
+            const size_t tail_cap = 2 * (size_t)TILE + 2 * (size_t)h->halo + 256;
+            rc = h->d_tail.ensure(tail_cap); if (rc) return rc;
+            const uint64_t start = inside * TILE;
+            if (nbytes - start > tail_cap) return fail(TD_E_INTERNAL, "tail copy larger than its buffer");
+            HIPCHK(hipMemsetAsync(h->d_tail.p, 0, tail_cap, stream));
+            if (nbytes > start)
+                HIPCHK(hipMemcpyAsync(h->d_tail.p, (const uint8_t *)d_fastq + start, nbytes - start, hipMemcpyDeviceToDevice, stream));
+            p.tail_buf = h->d_tail.p; p.tail_tile = (uint32_t)inside;
+        }
         tdk::FParams fp{};
         fp.k = p; fp.tile_info = h->d_tileinfo.p; fp.fixlist = h->d_fixlist.p; fp.nfix = h->d_nfix.p; fp.fix_cap = fix_cap;
         HIPCHK(hipMemsetAsync(h->d_nfix.p, 0, 4, stream));
@@ -522,7 +535,7 @@ void td_destroy(td_handle *h) {
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
-    h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_fixlist.release(); h->d_rec.release(); h->d_region_count.release(); h->d_slow.release();
+    h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release(); h->d_rec.release(); h->d_region_count.release(); h->d_slow.release();
     for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->work_stream) (void)hipStreamDestroy(h->work_stream);

@@ -16,8 +16,10 @@ NAMES_EXACT = ["ticket", "load+masks+LDS store", "barrier after load", "block sc
          "  p2: fetch+convert", "  p2: barcode", "  p2: tag probes", "-"]
 
 
-NAMES = ["loop head", "A: wait bytes + masks + pack", "-", "B: scan + local votes", "C: vote",
-         "-", "D: match + commit", "-", "-", "-", "-", "-"]
+NAMES = ["loop head", "A: wait bytes + masks + pack", "barrier A", "B: scan + local votes", "C: vote",
+         "finish pending line (end of A)", "D: commit + loop (rest)", "end barrier",
+         "  D: packed chunks + align", "  D: barcode walk", "  D: tag words", "(fix-up queue length)",
+         "  D: wanted-line selection", "  D: commit issued", "  D: hash + bucket loads issued", "  D: q-loop exit"]
 
 
 def main():
@@ -45,8 +47,8 @@ def main():
     eng.set_option("timing", 1)
     eng.count_device(d, cfg.nbytes())
     ms, _ = eng.kernel_time_ms()
-    c = eng.debug_counters()[:12]
-    tot = float(sum(c[:8])) or 1.0
+    c = list(eng.debug_counters()[:16]); c[11] = 0
+    tot = float(sum(c[:16])) or 1.0
     ntiles = (cfg.nbytes() + a.tile_kb * 1024 - 1) // (a.tile_kb * 1024)
     print("tile_kb=%d blocks_per_cu=%s prescan=%d  kernel %.2f ms (stamped build)  tiles=%d" % (
         a.tile_kb, a.blocks_per_cu or "auto", a.prescan, ms, ntiles))
