@@ -76,16 +76,28 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
     constexpr bool PIPE = !FIX && W <= 3;
     Pending<W> pd;
     bool pd_valid = false;
-    auto finish_pending = [&]() {
+    // compares of the pending line; returns its count cell, or ~0 (the caller commits: the atomic is
+    // issued after the next tile's loads, where the wait for it to leave the wave overlaps the barrier)
+    auto finish_pending = [&]() -> uint64_t {
         vm_settled();           // (the bucket has had a whole phase A to arrive; nothing younger is in flight)
+        TD_MSTAMP(cx, 16, 0);   // pending: wait for the bucket
         const uint64_t res = match_finish<W>(p, pd);
+        TD_MSTAMP(cx, 17, 0);   // pending: compares
         const uint32_t kind = (uint32_t)(res >> 62);
         st_reads += 1;
         if (kind >= 1) st_bar += 1;
-        if (kind == 2) {
-            st_tag += 1;
-            if (!(p.dbg & DBG_NO_ATOMIC))
-                __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kind == 2) st_tag += 1;
+        return kind == 2 ? (res & R_CELL) : ~0ull;
+    };
+    // (base + 32-bit offset -- the host only takes this path with a matrix below 4 GiB -- and the
+    // offset register is kept alive, see cell_off's use after phase C: the wave must not stall
+    // overwriting it while the atomic still waits to read it)
+    uint32_t cell_off = 0;
+    auto commit_cell = [&](uint64_t cell) {
+        if (cell != ~0ull && !(p.dbg & DBG_NO_ATOMIC)) {
+            cell_off = (uint32_t)cell * 4u;
+            __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(p.counts) + cell_off), 1u,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
 #ifdef TD_PHASE_PROF
@@ -108,25 +120,34 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
     };
     uint4 v[CPT];
     const bool has_halo = (uint32_t)tid < halo_ch;
-    auto tile_src = [&](uint32_t tile) -> const uint4 * {
-        const uint8_t *base = tile >= p.tail_tile ? p.tail_buf + (uint64_t)(tile - p.tail_tile) * TILE
-                                                  : p.buf + (uint64_t)tile * TILE;
-        return reinterpret_cast<const uint4 *>(base);
+    auto tile_base = [&](uint32_t tile) -> const uint8_t * {
+        return tile >= p.tail_tile ? p.tail_buf + (uint64_t)(tile - p.tail_tile) * TILE : p.buf + (uint64_t)tile * TILE;
     };
     // Every tile is loaded with plain, independent 16-byte loads: the tiles whose window crosses the
-    // buffer's end come from the zero-padded copy the host made of the buffer's tail.
+    // buffer's end come from the zero-padded copy the host made of the buffer's tail.  They are
+    // buffer loads: a scalar descriptor for the tile's window, a scalar offset per load, and ONE
+    // per-thread offset register that never changes.  (A load reads its address registers only
+    // when the memory pipeline gets to it; a wave that overwrites them before that -- the next
+    // load's address, say -- stalls until it has.)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t voff = (uint32_t)tid * 16u;
+    auto tile_rsrc = [&](uint32_t tile) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base(tile)), 0, (int)(TILE + 4096u), 0x00020000);
+    };
     auto fetch_tile = [&](uint32_t tile) {
-        const uint4 *src = tile_src(tile);
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(tile);
         if (p.nt_loads) {
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + j * BLOCK + tid));
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * (BLOCK * 16), 2 /* nt */);
                 v[j] = make_uint4(q.x, q.y, q.z, q.w);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < CPT; j++) v[j] = src[j * BLOCK + tid];
+            for (int j = 0; j < CPT; j++) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * (BLOCK * 16), 0);
+                v[j] = make_uint4(q.x, q.y, q.z, q.w);
+            }
         }
     };
     fetch_item(it, t, code, Pg);
@@ -153,7 +174,10 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
             // the halo (the first chunks of the next tile) is fetched now and packed at the end of A:
             // it is not carried across the rest of the loop like the tile's own prefetched bytes
             uint4 vh = make_uint4(0u, 0u, 0u, 0u);
-            if (has_halo) vh = tile_src(t)[TILE_CH + tid];
+            if (has_halo) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(t), voff, (int)TILE, 0);
+                vh = make_uint4(q.x, q.y, q.z, q.w);
+            }
             // (phase A ends by consuming vh unconditionally -- halo_seen -- so that the compiler knows
             // the load has landed and does not guard later writes of these registers with waits)
             auto halo_seen = [&]() { asm volatile("" ::"v"(vh.x), "v"(vh.y), "v"(vh.z), "v"(vh.w)); };
@@ -210,10 +234,12 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         TD_STAMP(1);   // A: wait for this tile's bytes, masks + packing
         // the line this thread left pending in the previous tile: its bucket has had phase A to arrive,
         // and nothing younger is in flight yet
-        if (PIPE && pd_valid) { finish_pending(); pd_valid = false; }
-        TD_STAMP(5);   // pending line finished
+        uint64_t pcell = ~0ull;
+        if (PIPE && pd_valid) { pcell = finish_pending(); pd_valid = false; }
         fetch_item(nit, tn, coden, Pgn);
         if (nit < nwork) fetch_tile(tn);
+        if (PIPE) commit_cell(pcell);
+        TD_STAMP(5);   // pending line committed, next tile's loads issued
         lds_barrier();
         TD_STAMP(2);   // barrier A
 
@@ -282,6 +308,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
             r0 = (4u - (uint32_t)(first_line & 3)) & 3u;      // tile 0: P = 0, the phase is known
         }
         TD_STAMP(4);   // C: vote
+        if (PIPE) asm volatile("" ::"v"(cell_off));       // (keeps the atomic's offset register untouched until here)
         if (tid == 0 && !FIX)
             fp.tile_info[t] = total | (r0 << TI_R0_SHIFT) | (tile_has_hi ? TI_HI : 0u);
 
@@ -408,7 +435,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         TD_STAMP(7);   // end barrier (other waves' matching)
         it = nit; t = tn; code = coden; Pg = Pgn;
     }
-    if (PIPE && pd_valid) finish_pending();         // lines left pending by the last tile
+    if (PIPE && pd_valid) commit_cell(finish_pending());   // lines left pending by the last tile
 #ifdef TD_PHASE_PROF
     if (tid == 0 && !FIX)
         for (int i = 0; i < PROF_PHASES; i++) atomicAdd(p.stats + 8 + i, prof_acc[i]);

@@ -194,12 +194,12 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
             prof_last = now_;                                               \
         }                                                                   \
     } while (0)
-// inside the matcher (wave 0, whatever lanes are active): drains LDS / memory first so that the
-// latency lands in the phase that waits for it
+// inside the matcher (wave 0, whatever lanes are active): drains LDS first so that its latency
+// lands in the phase that waits for it
 #define TD_MSTAMP(cx, i, drain)                                              \
     do {                                                                    \
         if ((cx).pacc && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) { \
-            if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+            if (drain) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
             unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
             (cx).pacc[i] += now_ - *(cx).plast;                             \
             *(cx).plast = now_;                                             \
@@ -209,7 +209,7 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #define TD_STAMP(i) do {} while (0)
 #define TD_MSTAMP(cx, i, drain) do {} while (0)
 #endif
-constexpr int PROF_PHASES = 16;
+constexpr int PROF_PHASES = 20;
 
 // ---------------------------------------------------------------- the kernel
 // 2-bit codes (first base in the top bits) and per-base invalid flags (bit k = byte k of the chunk)
@@ -303,6 +303,9 @@ enum { ML_FAST = 0, ML_SLOW = 1, ML_BOTH = 2 };
 template <int W> struct Pending {
     uint64_t R[W];          // the read from the tag offset on, packed
     uint32_t nr;            // valid bases there (bits 0..14), PD_PROBE: a bucket was fetched, row << 16 (count-matrix row)
+    uint32_t boff;          // byte offset of that bucket in the table.  Kept (rather than recomputed) on purpose:
+                            // the loads take it as their only address VGPR, and a VGPR that stays live is not
+                            // overwritten while the loads still wait to read it (which would stall the wave)
     uint4 b[W <= 3 ? 4 : 8];   // that bucket (loads left in flight by match_prepare)
 };
 constexpr uint32_t PD_PROBE = 1u << 15;
@@ -427,7 +430,8 @@ __device__ __forceinline__ uint64_t match_stream(const KParams &p, const TileCtx
     if (nrem >= p.m_bases && !(p.dbg & DBG_NO_PROBE)) {
         pd.nr |= PD_PROBE;
         const uint32_t bk = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
-        const uint4 *bp = p.buckets + (size_t)bk * BUCKET_U4_;
+        pd.boff = bk * (uint32_t)(BUCKET_U4_ * 16);         // (the table is far below 4 GiB: td_set_index checks)
+        const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(p.buckets) + pd.boff);
 #pragma unroll
         for (int q = 0; q < BUCKET_U4_; q++) pd.b[q] = bp[q];   // in flight: first used by match_finish
     } else if (p.nshort == 0) {
@@ -468,7 +472,7 @@ __device__ __forceinline__ uint64_t match_finish(const KParams &p, const Pending
     bool thit = false;
     uint32_t col = 0;
     if (pd.nr & PD_PROBE) {
-        uint32_t bk = 0;        // (recomputed from the read only if the bucket overflowed)
+        uint32_t bk = pd.boff / (uint32_t)(BUCKET_U4 * 16);
         uint32_t raw[BUCKET_U4 * 4];
 #pragma unroll
         for (int q = 0; q < BUCKET_U4; q++) {
@@ -486,7 +490,6 @@ __device__ __forceinline__ uint64_t match_finish(const KParams &p, const Pending
                 if (len != 0 && len <= nrem && prefix_eq(T, len)) { thit = true; col = meta2 >> 10; }
             }
             if (__builtin_expect(thit || !(raw[0] & 1u) || ++probes > p.bucket_mask, 1)) break;   // found, or the bucket never overflowed
-            if (probes == 1) bk = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
             bk = (bk + 1) & p.bucket_mask;
             const uint4 *bp = p.buckets + (size_t)bk * BUCKET_U4;
 #pragma unroll

@@ -329,7 +329,9 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     // (streamed pieces carry their true first line on the device; first_line_ub bounds it from above)
     const uint64_t fl_ub = std::max(first_line, first_line_ub);
     const bool limit_far = p.limit_line >= ~0ull - 16 || p.limit_line - std::min(p.limit_line, fl_ub) >= nbytes / 16;
-    if (h->fastpath && !tassel && !h->prescan && limit_far) {
+    // (it addresses count cells as base + 32-bit byte offset)
+    const bool counts32 = (uint64_t)h->barnum * h->ntags * 4 < (1ull << 32);
+    if (h->fastpath && !tassel && !h->prescan && limit_far && counts32) {
         int rc = h->d_tileinfo.ensure(ntiles); if (rc) return rc;
         const uint32_t fix_cap = 3u * ntiles + 8u;
         rc = h->d_fixlist.ensure(fix_cap); if (rc) return rc;
@@ -625,6 +627,7 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
     // load: at most half of the slots (measured: a denser, smaller table loses more to second
     // fetches on full buckets than it gains in L2 hits)
     while ((double)nbuckets * spb * h->table_load < (double)nlong) nbuckets <<= 1;
+    if ((uint64_t)nbuckets * bucket_dw * 4 >= (1ull << 32)) return fail(TD_E_LIMIT, "tag table beyond 4 GiB");   // 32-bit bucket offsets
     std::vector<uint32_t> slots(nbuckets * bucket_dw, 0);
     std::vector<uint32_t> shorts;
     std::vector<uint64_t> words(W);

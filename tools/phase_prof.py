@@ -17,9 +17,10 @@ NAMES_EXACT = ["ticket", "load+masks+LDS store", "barrier after load", "block sc
 
 
 NAMES = ["loop head", "A: wait bytes + masks + pack", "barrier A", "B: scan + local votes", "C: vote",
-         "finish pending line (end of A)", "D: commit + loop (rest)", "end barrier",
+         "  pending: commit (atomic issued)", "D: commit + loop (rest)", "end barrier",
          "  D: packed chunks + align", "  D: barcode walk", "  D: tag words", "(fix-up queue length)",
-         "  D: wanted-line selection", "  D: commit issued", "  D: hash + bucket loads issued", "  D: q-loop exit"]
+         "  D: wanted-line selection", "  D: commit issued", "  D: hash + bucket loads issued", "  D: hot part exit",
+         "  pending: wait for bucket", "  pending: compares", "-", "-"]
 
 
 def main():
@@ -47,8 +48,8 @@ def main():
     eng.set_option("timing", 1)
     eng.count_device(d, cfg.nbytes())
     ms, _ = eng.kernel_time_ms()
-    c = list(eng.debug_counters()[:16]); c[11] = 0
-    tot = float(sum(c[:16])) or 1.0
+    c = list(eng.debug_counters()[:20]); c[11] = 0
+    tot = float(sum(c[:20])) or 1.0
     ntiles = (cfg.nbytes() + a.tile_kb * 1024 - 1) // (a.tile_kb * 1024)
     print("tile_kb=%d blocks_per_cu=%s prescan=%d  kernel %.2f ms (stamped build)  tiles=%d" % (
         a.tile_kb, a.blocks_per_cu or "auto", a.prescan, ms, ntiles))
