@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--table-load", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
     ap.add_argument("--split", type=int, default=-1)
+    ap.add_argument("--prio", type=int, default=-1)
     ap.add_argument("--debug-ablate", type=int, default=0, help="timing-only kernel ablation bits (implies --no-check)")
     args = ap.parse_args()
 
@@ -88,6 +89,8 @@ def main():
         eng.set_option("nt_loads", args.nt)
     if args.split >= 0:
         eng.set_option("split", args.split)
+    if args.prio >= 0:
+        eng.set_option("prio", args.prio)
     if args.debug_ablate:
         eng.set_option("debug_ablate", args.debug_ablate)
         args.no_check = True

@@ -44,6 +44,17 @@ struct FParams {
     uint32_t fix_cap;
 };
 
+// Wave priority per phase (KParams::prio: bits 1:0 phase A and the tile's end, 3:2 phases B-C,
+// 5:4 phase D, 7:6 the end of phase A: pending line, next tile's loads).  The short, serial, latency-bound phases (scan, vote, matching) run above the long
+// arithmetic one: a wave that gets through them sooner has its memory requests out sooner, and
+// phase A of the co-resident workgroups fills the issue slots it leaves.
+__device__ __forceinline__ void set_prio(uint32_t level) {
+    if (level == 0) __builtin_amdgcn_s_setprio(0);
+    else if (level == 1) __builtin_amdgcn_s_setprio(1);
+    else if (level == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 // FIX = false: the main pass over all tiles (phase predicted, nothing to subtract, no limit);
 // FIX = true: the fix-up pass over the queue k_resolve left.
 template <int CPT, int W, bool FIX>
@@ -234,6 +245,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         TD_STAMP(1);   // A: wait for this tile's bytes, masks + packing
         // the line this thread left pending in the previous tile: its bucket has had phase A to arrive,
         // and nothing younger is in flight yet
+        set_prio((p.prio >> 6) & 3u);
         uint64_t pcell = ~0ull;
         if (PIPE && pd_valid) { pcell = finish_pending(); pd_valid = false; }
         fetch_item(nit, tn, coden, Pgn);
@@ -242,6 +254,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         TD_STAMP(5);   // pending line committed, next tile's loads issued
         lds_barrier();
         TD_STAMP(2);   // barrier A
+        set_prio((p.prio >> 2) & 3u);
 
         // ---------------- B: terminators of this thread's CPT consecutive chunks, block scan
         const bool tile_has_hi = L_misc[1] != 0;
@@ -308,6 +321,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
             r0 = (4u - (uint32_t)(first_line & 3)) & 3u;      // tile 0: P = 0, the phase is known
         }
         TD_STAMP(4);   // C: vote
+        set_prio((p.prio >> 4) & 3u);
         if (PIPE) asm volatile("" ::"v"(cell_off));       // (keeps the atomic's offset register untouched until here)
         if (tid == 0 && !FIX)
             fp.tile_info[t] = total | (r0 << TI_R0_SHIFT) | (tile_has_hi ? TI_HI : 0u);
@@ -428,6 +442,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
             }
         }
 
+        set_prio(p.prio & 3u);
         TD_STAMP(6);   // D: match + commit (thread 0's share)
         // ---------------- next work item
         if (tid == 0) L_misc[1] = 0;

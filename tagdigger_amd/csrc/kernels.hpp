@@ -94,6 +94,7 @@ struct KParams {
     // are loaded from a zero-padded copy, so that every tile is fetched with plain unconditional loads
     const uint8_t *tail_buf;
     uint32_t tail_tile;
+    uint32_t prio;           // fast path: wave priority per phase, see set_prio
     uint32_t stagger, stagger_div;   // start-up stagger of co-resident workgroups (units of 4096 cycles; 0 = off)
     uint32_t dbg;            // timing-only ablations (results wrong when nonzero); see DBG_*
 };

@@ -164,6 +164,7 @@ struct td_handle {
     uint32_t debug_ablate = 0;
     double table_load = 0.5;
     int stagger = 0;
+    int prio = 0xE8;            // wave priority per phase of the fast path: A 0, B-C 2, D 2, end of A 3 (kernel_fast.hpp set_prio)
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
@@ -323,6 +324,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     p.dbg = h->debug_ablate;
     p.stagger = (uint32_t)h->stagger; p.stagger_div = (uint32_t)h->num_cu;
     p.nt_loads = (uint32_t)h->nt_loads;
+    p.prio = (uint32_t)h->prio;
 
     // ---- fast path: free-running tiles with a predicted line phase, exact resolve, fix-up pass.
     // Chosen when the maxreads limit cannot bite early (it is still applied exactly, by fix-ups).
@@ -940,6 +942,7 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     else if (n == "timing") h->timing = value ? 1 : 0;
     else if (n == "fastpath") h->fastpath = value ? 1 : 0;
     else if (n == "stagger") h->stagger = (int)value;
+    else if (n == "prio") h->prio = (int)value & 255;
     else if (n == "split") h->split = value ? 1 : 0;
     else if (n == "table_load_pct") h->table_load = std::max<int64_t>(10, std::min<int64_t>(value, 95)) / 100.0;
     else if (n == "nt_loads") h->nt_loads = value ? 1 : 0;
