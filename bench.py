@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--tile-kb", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="reads in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--stagger", type=int, default=-1)
     ap.add_argument("--slabs", type=int, default=0)
