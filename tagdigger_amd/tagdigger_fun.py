@@ -38,6 +38,7 @@ def find_tags_fastq(fqfile, barcodes, tags, cutsite="TGCAG", maxreads=5e9, tasse
 import bisect as _bisect
 import csv as _csv
 import gzip as _gzip
+import re as _re
 
 
 def isFastq(filename):
@@ -138,9 +139,34 @@ def compareTags(taglist, trim=True):
     return out
 
 
+class _SeqList(list):
+    """The list of tag sequences a reader builds, with a set beside it: the reference's uniqueness
+    checks are `x in seqlist` on a plain list (quadratic; hours at 500 k tags).  Same answers."""
+    def __init__(self):
+        super().__init__()
+        self._seen = set()
+
+    def __contains__(self, x):
+        return x in self._seen
+
+    def append(self, x):
+        self._seen.add(x)
+        super().append(x)
+
+    def extend(self, xs):
+        xs = list(xs)
+        self._seen.update(xs)
+        super().extend(xs)
+
+
+def _keep_set(toKeep):
+    """Marker names to keep as a set (the reference tests `name in toKeep` on the list)."""
+    return None if toKeep is None else set(toKeep)
+
+
 def _read_tag_table(filename, needed, header_msg, handle_row):
     """Shared skeleton of the CSV tag readers: header check, per-row callback, error printing."""
-    names, seqs = [], []
+    names, seqs = [], _SeqList()
     try:
         with open(filename, mode='r') as con:
             where = None
@@ -157,12 +183,14 @@ def _read_tag_table(filename, needed, header_msg, handle_row):
     except Exception as err:
         print(err.args[0])
         return None
-    return [names, seqs]
+    return [names, list(seqs)]
 
 
 def readTags_Merged(filename, toKeep=None, allowDuplicates=False):
     """Merged format: marker name + tag with the variable region as [A/C] (reference
     tagdigger_fun.py:563-618).  Names come out as marker_allele_index."""
+    toKeep = _keep_set(toKeep)
+
     def row_fn(row, where, rownum, names, seqs):
         cell = row[where[1]]
         if not set('[/]') < set(cell):
@@ -189,6 +217,8 @@ def readTags_Merged(filename, toKeep=None, allowDuplicates=False):
 
 def readTags_Rows(filename, toKeep=None):
     """One row per allele: marker name, allele name, tag (reference tagdigger_fun.py:475-514)."""
+    toKeep = _keep_set(toKeep)
+
     def row_fn(row, where, rownum, names, seqs):
         marker = row[where[0]].strip()
         if '_' in marker:
@@ -209,6 +239,8 @@ def readTags_Rows(filename, toKeep=None):
 
 def readTags_Columns(filename, toKeep=None):
     """One row per marker with two tags (reference tagdigger_fun.py:516-561)."""
+    toKeep = _keep_set(toKeep)
+
     def row_fn(row, where, rownum, names, seqs):
         marker = row[where[0]].strip()
         if '_' in marker:
@@ -231,7 +263,8 @@ def readTags_Columns(filename, toKeep=None):
 def readTags_UNEAK_FASTA(filename, toKeep=None):
     """Tag pairs from a TASSEL-UNEAK FASTA: four lines per pair, '>TPn_query_len' / sequence /
     '>TPn_hit_len' / sequence (reference tagdigger_fun.py:395-473)."""
-    names, seqs = [], []
+    names, seqs = [], _SeqList()
+    toKeep = _keep_set(toKeep)
     try:
         with open(filename, mode='r') as con:
             name1 = name2 = seq1 = seq2 = None
@@ -278,6 +311,235 @@ def readTags_UNEAK_FASTA(filename, toKeep=None):
         print("File {} not readable.".format(filename))
         return None
     except Exception as err:
+        print(err.args[0])
+        return None
+    return [names, list(seqs)]
+
+
+def reverseComplement(sequence):
+    """Reverse complement; characters other than A, C, G, T pass through unchanged (reference
+    tagdigger_fun.py:1203-1206)."""
+    return sequence.translate({65: 'T', 67: 'G', 71: 'C', 84: 'A'})[::-1]
+
+
+def _open_maybe_gz(path):
+    """Text-mode handle; gzip when the name ends in '.gz' (as the Stacks reader decides, :630)."""
+    return _gzip.open(path, mode='rt') if path.endswith('.gz') else open(path, mode='r')
+
+
+def _stacks_rows(path):
+    """Rows of a Stacks catalog table (tab separated), comment rows ('#...') left out."""
+    with _open_maybe_gz(path) as con:
+        for row in _csv.reader(con, delimiter='\t'):
+            if not row[0].startswith("#"):
+                yield row
+
+
+def readTags_Stacks(tagsfile, snpsfile, allelesfile, toKeep=None, binaryOnly=False, version=1):
+    """Tags from a Stacks catalog: consensus sequences (tags.tsv), SNP columns (snps.tsv) and
+    haplotypes (alleles.tsv) -> one tag per haplotype, named locus_haplotype (reference
+    tagdigger_fun.py:620-719).  The column layout depends on the Stacks version."""
+    if version == 1:
+        col_locus, col_seq, col_hap, col_pos = 2, 9, 3, 3
+    else:
+        col_locus, col_seq, col_hap, col_pos = 1, 5, 2, 2
+    wanted = lambda locus: toKeep == None or locus in toKeep
+    try:
+        consensus = {}
+        for row in _stacks_rows(tagsfile):
+            if wanted(row[col_locus]):
+                consensus[row[col_locus]] = row[col_seq]
+        haplotypes = []
+        for row in _stacks_rows(allelesfile):
+            if wanted(row[col_locus]):
+                haplotypes.append((row[col_locus], row[col_hap]))
+        snp_columns = {}
+        for row in _stacks_rows(snpsfile):
+            if wanted(row[col_locus]):
+                snp_columns.setdefault(row[col_locus], []).append(int(row[col_pos]))
+
+        names, seqs = [], []
+        for locus, hap in haplotypes:
+            seq = consensus[locus]
+            if len(hap) > 0:
+                # the haplotype's k-th character replaces the consensus base at the k-th SNP column
+                cols = snp_columns[locus]
+                pieces = [seq[:cols[0]]]
+                for k, base in enumerate(hap):
+                    pieces.append(base)
+                    pieces.append(seq[cols[k] + 1:] if k + 1 == len(hap) else seq[cols[k] + 1:cols[k + 1]])
+                seq = "".join(pieces)
+            seq = seq.upper()
+            if set(seq) <= set('ACGT'):
+                names.append(locus + '_' + hap)
+                seqs.append(seq)
+            else:
+                print("{}_{} skipped for having non-ACGT nucleotides.".format(locus, hap))
+        if binaryOnly:
+            # loci with exactly two haplotypes; 0 / 1 by alphabetical order of the haplotypes
+            kept_names, kept_seqs = [], []
+            for alleles, where in extractMarkers(names)[1]:
+                if len(alleles) != 2:
+                    continue
+                first_is_0 = alleles[0] < alleles[1]
+                kept_names.append(names[where[0]] + ('_0' if first_is_0 else '_1'))
+                kept_names.append(names[where[1]] + ('_1' if first_is_0 else '_0'))
+                kept_seqs.extend([seqs[where[0]], seqs[where[1]]])
+            names, seqs = kept_names, kept_seqs
+        return [names, seqs]
+    except IOError:
+        print("Files not readable.")
+    except (IndexError, ValueError):
+        print("Files in wrong format.")
+    except KeyError:
+        print("Locus names not matching properly.")
+    except Exception as err:
+        print(err.args[0])
+    return None
+
+
+_SAM_UNALIGNED = {4 + f for f in (0, 1, 2, 8, 16, 32, 64, 128)}     # the forms of flag 4 the reference tests for (:750)
+_SAM_REVERSE = {16 + f for f in (0, 1, 2, 8, 32, 64, 128)}          # and of flag 16 (:761)
+
+
+def readTags_TASSELSAM(filename, toKeep=None, binaryOnly=False, noMonomorphic=False,
+                       writeMarkerKey=False, keyfilename=None):
+    """Tags from a SAM file of aligned TASSEL-GBSv2 tags; alignments that start at the same
+    position and strand are the tags of one marker, named chromosome-position-strand (reference
+    tagdigger_fun.py:721-854).  toKeep holds TASSEL SNP names (e.g. S03_350622)."""
+    assert (not writeMarkerKey) or keyfilename != None, "keyfilename needed."
+    names, seqs, snp_key = [], [], []
+    by_marker = {}
+    width = 0            # digits of the longest chromosome length seen so far (@SQ LN:)
+    try:
+        with open(filename, mode='r') as con:
+            for line in con:
+                if line[0:3] == '@SQ':
+                    width = max(width, len(line.split()[2][3:]))
+                    continue
+                if line[0] == '@':
+                    continue
+                f = line.split()
+                flags = int(f[1])
+                if flags in _SAM_UNALIGNED:
+                    continue
+                chrom = f[2].replace('_', '*')            # '_' separates marker from allele in tag names
+                pos = int(f[3])
+                seq = f[9]
+                strand = "top"
+                if flags in _SAM_REVERSE:
+                    strand = "bot"
+                    seq = reverseComplement(seq)
+                    # the tag starts at the cut site, i.e. at the alignment's last reference base
+                    cigar = f[5]
+                    deleted = sum(int(x[:-1]) for x in _re.findall(r'\d+D', cigar))
+                    inserted = sum(int(x[:-1]) for x in _re.findall(r'\d+I', cigar))
+                    pos = pos + len(seq) - inserted + deleted - 1
+                marker = "{}-{:0>{width}}-{}".format(chrom, pos, strand, width=width)
+                if marker not in by_marker:
+                    by_marker[marker] = [seq]
+                    continue
+                # of two tags one of which is a prefix of the other, the shorter stays (:776-785)
+                kept = [t for t in by_marker[marker] if not t.startswith(seq)]
+                by_marker[marker] = kept
+                if not any(seq.startswith(t) for t in kept):
+                    kept.append(seq)
+
+        for marker in sorted(by_marker):
+            tags = by_marker[marker]
+            if (binaryOnly and len(tags) != 2) or (noMonomorphic and len(tags) == 1):
+                continue
+            diff = compareTags(tags, trim=False)
+            if toKeep != None or writeMarkerKey:
+                chrom, postext, strand = marker.split('-')[:3]
+                chrom = chrom.upper()
+                if chrom.startswith("CHROMOSOME"):
+                    chrom = chrom[10:]
+                if chrom.startswith("CHR"):
+                    chrom = chrom[3:]
+                step = 1 if strand == 'top' else -1
+                tassel_names = ['S{}_{}'.format(chrom, int(postext) + step * d[0]) for d in diff]
+                if toKeep != None and all(n not in toKeep for n in tassel_names):
+                    continue
+                if writeMarkerKey:
+                    snp_key.extend((n, marker) for n in tassel_names)
+            alleles = [''.join(d[1][i] for d in diff) for i in range(len(tags))]
+            tagnames = [marker + '_' + a for a in alleles]
+            if binaryOnly and alleles[0] != alleles[1]:
+                low = 0 if alleles[0] < alleles[1] else 1
+                tagnames[low] += '_0'
+                tagnames[1 - low] += '_1'
+            names.extend(tagnames)
+            seqs.extend(tags)
+        if len(names) == 0:
+            raise Exception("No markers output; is list of markers to keep in right format (e.g. S03_350622)?")
+    except IOError:
+        print("Could not read file {}.".format(filename))
+        return None
+    except Exception as err:
+        print(err.args[0])
+        return None
+    if writeMarkerKey:
+        try:
+            with open(keyfilename, mode='w', newline='') as out:
+                w = _csv.writer(out)
+                w.writerow(["TASSEL-GBSv2 marker name", "TagDigger marker name"])
+                for pair in snp_key:
+                    w.writerow(pair)
+        except IOError:
+            print("Could not write file {}.".format(keyfilename))
+            return None
+    return [names, seqs]
+
+
+def _pyrad_locus(seqset, marker, binaryOnly):
+    """Names and sequences for the alleles of one pyRAD locus (reference tagdigger_fun.py:865-889):
+    trim to the shortest, drop trailing gap columns, drop alleles with N, sort, name by the
+    variable columns."""
+    n = min(len(x) for x in seqset)
+    aligned = [x[:n] for x in seqset]
+    while any(x[-1] == '-' for x in aligned):
+        aligned = [x[:-1] for x in aligned]
+        n -= 1
+    aligned = sorted(set(x for x in aligned if 'N' not in x))
+    if not ((len(aligned) != 0 and not binaryOnly) or len(aligned) == 2):
+        return [], []
+    variable = [i for i in range(n) if len(set(x[i] for x in aligned)) > 1]
+    names = ['{}_{}_{}'.format(marker, ''.join(x[i] for i in variable), k) for k, x in enumerate(aligned)]
+    return names, [x.replace('-', '') for x in aligned]
+
+
+def readTags_pyRAD(filename, toKeep=None, binaryOnly=False):
+    """Tags from a pyRAD .alleles file: '>sample  sequence' lines, each locus closed by a '//' line
+    that carries its number (reference tagdigger_fun.py:856-919)."""
+    names, seqs = [], []
+    current = set()
+    linenum = 0
+    try:
+        with open(filename, mode='r') as con:
+            for line in con:
+                if line[0] == '>':
+                    seq = line.split()[1]
+                    if not set(seq) <= set('ACGT-N'):
+                        raise Exception("Character other than ACGTN- detected in sequence.")
+                    current.add(seq)
+                elif line[0] == '/':
+                    marker = line.split()[-1][1:-1]
+                    for ch in "|*-":
+                        marker = marker.replace(ch, "")
+                    if toKeep == None or marker in toKeep:
+                        n, q = _pyrad_locus(current, marker, binaryOnly)
+                        names.extend(n)
+                        seqs.extend(q)
+                    current = set()
+                else:
+                    raise Exception("File not in pyRAD format.")
+                linenum += 1
+    except IOError:
+        print("File {} not readable.".format(filename))
+        return None
+    except Exception as err:
+        print("Line {}:".format(linenum))
         print(err.args[0])
         return None
     return [names, seqs]

@@ -77,6 +77,7 @@ def main(argv=None):
         if toKeep == None:
             raise Exception("Problem reading marker names to keep.")
 
+    binaryOnly = args.binaryOnly == 'T'
     if given[0]:
         tags = tagdigger_fun.readTags_UNEAK_FASTA(args.UNEAKtags, toKeep=toKeep)
     elif given[1]:
@@ -85,10 +86,15 @@ def main(argv=None):
         tags = tagdigger_fun.readTags_Columns(args.ColumnTags, toKeep=toKeep)
     elif given[3]:
         tags = tagdigger_fun.readTags_Rows(args.RowTags, toKeep=toKeep)
+    elif given[4]:
+        tags = tagdigger_fun.readTags_Stacks(args.StacksTags, args.StacksSnps, args.StacksAlleles,
+                                             toKeep=toKeep, binaryOnly=binaryOnly)
+    elif given[5]:
+        tags = tagdigger_fun.readTags_TASSELSAM(args.TASSELSAM, toKeep=toKeep, binaryOnly=binaryOnly,
+                                                writeMarkerKey=args.TASSELkeyFile != None,
+                                                keyfilename=args.TASSELkeyFile)
     else:
-        # Stacks / TASSEL-SAM / pyRAD readers: SURVEY.md section 8f-3, not built yet
-        raise NotImplementedError("this build reads UNEAK, Merged, Column and Row tag files; "
-                                  "Stacks, TASSEL-SAM and pyRAD inputs are not implemented yet")
+        tags = tagdigger_fun.readTags_pyRAD(args.pyRADalleles, toKeep=toKeep, binaryOnly=binaryOnly)
     if tags == None:
         raise Exception("Problem reading tags.")
     tags = tagdigger_fun.sanitizeTags(tags)

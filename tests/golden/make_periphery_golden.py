@@ -125,6 +125,86 @@ def main():
     E.append(entry("readTags_UNEAK_FASTA", {"u.fa": uneak.replace(">TP539_hit", ">TP540_hit")}, ["u.fa"]))
     E.append(entry("readTags_UNEAK_FASTA", {"u.fa": ">XP1_query_4\nACGT\n"}, ["u.fa"]))
     E.append(entry("readTags_UNEAK_FASTA", {"u.fa": ">TP1_query_8\nACGTACGT\n>TP1_hit_4\nACGTTTTT\n"}, ["u.fa"]))
+    # ---- reverseComplement
+    E.append(entry("reverseComplement", {}, ["ACGTTGCAN"]))
+    E.append(entry("reverseComplement", {}, ["acgtA"]))
+    # ---- Stacks catalog (v1 columns: locus 2, sequence 9, haplotype 3, SNP column 3; v2: 1, 5, 2, 2)
+    def stacks_v1(rows_tags, rows_snps, rows_alleles):
+        t = "# comment\n" + "".join("0\t1\t%s\t\t0\t+\tconsensus\t0\t\t%s\t0\t0\t0\n" % r for r in rows_tags)
+        sn = "# c\n" + "".join("0\t1\t%s\t%d\tE\t0\tA\tC\n" % r for r in rows_snps)
+        al = "# c\n" + "".join("0\t1\t%s\t%s\t50.0\t10\n" % r for r in rows_alleles)
+        return {"cat.tags.tsv": t, "cat.snps.tsv": sn, "cat.alleles.tsv": al}
+    st = stacks_v1([("1", "TGCAGAAAACCCCGGGGTTTT"), ("2", "TGCAGTTTTGGGGCCCCAAAA"), ("3", "TGCAGACGTACGTACGTACGN"), ("4", "tgcagcccccaaaaa")],
+                   [("1", 7), ("1", 12), ("2", 9), ("3", 6)],
+                   [("1", "AC"), ("1", "GT"), ("1", "AT"), ("2", "C"), ("2", "A"), ("3", "G"), ("4", "")])
+    sargs = ["cat.tags.tsv", "cat.snps.tsv", "cat.alleles.tsv"]
+    E.append(entry("readTags_Stacks", st, sargs))
+    E.append(entry("readTags_Stacks", st, sargs, {"binaryOnly": True}))
+    E.append(entry("readTags_Stacks", st, sargs, {"toKeep": ["2", "4"]}))
+    stgz = dict(st)
+    stgz["cat.tags.tsv.gz"] = gzip.compress(st["cat.tags.tsv"].encode(), mtime=0)
+    del stgz["cat.tags.tsv"]
+    E.append(entry("readTags_Stacks", stgz, ["cat.tags.tsv.gz", "cat.snps.tsv", "cat.alleles.tsv"]))
+    v2 = {"t.tsv": "# c\n1\t7\t\t\t\tTGCAGAAAACCCC\n1\t8\t\t\t\tTGCAGTTTTGGGG\n",
+          "s.tsv": "1\t7\t6\tE\n1\t8\t5\tE\n", "a.tsv": "1\t7\tA\n1\t7\tG\n1\t8\tC\n1\t8\tA\n"}
+    E.append(entry("readTags_Stacks", v2, ["t.tsv", "s.tsv", "a.tsv"], {"version": 2}))
+    E.append(entry("readTags_Stacks", v2, ["t.tsv", "s.tsv", "a.tsv"], {"version": 2, "binaryOnly": True}))
+    E.append(entry("readTags_Stacks", {}, ["no.tsv", "no2.tsv", "no3.tsv"]))
+    bad = dict(st); bad["cat.snps.tsv"] = "0\t1\t1\tx\n"
+    E.append(entry("readTags_Stacks", bad, sargs))                       # ValueError
+    bad = dict(st); bad["cat.alleles.tsv"] = "0\t1\t9\tA\n"
+    E.append(entry("readTags_Stacks", bad, sargs))                       # KeyError
+    bad = dict(st); bad["cat.alleles.tsv"] = "0\t1\n"
+    E.append(entry("readTags_Stacks", bad, sargs))                       # IndexError
+    bad = dict(st); bad["cat.alleles.tsv"] = st["cat.alleles.tsv"] + "0\t1\t1\tAC\t1\t1\n"
+    E.append(entry("readTags_Stacks", bad, sargs, {"binaryOnly": True}))  # non-unique names
+    bad = dict(st); bad["cat.alleles.tsv"] = "0\t1\t2\tCAG\n"
+    E.append(entry("readTags_Stacks", bad, sargs))                       # haplotype longer than the SNP list
+    # ---- TASSEL-GBSv2 SAM
+    sam = ("@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:Chr01\tLN:43270923\n@SQ\tSN:scaffold_12\tLN:9000\n@PG\tID:bowtie2\n"
+           "tagSeq=A\t0\tChr01\t1000\t42\t20M\t*\t0\t0\tTGCAGAAAACCCCGGGGTTT\tIIII\n"
+           "tagSeq=B\t0\tChr01\t1000\t42\t20M\t*\t0\t0\tTGCAGAAAACCCCGGTGTTT\tIIII\n"
+           "tagSeq=C\t16\tChr01\t2000\t42\t10M2D8M\t*\t0\t0\tAAACCCGGGTTTACTGCA\tIIII\n"
+           "tagSeq=D\t16\tChr01\t2000\t42\t10M2D8M\t*\t0\t0\tAAACCCGGGTTAACTGCA\tIIII\n"
+           "tagSeq=E\t4\t*\t0\t0\t*\t*\t0\t0\tTGCAGGGGGGGGGG\tIIII\n"
+           "tagSeq=F\t0\tscaffold_12\t77\t42\t12M\t*\t0\t0\tTGCAGTTTTTTT\tIIII\n"
+           "tagSeq=G\t0\tscaffold_12\t77\t42\t16M\t*\t0\t0\tTGCAGTTTTTTTACGT\tIIII\n"
+           "tagSeq=H\t0\tscaffold_12\t77\t42\t12M\t*\t0\t0\tTGCAGTTATTTT\tIIII\n"
+           "tagSeq=I\t0\tscaffold_12\t77\t42\t8M\t*\t0\t0\tTGCAGTTA\tIIII\n"
+           "tagSeq=J\t16\tChr01\t500\t42\t4M1I10M\t*\t0\t0\tAAACCCGGGTTCTGCA\tIIII\n"
+           "tagSeq=K\t0\tchromosome03\t31\t42\t9M\t*\t0\t0\tTGCAGACGT\tIIII\n"
+           "tagSeq=L\t0\tchromosome03\t31\t42\t9M\t*\t0\t0\tTGCAGACGA\tIIII\n"
+           "tagSeq=M\t0\tchromosome03\t31\t42\t9M\t*\t0\t0\tTGCAGTCGA\tIIII\n")
+    E.append(entry("readTags_TASSELSAM", {"t.sam": sam}, ["t.sam"]))
+    E.append(entry("readTags_TASSELSAM", {"t.sam": sam}, ["t.sam"], {"binaryOnly": True}))
+    E.append(entry("readTags_TASSELSAM", {"t.sam": sam}, ["t.sam"], {"noMonomorphic": True}))
+    E.append(entry("readTags_TASSELSAM", {"t.sam": sam}, ["t.sam"], {"toKeep": ["S01_1015", "S03_31", "S01_1989"]}))
+    E.append(entry("readTags_TASSELSAM", {"t.sam": sam}, ["t.sam"], {"toKeep": ["nothing"]}))
+    E.append(entry("readTags_TASSELSAM", {"t.sam": sam}, ["t.sam"], {"writeMarkerKey": True, "keyfilename": "key_out.csv"}))
+    E.append(entry("readTags_TASSELSAM", {"t.sam": sam}, ["t.sam"], {"writeMarkerKey": True, "keyfilename": "key_out.csv", "binaryOnly": True,
+                                                                   "toKeep": ["S03_31", "S03_35"]}))
+    E.append(entry("readTags_TASSELSAM", {"t.sam": sam}, ["t.sam"], {"writeMarkerKey": True}))
+    E.append(entry("readTags_TASSELSAM", {}, ["missing.sam"]))
+    E.append(entry("readTags_TASSELSAM", {"t.sam": sam + "\n"}, ["t.sam"]))
+    E.append(entry("readTags_TASSELSAM", {"t.sam": sam + "x\t0\tChr01\t9\t1\t5M\t*\t0\t0\tTGCNG\tI\n"}, ["t.sam"]))
+    E.append(entry("readTags_TASSELSAM", {"t.sam": sam + "x\tzz\tChr01\t9\t1\t5M\t*\t0\t0\tTGCAG\tI\n"}, ["t.sam"]))
+    # ---- pyRAD .alleles
+    pyrad = (">s1_0    TGCAGAAAACCCCGGGG--\n>s1_1    TGCAGAAAACCCCGGGG--\n>s2_0    TGCAGAAAATCCCGGGGTT\n>s2_1    TGCAGAAAACCCCGGGG\n"
+             "//                   *              |0|\n"
+             ">s1_0    TGCAGTTNT\n>s1_1    TGCAGTTAT\n>s2_0    TGCAGTTCT\n>s2_1    TGCAGTT-T\n"
+             "//             -     |1|\n"
+             ">s1_0    TGCAGGG\n>s1_1    TGCAGGG\n"
+             "//           |2|\n"
+             ">s1_0    TGCAGCA\n>s1_1    TGCAGCC\n>s2_0    TGCAGCG\n"
+             "//      * |13|\n")
+    E.append(entry("readTags_pyRAD", {"p.alleles": pyrad}, ["p.alleles"]))
+    E.append(entry("readTags_pyRAD", {"p.alleles": pyrad}, ["p.alleles"], {"binaryOnly": True}))
+    E.append(entry("readTags_pyRAD", {"p.alleles": pyrad}, ["p.alleles"], {"toKeep": ["1", "13"]}))
+    E.append(entry("readTags_pyRAD", {"p.alleles": pyrad + ">s1_0    TGCAGXA\n"}, ["p.alleles"]))
+    E.append(entry("readTags_pyRAD", {"p.alleles": pyrad + "junk\n"}, ["p.alleles"]))
+    E.append(entry("readTags_pyRAD", {"p.alleles": "//   |5|\n"}, ["p.alleles"]))
+    E.append(entry("readTags_pyRAD", {"p.alleles": ">a   ---\n>b   ---\n//   |5|\n"}, ["p.alleles"]))
+    E.append(entry("readTags_pyRAD", {}, ["missing.alleles"]))
     # ---- compareTags
     E.append(entry("compareTags", {}, [["ACGTA", "ACCTA", "ACGTT"]]))
     E.append(entry("compareTags", {}, [["ACGTA", "ACC"]]))
