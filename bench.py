@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--tile-kb", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="reads in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-python-sample", type=int, default=400_000,
+                    help="reads for the pure-Python restatement's timing inside cpu_baseline (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--stagger", type=int, default=-1)
     ap.add_argument("--slabs", type=int, default=0)
@@ -190,7 +192,7 @@ def main():
             "check": check,
         }
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample, cfg.nreads))
+            out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample, cfg.nreads), min(args.cpu_python_sample, cfg.nreads))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -198,9 +200,12 @@ def main():
     eng.close()
 
 
-def cpu_baseline(cfg, sample_reads):
+def cpu_baseline(cfg, sample_reads, python_reads=0):
     """The oracle's C restatement (oracle/oracle.c, scalar, one thread) on the first
-    `sample_reads` reads of the same stream, produced by the host reference generator."""
+    `sample_reads` reads of the same stream, produced by the host reference generator.
+    `python_restatement`: the pure-Python restatement (oracle/tagdigger_oracle.py: the reference's own
+    nested-list trie and per-line loop, the closest thing to the reference that can travel; BASELINE.md
+    has its calibration against the real reference: 41.6 k vs 28.2 k reads/s on the build host)."""
     from helpers import synth_host_bytes
     from oracle import c_oracle
     data = synth_host_bytes(cfg, 0, sample_reads)
@@ -210,11 +215,24 @@ def cpu_baseline(cfg, sample_reads):
     t0 = time.perf_counter()
     ora.count_bytes(data)
     loop_s = time.perf_counter() - t0
-    return {"value": sample_reads / loop_s, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads of the same synthetic stream (%.2f GB), record loop only; "
-                      "trie build %.2f s timed separately; scalar C restatement oracle/oracle.c"
-                      % (sample_reads, data.nbytes / 1e9, build_s),
-            "index_build_s": build_s, "loop_s": loop_s}
+    out = {"value": sample_reads / loop_s, "unit": "reads/s", "cores": 1, "kind": "port",
+           "sample": "first %d reads of the same synthetic stream (%.2f GB), record loop only; "
+                     "trie build %.2f s timed separately; scalar C restatement oracle/oracle.c"
+                     % (sample_reads, data.nbytes / 1e9, build_s),
+           "index_build_s": build_s, "loop_s": loop_s}
+    if python_reads > 0:
+        from oracle import tagdigger_oracle as po
+        pdata = bytes(data[:python_reads * cfg.record_bytes])
+        t0 = time.perf_counter()
+        index = po.prepare_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        pbuild = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        po.count_bytes(pdata, cfg.barcodes, cfg.tags, cfg.cutsite, index=index)
+        ploop = time.perf_counter() - t0
+        out["python_restatement"] = {"value": python_reads / ploop, "unit": "reads/s", "cores": 1,
+                                     "sample": "first %d reads, record loop only" % python_reads,
+                                     "index_build_s": pbuild, "loop_s": ploop}
+    return out
 
 
 if __name__ == "__main__":
