@@ -113,6 +113,34 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
 int td_count_lines_device(td_handle *h, const void *d_fastq, uint64_t nbytes,
                           void *stream, uint64_t *terminators_out);
 
+/* ---- barcode splitter (the adapter-trim branch) -----------------------------
+ * Replaces the record loop of barcodeSplitter (tagdigger_fun.py:1318-1368) with its per-read
+ * decisions -- sequence_index_lookup on barcode+cutsite (:1340) and findAdapterSeq (:1251-1283)
+ * -- on the GPU; the host writes the clipped records.
+ *
+ * td_set_splitter: barcodes[nbar] and the single ACGT cut site (:1292-1293); fullsite0/1 = the two
+ * full restriction sites (adapter[k][0] without '^', :1311-1312, at most 8 bases); and, per
+ * barcode b, the adapter beginnings to look for at the END of a read, entries
+ * ent_begin[b] .. ent_begin[b+1]-1: ent_seq[e] (forward orientation) and ent_slice[e] = the index
+ * build_adapter_tree (:1208-1249) pairs with it.  The caller resolves that list with the
+ * reference's rules (tagdigger_amd/tagdigger_fun.py does). */
+int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, const char *cutsite,
+                    const char *fullsite0, const char *fullsite1, const uint32_t *ent_begin,
+                    const char *const *ent_seq, const int32_t *ent_slice, uint32_t nent);
+
+/* Decisions for a buffer in device memory: d_out[2r], d_out[2r+1] = barcode index (-1: none) and
+ * findAdapterSeq's return value (999: nothing to clip) for the buffer's r-th sequence line (lines
+ * whose global index first_line + k is 1 mod 4).  out_capacity (in results) >= nbytes / 4 + 2.
+ * Synchronous; *n_terminators (optional) receives the buffer's line terminators. */
+int td_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line,
+                    int32_t *d_out, uint64_t out_capacity, void *stream, uint64_t *n_terminators);
+
+/* The whole loop on a file (plain or gzip by name, :1318-1321): out_paths[nbar] are created
+ * (truncated) and receive the clipped records of their barcode; stops after max_reads records
+ * (:1361-1362).  stats = reads, reads with barcode+cut site, reads clipped on the 3' end (:1359). */
+int td_split_file(td_handle *h, const char *in_path, const char *const *out_paths,
+                  uint64_t max_reads, uint64_t stats[3]);
+
 /* ---- results ---------------------------------------------------------------
  * Both synchronise with all work enqueued through this handle first and
  * return TD_E_NONASCII / TD_E_INTERNAL if a kernel flagged a problem. */

@@ -18,6 +18,7 @@
 #include "kernels.hpp"
 #include "kernel_fast.hpp"
 #include "kernel_split.hpp"
+#include "kernel_splitter.hpp"
 
 namespace {
 
@@ -153,6 +154,15 @@ struct td_handle {
     DevBuf<unsigned long long> d_cursor;      // [2] line cursor for streamed pieces
     DevBuf<uint32_t> d_tileinfo, d_nfix;      // fast path: per-tile count+phase, fix-up queue length
     DevBuf<uint8_t> d_tail;                   // fast path: zero-padded copy of the buffer's last tiles
+    // barcode splitter (td_set_splitter / td_split_*)
+    bool have_splitter = false;
+    std::vector<std::string> sp_barcodes;
+    uint32_t sp_bblob_bytes = 0, sp_off_bmeta = 0, sp_off_bdir = 0, sp_cutlen = 0;
+    unsigned long long sp_site[2] = {0, 0};
+    uint32_t sp_site_len[2] = {0, 0};
+    DevBuf<uint32_t> d_sp_bblob, d_sp_ent_begin;
+    DevBuf<tdk::SplitEntry> d_sp_entries;
+    DevBuf<uint8_t> d_sp_pool;
     DevBuf<uint4> d_fixlist;
     DevBuf<uint32_t> d_rec, d_region_count;   // split path: packed read records per wave region (two slab buffers)
     hipStream_t side_stream = nullptr;        //             k_match runs here, beside the next slab's k_emit
@@ -504,6 +514,55 @@ int check_device_errors(td_handle *h, const unsigned long long *st) {
 }  // namespace
 
 // ============================================================================ C-ABI
+namespace {
+// barcode (+ cut site) index as the kernels read it from LDS:
+// bval u64[ne] | bmeta u32[ne] | bdir u16[1024]; entries stored bucket by bucket.
+// `entries`: the resolved (sequence, row) set; tagoff[row] goes into bmeta's offset field.
+int build_barcode_blob(const std::vector<std::pair<std::string, uint32_t>> &entries, uint32_t barnum, const uint32_t *tagoff,
+                       std::vector<uint8_t> &blob, uint32_t &off_bmeta, uint32_t &off_bdir, uint32_t &max_off) {
+    const size_t nb = entries.size();
+    if (barnum > 65535) return fail(TD_E_LIMIT, "more than 65535 barcodes");
+    max_off = 0;
+    std::vector<std::vector<uint32_t>> buckets(tdk::BDIR_SIZE);
+    std::vector<uint64_t> eval(nb);
+    std::vector<uint32_t> emeta(nb);
+    for (size_t e = 0; e < nb; e++) {
+        const std::string &s = entries[e].first;
+        const uint32_t row = entries[e].second;
+        if (s.size() > 32) return fail(TD_E_LIMIT, "barcode+cutsite longer than 32 bases");
+        const uint32_t off = tagoff[row];
+        if (off > 63) return fail(TD_E_LIMIT, "tag offset beyond 63 bases");
+        max_off = std::max(max_off, off);
+        pack_bases(s, &eval[e], 1);
+        emeta[e] = (uint32_t)s.size() | (off << 6) | (row << 16);
+        const uint32_t L = (uint32_t)s.size();
+        const uint32_t base = (uint32_t)(eval[e] >> (64 - 2 * tdk::BDIR_BASES));
+        const uint32_t span = L >= tdk::BDIR_BASES ? 1u : 1u << (2 * (tdk::BDIR_BASES - L));
+        for (uint32_t k = 0; k < span; k++) buckets[base + k].push_back((uint32_t)e);
+    }
+    std::vector<uint16_t> bdir(tdk::BDIR_SIZE, 0xFFFF);
+    std::vector<uint64_t> bval;
+    std::vector<uint32_t> bmeta;
+    for (uint32_t b = 0; b < tdk::BDIR_SIZE; b++) {
+        if (buckets[b].empty()) continue;
+        if (bval.size() + buckets[b].size() > 65534) return fail(TD_E_LIMIT, "barcode directory too large");
+        bdir[b] = (uint16_t)bval.size();
+        for (size_t k = 0; k < buckets[b].size(); k++) {
+            bval.push_back(eval[buckets[b][k]]);
+            bmeta.push_back(emeta[buckets[b][k]] | (k + 1 == buckets[b].size() ? tdk::BMETA_LAST : 0u));
+        }
+    }
+    const size_t ne = bval.size();
+    off_bmeta = (uint32_t)(ne * 8);
+    off_bdir = off_bmeta + (uint32_t)((ne * 4 + 7) / 8 * 8);
+    blob.assign((off_bdir + tdk::BDIR_SIZE * 2 + 15) / 16 * 16, 0);
+    memcpy(blob.data(), bval.data(), ne * 8);
+    memcpy(blob.data() + off_bmeta, bmeta.data(), ne * 4);
+    memcpy(blob.data() + off_bdir, bdir.data(), tdk::BDIR_SIZE * 2);
+    return TD_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const char *td_last_error(void) { return g_err.c_str(); }
@@ -564,48 +623,13 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
     rc = rt.run();
     if (rc) { g_bad = rt.bad; return fail(rc, rc == TD_E_OVERLAP ? "overlapping tags" : "tag index build failed"); }
 
-    // ---- barcode blob: bval u64[ne] | bmeta u32[ne] | bdir u16[1024]; entries bucket by bucket
-    const size_t nb = rb.out.size();
-    if (barnum > 65535) return fail(TD_E_LIMIT, "more than 65535 barcodes");
+    // ---- barcode blob
     uint32_t max_off = 0;
-    std::vector<std::vector<uint32_t>> buckets(tdk::BDIR_SIZE);
-    std::vector<uint64_t> eval(nb);
-    std::vector<uint32_t> emeta(nb);
-    for (size_t e = 0; e < nb; e++) {
-        const std::string &s = rb.out[e].first;
-        const uint32_t row = rb.out[e].second;
-        if (s.size() > 32) return fail(TD_E_LIMIT, "barcode+cutsite longer than 32 bases");
-        const uint32_t off = tagoff[row];
-        if (off > 63) return fail(TD_E_LIMIT, "tag offset beyond 63 bases");
-        max_off = std::max(max_off, off);
-        pack_bases(s, &eval[e], 1);
-        emeta[e] = (uint32_t)s.size() | (off << 6) | (row << 16);
-        const uint32_t L = (uint32_t)s.size();
-        const uint32_t base = (uint32_t)(eval[e] >> (64 - 2 * tdk::BDIR_BASES));
-        const uint32_t span = L >= tdk::BDIR_BASES ? 1u : 1u << (2 * (tdk::BDIR_BASES - L));
-        for (uint32_t k = 0; k < span; k++) buckets[base + k].push_back((uint32_t)e);
-    }
-    std::vector<uint16_t> bdir(tdk::BDIR_SIZE, 0xFFFF);
-    std::vector<uint64_t> bval;
-    std::vector<uint32_t> bmeta;
-    for (uint32_t b = 0; b < tdk::BDIR_SIZE; b++) {
-        if (buckets[b].empty()) continue;
-        if (bval.size() + buckets[b].size() > 65534) return fail(TD_E_LIMIT, "barcode directory too large");
-        bdir[b] = (uint16_t)bval.size();
-        for (size_t k = 0; k < buckets[b].size(); k++) {
-            bval.push_back(eval[buckets[b][k]]);
-            bmeta.push_back(emeta[buckets[b][k]] | (k + 1 == buckets[b].size() ? tdk::BMETA_LAST : 0u));
-        }
-    }
-    const size_t ne = bval.size();
-    h->off_bmeta = (uint32_t)(ne * 8);
-    h->off_bdir = h->off_bmeta + (uint32_t)((ne * 4 + 7) / 8 * 8);
+    std::vector<uint8_t> blob;
+    rc = build_barcode_blob(rb.out, barnum, tagoff, blob, h->off_bmeta, h->off_bdir, max_off);
+    if (rc) return rc;
     h->off_bcand = 0;
-    h->bblob_bytes = (h->off_bdir + tdk::BDIR_SIZE * 2 + 15) / 16 * 16;
-    std::vector<uint8_t> blob(h->bblob_bytes, 0);
-    memcpy(blob.data(), bval.data(), ne * 8);
-    memcpy(blob.data() + h->off_bmeta, bmeta.data(), ne * 4);
-    memcpy(blob.data() + h->off_bdir, bdir.data(), tdk::BDIR_SIZE * 2);
+    h->bblob_bytes = (uint32_t)blob.size();
 
     // ---- tag table
     size_t maxlen = 0;
@@ -1037,6 +1061,308 @@ int td_synth_fill_device(td_handle *h, const void *params, uint64_t first_read, 
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     (void)hipFree(d_bar); (void)hipFree(d_bl); (void)hipFree(d_cut); (void)hipFree(d_tag); (void)hipFree(d_tl);
+    return TD_OK;
+}
+
+}  // extern "C"
+
+// ================================================================ barcode splitter
+// td_set_splitter: the index.  td_split_device: the per-read decisions for a buffer in HBM.
+// td_split_file: the reference's barcodeSplitter loop (tagdigger_fun.py:1318-1368) -- the GPU decides
+// every read, the host writes the clipped records.
+namespace {
+
+// async part of td_split_device: line prefix + k_split on `s`; out must hold one int2 per sequence line
+int launch_split(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, int2 *d_out, hipStream_t s) {
+    const uint64_t tile = 16 * 1024;
+    const uint64_t nt = (nbytes + tile - 1) / tile;
+    if (nt > 0x7FFFFFFFull) return fail(TD_E_LIMIT, "buffer too large for one launch; split it");
+    int rc = h->d_tilecounts.ensure(nt); if (rc) return rc;
+    rc = h->d_state.ensure(nt); if (rc) return rc;
+    const uint32_t g = (uint32_t)std::min<uint64_t>(nt, (uint64_t)h->num_cu * 8);
+    hipLaunchKernelGGL((tdk::k_count_lines<4>), dim3(g), dim3(tdk::BLOCK), 0, s, (const uint8_t *)d_fastq, nbytes, (uint32_t)nt, h->d_tilecounts.p);
+    hipLaunchKernelGGL(tdk::k_scan_tiles, dim3(1), dim3(1024), 0, s, h->d_tilecounts.p, (uint32_t)nt, h->d_state.p, h->d_cursor.p);
+    tdk::SplitParams sp{};
+    sp.buf = (const uint8_t *)d_fastq; sp.nbytes = nbytes; sp.first_line = first_line;
+    sp.prefix = h->d_state.p; sp.ntiles = (uint32_t)nt;
+    sp.bblob = h->d_sp_bblob.p; sp.bblob_bytes = h->sp_bblob_bytes; sp.off_bmeta = h->sp_off_bmeta; sp.off_bdir = h->sp_off_bdir;
+    sp.cutlen = h->sp_cutlen;
+    sp.site0 = h->sp_site[0]; sp.site1 = h->sp_site[1]; sp.site0_len = h->sp_site_len[0]; sp.site1_len = h->sp_site_len[1];
+    sp.ent_begin = h->d_sp_ent_begin.p; sp.entries = h->d_sp_entries.p; sp.pool = h->d_sp_pool.p;
+    sp.out = d_out; sp.stats = h->d_stats.p;
+    const size_t lds = (size_t)4 * tdk::BLOCK * 2 + 64 + h->sp_bblob_bytes;
+    hipLaunchKernelGGL((tdk::k_split<4>), dim3(g), dim3(tdk::BLOCK), lds, s, sp);
+    HIPCHK(hipGetLastError());
+    return TD_OK;
+}
+
+// upper bound of the sequence lines of a buffer: a line holds at least its terminator
+inline uint64_t max_seq_lines(uint64_t nbytes) { return nbytes / 4 + 2; }
+
+inline bool host_blank(uint8_t b) { return b == 0x20 || b == 0x09 || b == 0x0B || b == 0x0C || (b >= 0x1C && b <= 0x1F); }
+
+// The reference's record loop (:1328-1363) on the host side: lines as text mode yields them,
+// str.strip() on each, the clipped record written to its barcode's file.
+struct SplitWriter {
+    const std::vector<std::string> &barcodes;
+    std::vector<FILE *> out;
+    uint64_t lineindex = 0, reads = 0, barcut = 0, clipped = 0, max_reads = 0;
+    std::string comment1, sequence, comment2;
+    int cur_bar = -1, cur_slice = 999;
+    bool stop = false, nonascii = false;
+
+    explicit SplitWriter(const std::vector<std::string> &b) : barcodes(b) {}
+    ~SplitWriter() { for (FILE *f : out) if (f) fclose(f); }
+
+    static void stripped(const uint8_t *p, size_t n, std::string &dst, bool upper) {
+        size_t a = 0, b = n;
+        while (a < b && host_blank(p[a])) a++;
+        while (b > a && host_blank(p[b - 1])) b--;
+        dst.assign((const char *)p + a, b - a);
+        if (upper) for (char &c : dst) if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+    }
+    // s[a:b] with Python's rules for a >= 0 and any b
+    static void put_slice(FILE *f, const std::string &s, long a, long b) {
+        const long n = (long)s.size();
+        if (b < 0) { b += n; if (b < 0) b = 0; }
+        if (b > n) b = n;
+        if (a < b) fwrite(s.data() + a, 1, (size_t)(b - a), f);
+        fputc('\n', f);
+    }
+    // one line (terminator excluded); `res` advances over the piece's sequence-line results
+    void line(const uint8_t *p, size_t n, const int2 *&res) {
+        switch (lineindex & 3) {
+        case 0: stripped(p, n, comment1, false); break;
+        case 1: stripped(p, n, sequence, true); cur_bar = res->x; cur_slice = res->y; res++; break;
+        case 2: stripped(p, n, comment2, false); break;
+        default: {
+            reads++;
+            if (cur_bar > -1) {
+                std::string quality;
+                stripped(p, n, quality, false);
+                barcut++;
+                const std::string &bc = barcodes[(size_t)cur_bar];
+                const long slice1 = (long)bc.size();
+                long slice2 = cur_slice;
+                if (slice2 == 999) slice2 = (long)sequence.size(); else clipped++;
+                FILE *f = out[(size_t)cur_bar];
+                fwrite(comment1.data(), 1, comment1.size(), f); fwrite(bc.data(), 1, bc.size(), f); fputc('\n', f);
+                put_slice(f, sequence, slice1, slice2);
+                if (comment2 == "+") { fputc('+', f); fputc('\n', f); }
+                else { fwrite(comment1.data(), 1, comment1.size(), f); fwrite(bc.data(), 1, bc.size(), f); fputc('\n', f); }
+                put_slice(f, quality, slice1, slice2);
+            }
+            if (reads >= max_reads) stop = true;
+        } }
+        lineindex++;
+    }
+    // all lines of a piece that ends at a line end (or at the end of the file)
+    void piece(const uint8_t *p, size_t n, const int2 *res) {
+        size_t start = 0, i = 0;
+        while (i < n && !stop) {
+            const uint8_t c = p[i];
+            if (c >= 0x80) nonascii = true;
+            if (c == '\n') { line(p + start, i - start, res); start = ++i; }
+            else if (c == '\r') { line(p + start, i - start, res); i++; if (i < n && p[i] == '\n') i++; start = i; }
+            else i++;
+        }
+        if (!stop && start < n) line(p + start, n - start, res);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, const char *cutsite,
+                    const char *fullsite0, const char *fullsite1, const uint32_t *ent_begin,
+                    const char *const *ent_seq, const int32_t *ent_slice, uint32_t nent) {
+    if (!h || !barcodes || !cutsite || !fullsite0 || !fullsite1 || !ent_begin) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    h->have_splitter = false;
+    if (nbar == 0) return fail(TD_E_EMPTY, "empty barcode list");
+    const std::string cs(cutsite);
+    std::vector<std::string> barcut(nbar);
+    std::vector<uint32_t> barlen(nbar);
+    h->sp_barcodes.assign(nbar, std::string());
+    for (uint32_t i = 0; i < nbar; i++) {
+        h->sp_barcodes[i] = barcodes[i];
+        barcut[i] = h->sp_barcodes[i] + cs;
+        for (char &c : barcut[i]) if (c >= 'a' && c <= 'z') c = (char)(c - 32);     // combine_barcode_and_cutsite upper-cases (:69)
+        barlen[i] = (uint32_t)h->sp_barcodes[i].size();
+        if (barcut[i].empty()) return fail(TD_E_LIMIT, "empty barcode with an empty cut site is not supported by the splitter");
+    }
+    Resolver rb(barcut, nbar);
+    int rc = rb.run();
+    if (rc) { g_bad = rb.bad; return fail(rc, rc == TD_E_OVERLAP ? "overlapping barcode+cutsite sequences" : "barcode index build failed"); }
+    std::vector<uint8_t> blob;
+    uint32_t max_off = 0;
+    rc = build_barcode_blob(rb.out, nbar, barlen.data(), blob, h->sp_off_bmeta, h->sp_off_bdir, max_off);
+    if (rc) return rc;
+    h->sp_bblob_bytes = (uint32_t)blob.size();
+    if ((size_t)4 * tdk::BLOCK * 2 + 64 + blob.size() > LDS_BUDGET) return fail(TD_E_LIMIT, "barcode index does not fit the LDS budget");
+    h->sp_cutlen = (uint32_t)cs.size();
+    const char *sites[2] = {fullsite0, fullsite1};
+    for (int k = 0; k < 2; k++) {
+        const size_t L = strlen(sites[k]);
+        if (L > 8) return fail(TD_E_LIMIT, "restriction site longer than 8 bases");
+        unsigned long long v = 0;
+        for (size_t q = 0; q < L; q++) v = (v << 8) | (uint8_t)sites[k][q];
+        h->sp_site[k] = v; h->sp_site_len[k] = (uint32_t)L;
+    }
+    std::vector<tdk::SplitEntry> ents(nent);
+    std::vector<uint8_t> pool;
+    for (uint32_t e = 0; e < nent; e++) {
+        const size_t L = strlen(ent_seq[e]);
+        ents[e].off = (uint32_t)pool.size(); ents[e].len = (uint32_t)L; ents[e].slice = ent_slice[e]; ents[e].pad = 0;
+        pool.insert(pool.end(), (const uint8_t *)ent_seq[e], (const uint8_t *)ent_seq[e] + L);
+    }
+    if (ent_begin[nbar] != nent) return fail(TD_E_ARG, "ent_begin[nbar] must equal nent");
+    rc = h->d_sp_bblob.ensure(blob.size() / 4); if (rc) return rc;
+    HIPCHK(hipMemcpy(h->d_sp_bblob.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    rc = h->d_sp_ent_begin.ensure(nbar + 1); if (rc) return rc;
+    HIPCHK(hipMemcpy(h->d_sp_ent_begin.p, ent_begin, (size_t)(nbar + 1) * 4, hipMemcpyHostToDevice));
+    rc = h->d_sp_entries.ensure(std::max<size_t>(1, nent)); if (rc) return rc;
+    if (nent) HIPCHK(hipMemcpy(h->d_sp_entries.p, ents.data(), (size_t)nent * sizeof(tdk::SplitEntry), hipMemcpyHostToDevice));
+    rc = h->d_sp_pool.ensure(std::max<size_t>(1, pool.size())); if (rc) return rc;
+    if (!pool.empty()) HIPCHK(hipMemcpy(h->d_sp_pool.p, pool.data(), pool.size(), hipMemcpyHostToDevice));
+    rc = h->d_cursor.ensure(2); if (rc) return rc;
+    h->have_splitter = true;
+    return TD_OK;
+}
+
+int td_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, int32_t *d_out,
+                    uint64_t out_capacity, void *stream, uint64_t *n_terminators) {
+    if (!h || !d_out) return fail(TD_E_ARG, "NULL argument");
+    if (!h->have_splitter) return fail(TD_E_STATE, "td_set_splitter has not been called");
+    if (((uintptr_t)d_fastq & 15) != 0) return fail(TD_E_ARG, "device FASTQ pointer must be 16-byte aligned");
+    HIPCHK(hipSetDevice(h->device));
+    if (n_terminators) *n_terminators = 0;
+    if (nbytes == 0) return TD_OK;
+    if (out_capacity < max_seq_lines(nbytes)) return fail(TD_E_ARG, "output must hold nbytes / 4 + 2 results");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_split(h, d_fastq, nbytes, first_line, (int2 *)d_out, s); if (rc) return rc;
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->d_cursor.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (n_terminators) *n_terminators = v;
+    unsigned long long st[TD_STAT_NSTATS];
+    HIPCHK(hipMemcpy(st, h->d_stats.p, sizeof(st), hipMemcpyDeviceToHost));
+    return check_device_errors(h, st);
+}
+
+int td_split_file(td_handle *h, const char *in_path, const char *const *out_paths, uint64_t max_reads, uint64_t stats[3]) {
+    if (!h || !in_path || !out_paths) return fail(TD_E_ARG, "NULL argument");
+    if (!h->have_splitter) return fail(TD_E_STATE, "td_set_splitter has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t len = strlen(in_path);
+    const bool gz = len >= 2 && (in_path[len - 2] == 'g' || in_path[len - 2] == 'G') && (in_path[len - 1] == 'z' || in_path[len - 1] == 'Z');
+    gzFile zf = nullptr; FILE *pf = nullptr;
+    if (gz) { zf = gzopen(in_path, "rb"); if (zf) gzbuffer(zf, 1 << 20); } else pf = fopen(in_path, "rb");
+    if (!zf && !pf) return fail(TD_E_IO, std::string("cannot open ") + in_path);
+    auto reader = [&](uint8_t *dst, size_t want) -> long {
+        if (zf) return gzread(zf, dst, (unsigned)std::min<size_t>(want, 1u << 30));
+        size_t n = fread(dst, 1, want, pf);
+        if (n == 0 && ferror(pf)) return -1;
+        return (long)n;
+    };
+    SplitWriter w(h->sp_barcodes);
+    w.max_reads = std::max<uint64_t>(1, max_reads);
+    int rc = TD_OK;
+    const size_t cap = (size_t)32 << 20;
+    // two slots: the GPU decides piece k + 1 while the host writes piece k
+    struct Slot { uint8_t *pin = nullptr, *dev = nullptr; int2 *res_dev = nullptr, *res_pin = nullptr; size_t n = 0; hipEvent_t done = nullptr; bool pending = false; } slot[2];
+    auto cleanup = [&]() {
+        for (auto &sl : slot) {
+            if (sl.pin) (void)hipHostFree(sl.pin);
+            if (sl.dev) (void)hipFree(sl.dev);
+            if (sl.res_dev) (void)hipFree(sl.res_dev);
+            if (sl.res_pin) (void)hipHostFree(sl.res_pin);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+        }
+        if (zf) gzclose(zf);
+        if (pf) fclose(pf);
+    };
+#define SPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(TD_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    for (auto &sl : slot) {
+        SPCHK(hipHostMalloc((void **)&sl.pin, cap, hipHostMallocDefault));
+        SPCHK(hipMalloc((void **)&sl.dev, cap));
+        SPCHK(hipMalloc((void **)&sl.res_dev, max_seq_lines(cap) * sizeof(int2)));
+        SPCHK(hipHostMalloc((void **)&sl.res_pin, max_seq_lines(cap) * sizeof(int2), hipHostMallocDefault));
+        SPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    for (uint32_t b = 0; b < h->sp_barcodes.size(); b++) {
+        FILE *f = fopen(out_paths[b], "wb");
+        if (!f) { cleanup(); return fail(TD_E_IO, std::string("cannot open ") + out_paths[b] + " for writing"); }
+        setvbuf(f, nullptr, _IOFBF, 1 << 20);
+        w.out.push_back(f);
+    }
+    std::vector<uint8_t> carry;
+    bool eof = false;
+    uint64_t gpu_line = 0;            // global index of the next piece's first line (what the GPU is told)
+    int cur = 0;
+    auto drain = [&](Slot &sl) -> int {      // wait for the slot's decisions, then write its records
+        if (!sl.pending) return TD_OK;
+        hipError_t e = hipEventSynchronize(sl.done);
+        if (e != hipSuccess) return fail(TD_E_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+        sl.pending = false;
+        if (!w.stop) w.piece(sl.pin, sl.n, sl.res_pin);
+        return TD_OK;
+    };
+    while (!eof && !w.stop) {
+        Slot &sl = slot[cur];
+        rc = drain(sl); if (rc) break;                   // (its previous piece, two iterations ago)
+        size_t have = carry.size();
+        if (have) memcpy(sl.pin, carry.data(), have);
+        carry.clear();
+        while (have < cap) {
+            long got = reader(sl.pin + have, cap - have);
+            if (got < 0) { rc = fail(TD_E_IO, "read error while streaming FASTQ"); break; }
+            if (got == 0) { eof = true; break; }
+            have += (size_t)got;
+        }
+        if (rc) break;
+        size_t cut = have;
+        if (!eof) {
+            cut = cut_at_line_end(sl.pin, have);
+            if (cut == 0) { rc = fail(TD_E_LIMIT, "a single line exceeds the staging buffer"); break; }
+            carry.assign(sl.pin + cut, sl.pin + have);
+        }
+        sl.n = cut;
+        if (cut) {
+            // line count of the piece on the host (cheap next to the writing) keeps gpu_line exact
+            hipError_t e = hipMemcpyAsync(sl.dev, sl.pin, cut, hipMemcpyHostToDevice, h->work_stream);
+            if (e != hipSuccess) { rc = fail(TD_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e)); break; }
+            rc = launch_split(h, sl.dev, cut, gpu_line, sl.res_dev, h->work_stream); if (rc) break;
+            e = hipMemcpyAsync(sl.res_pin, sl.res_dev, max_seq_lines(cut) * sizeof(int2), hipMemcpyDeviceToHost, h->work_stream);
+            if (e != hipSuccess) { rc = fail(TD_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e)); break; }
+            (void)hipEventRecord(sl.done, h->work_stream);
+            sl.pending = true;
+            // lines in this piece = its terminators (+1 for an unterminated last line at the end of the file)
+            uint64_t nl = 0;
+            for (size_t i = 0; i < cut; i++) {
+                const uint8_t c = sl.pin[i];
+                if (c == '\n') nl++;
+                else if (c == '\r' && !(i + 1 < cut && sl.pin[i + 1] == '\n')) nl++;
+            }
+            if (cut && sl.pin[cut - 1] != '\n' && sl.pin[cut - 1] != '\r') nl++;
+            gpu_line += nl;
+        }
+        cur ^= 1;
+        rc = drain(slot[cur]); if (rc) break;            // write the previous piece while this one is decided
+    }
+    if (!rc) rc = drain(slot[0]);
+    if (!rc) rc = drain(slot[1]);
+    (void)hipStreamSynchronize(h->work_stream);
+    unsigned long long st[TD_STAT_NSTATS];
+    const bool have_st = hipMemcpy(st, h->d_stats.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess;
+    cleanup();
+#undef SPCHK
+    for (FILE *&f : w.out) { if (f && fclose(f) != 0 && !rc) rc = fail(TD_E_IO, "error writing an output file"); f = nullptr; }
+    if (stats) { stats[0] = w.reads; stats[1] = w.barcut; stats[2] = w.clipped; }
+    if (rc) return rc;
+    if (w.nonascii) return fail(TD_E_NONASCII, "the splitter accepts ASCII FASTQ only (a byte >= 0x80 was found)");
+    if (have_st) return check_device_errors(h, st);
     return TD_OK;
 }
 

@@ -153,6 +153,45 @@ class Engine:
         B.check(self._L.td_count_file(self._h, path.encode(), effective_maxreads(maxreads),
                                       1 if tassel_tagcount else 0))
 
+    # ------------------------------------------------------------------ barcode splitter
+    def set_splitter(self, barcodes, cutsite, fullsite0, fullsite1, entries):
+        """entries[b] = [(adapter beginning to look for at the end of a read, slice index), ...] for
+        barcode b (what build_adapter_tree, tagdigger_fun.py:1208-1249, resolves to)."""
+        begin = [0]
+        seqs, slices = [], []
+        for per_barcode in entries:
+            for seq, sl in per_barcode:
+                seqs.append(seq)
+                slices.append(sl)
+            begin.append(len(seqs))
+        B.check(self._L.td_set_splitter(self._h, _c_strings(barcodes), len(barcodes), cutsite.encode("ascii"),
+                                        fullsite0.encode("ascii"), fullsite1.encode("ascii"),
+                                        (C.c_uint32 * len(begin))(*begin), _c_strings(seqs),
+                                        (C.c_int32 * max(1, len(slices)))(*slices), len(seqs)))
+
+    def split_device(self, d_ptr, nbytes, first_line=0, stream=0):
+        """[(barcode index or -1, findAdapterSeq value), ...] for the sequence lines of a device buffer."""
+        import numpy as np
+        cap = nbytes // 4 + 2
+        d_out = self.dev_alloc(cap * 8)
+        try:
+            terms = C.c_uint64(0)
+            B.check(self._L.td_split_device(self._h, C.c_void_p(d_ptr), nbytes, first_line, C.c_void_p(d_out), cap,
+                                            C.c_void_p(stream) if stream else None, C.byref(terms)))
+            raw = self.d2h(d_out, cap * 8)
+        finally:
+            self.dev_free(d_out)
+        # lines of the buffer: one per terminator, plus an unterminated last line (the caller knows)
+        return np.frombuffer(raw, dtype=np.int32).reshape(-1, 2), terms.value
+
+    def split_file(self, in_path, out_paths, maxreads=500000000):
+        """The record loop of barcodeSplitter (tagdigger_fun.py:1318-1368); returns (reads, with
+        barcode and cut site, clipped on the 3' end)."""
+        st = (C.c_uint64 * 3)()
+        B.check(self._L.td_split_file(self._h, in_path.encode(), _c_strings(out_paths),
+                                      effective_maxreads(maxreads), st))
+        return st[0], st[1], st[2]
+
     def count_lines_device(self, d_ptr, nbytes, stream=0):
         out = C.c_uint64(0)
         B.check(self._L.td_count_lines_device(self._h, C.c_void_p(d_ptr), nbytes,

@@ -545,6 +545,118 @@ def readTags_pyRAD(filename, toKeep=None, binaryOnly=False):
     return [names, seqs]
 
 
+# adapter sets for the barcode splitter: (restriction site with ^ where genomic sequence ends,
+# top-strand adapter after the overhang; [barcode] = reverse complement of the barcode)
+# (reference tagdigger_fun.py:27-47)
+_P5_BARCODED = '[barcode]AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGTAGATCTCGGTGGTCGCCGTATCATT'
+_HALL_COMMON = 'CTCAGGCATCACTCGATTCCTCCGTCGTATGCCGTCTTCTGCTTG'
+_CLARK_COMMON = 'CTCAGGCATCACTCGATTCCTATCTCGTATGCCGTCTTCTGCTTG'
+adapters = {'PstI-MspI-Hall': [('CCG^G', _HALL_COMMON), ('CTGCA^G', _P5_BARCODED)],
+            'NsiI-MspI-Hall': [('CCG^G', _HALL_COMMON), ('ATGCA^T', _P5_BARCODED)],
+            'PstI-MspI-Clark': [('CCG^G', _CLARK_COMMON), ('CTGCA^G', _P5_BARCODED)],
+            'NsiI-MspI-Clark': [('CCG^G', _CLARK_COMMON), ('ATGCA^T', _P5_BARCODED)],
+            'PstI-MspI-Poland': [('CCG^G', 'AGATCGGAAGAGCGGTTCAGCAGGAATGCCGAGACCGATCTCGTATGCCGTCTTCTGCTTG'),
+                                 ('CTGCA^G', _P5_BARCODED)]}
+
+
+def _trie_survivors(sequences):
+    """Which of `sequences` (ACGT strings) a prefix trie built in this order would hold, as
+    (sequence, position) pairs -- the rules of tree_one_level (reference tagdigger_fun.py:71-86):
+    among sequences sharing a path, if the FIRST one ends there it is kept and the others
+    (duplicates, extensions) are dropped silently; if a LATER one ends inside the first, that is an
+    AssertionError naming its position.  Children are visited in A, C, G, T order."""
+    kept = []
+
+    def walk(group, depth):
+        first = group[0]
+        if len(first[0]) == depth:
+            kept.append(first)
+            return
+        branches = ([], [], [], [])
+        for item in group:
+            assert len(item[0]) > depth, \
+                "Problematic sequence: {}.  Likely due to overlapping tags.".format(item[1])
+            branches["ACGT".find(item[0][depth])].append(item)
+        for branch in branches:
+            if branch:
+                walk(branch, depth + 1)
+
+    if sequences:
+        walk([(s, k) for k, s in enumerate(sequences)], 0)
+    return kept
+
+
+def _adapter_ends(adapter, barcodes):
+    """For every barcode, the adapter beginnings the splitter looks for at the END of a read, each
+    with the (negative) index the read is then sliced with: what build_adapter_tree (reference
+    tagdigger_fun.py:1208-1249) builds as a reversed-sequence trie, resolved to a flat list.
+    Every beginning keeps at least one base beyond the remains of the restriction site."""
+    def beginnings(site, tail):
+        remains = site.find('^')
+        full = site[:remains] + tail
+        # longest first, down to one base past the site's remains; reversed, as the trie stores them
+        rev = full[::-1]
+        cut = [rev[i:] for i in range(len(rev) - remains)]
+        return remains, cut, [remains - len(c) for c in cut]
+
+    remains0, common, common_idx = beginnings(adapter[0][0], adapter[0][1])
+    out = []
+    for bc in barcodes:
+        remains1, rare, rare_idx = beginnings(adapter[1][0], adapter[1][1].replace('[barcode]', reverseComplement(bc)))
+        everything, indices = common + rare, common_idx + rare_idx
+        try:
+            kept = _trie_survivors(everything)
+        except AssertionError:
+            # some beginning is the end of another: keep the shorter of each such (sorted-adjacent) pair
+            print("Some overlap of adapter sequence for barcode {}.".format(bc))
+            everything = sorted(everything)
+            drop = set()
+            for k in range(len(everything) - 1):
+                if everything[k + 1].startswith(everything[k]):
+                    drop.add(k + 1)
+                    print("Won't search for {0} at end of sequence since {1} is already being searched for.".format(
+                        everything[k + 1][::-1], everything[k][::-1]))
+            everything = [x for k, x in enumerate(everything) if k not in drop]
+            indices = [remains1 - len(x) for x in everything]          # (the rare cutter's offset for all, as :1246)
+            kept = _trie_survivors(everything)
+        out.append([(seq[::-1], indices[pos]) for seq, pos in kept])
+    return out
+
+
+def barcodeSplitter(inputFile, barcodes, outputFiles, cutsite='TGCAG', adapter=adapters["PstI-MspI-Hall"],
+                    maxreads=500000000, device=0):
+    """Split one FASTQ file into one file per barcode, removing the barcode and, on the 3' end,
+    anything from the first full restriction site or from an adapter that runs off the read
+    (reference tagdigger_fun.py:1286-1368).  The per-read decisions are made on the GPU.
+    No progress lines are printed (the reference prints one every 50 000 reads)."""
+    assert set(cutsite) <= set('ACGT'), "Only ACGT cut sites allowed."
+    assert all([set(bc) <= set('ACGT') for bc in barcodes]), "Found non-ACGT barcodes."
+    assert len(adapter) == 2
+    assert all([set(a[0]) <= set('ACGT^') for a in adapter])
+    assert set(adapter[0][1]) <= set('ACGT')
+    assert set(adapter[1][1]) <= set('[barcode]ACGT')
+
+    print("Building indices for rapid searching...")
+    entries = _adapter_ends(adapter, barcodes)
+    eng = default_engine(device)
+    eng.set_splitter(barcodes, cutsite, adapter[0][0].replace('^', ''), adapter[1][0].replace('^', ''), entries)
+    print("Done with indexing setup.")
+    print(inputFile)
+
+    # the same failures as the reference's open() calls, in its order (:1318-1327)
+    if inputFile[-2:].lower() == 'gz':
+        with open(inputFile, 'rb') as fh:
+            head = fh.read(2)
+        if head and head != b'\x1f\x8b':
+            raise _gzip.BadGzipFile("Not a gzipped file (%r)" % head)
+    else:
+        open(inputFile, 'r').close()
+    for name in outputFiles:
+        open(name, mode='w').close()
+    eng.split_file(inputFile, outputFiles, maxreads)
+    return None
+
+
 def sanitizeTags(taglist):
     """Drop every marker one of whose tags is a prefix of (or equal to) another tag, so that the
     tag set handed to find_tags_fastq is prefix-free (reference tagdigger_fun.py:1030-1058).

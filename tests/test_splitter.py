@@ -1,0 +1,217 @@
+"""Barcode splitter: the oracle's restatement and the product's host logic against
+fixtures captured from the real reference (tests/golden/make_splitter_golden.py), then the GPU
+path -- through the C-ABI -- against both."""
+import base64
+import contextlib
+import gzip
+import io
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import tagdigger_oracle as po
+
+G = load_golden("splitter.json")
+
+
+def adapter_of(name):
+    return [tuple(x) for x in G["adapters"][name]]
+
+
+# ------------------------------------------------------------------ CPU: oracle vs reference
+@pytest.mark.parametrize("case", G["find"], ids=lambda c: "%s-%d" % (c["adapter"], c["barcode"]))
+def test_oracle_find_adapter_seq(case):
+    ad = adapter_of(case["adapter"])
+    log = []
+    trees = po.build_adapter_tree(ad, case["barcodes"], log)
+    assert "".join(x + "\n" for x in log) == case["stdout"]
+    s0, s1 = ad[0][0].replace("^", ""), ad[1][0].replace("^", "")
+    start = len(case["barcodes"][case["barcode"]]) + len(case["cutsite"])
+    got = [po.find_adapter_seq(r, trees[case["barcode"]], s0, s1, start) for r in case["reads"]]
+    assert got == case["values"]
+
+
+def good_split_cases():
+    return [c for c in G["split"] if "raises" not in c]
+
+
+@pytest.mark.parametrize("k", range(len(good_split_cases())))
+def test_oracle_splitter_outputs(k):
+    c = good_split_cases()[k]
+    outs, _ = po.barcode_splitter_bytes(base64.b64decode(c["fastq_b64"]), c["barcodes"], c["cutsite"], adapter_of(c["adapter"]),
+                                        maxreads=c["maxreads"] if c["maxreads"] is not None else 500000000)
+    assert [base64.b64encode(o).decode() for o in outs] == c["outputs_b64"]
+
+
+# ------------------------------------------------------------------ CPU: product host logic
+@pytest.mark.parametrize("case", G["find"], ids=lambda c: "%s-%d" % (c["adapter"], c["barcode"]))
+def test_adapter_ends_match_the_trie(case):
+    """The flat list the product hands to the GPU decides every read end like the oracle's trie,
+    and the messages printed while resolving it are the reference's."""
+    from tagdigger_amd import tagdigger_fun as tf
+    ad = adapter_of(case["adapter"])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ends = tf._adapter_ends(ad, case["barcodes"])
+    assert buf.getvalue() == case["stdout"]
+    trees = po.build_adapter_tree(ad, case["barcodes"])
+    rng = random.Random(5)
+    for b, bc in enumerate(case["barcodes"]):
+        reads = list(case["reads"])
+        for seq, _ in ends[b]:                       # every stored beginning, alone and behind random bases
+            reads += [seq, "ACGT" * 3 + seq, seq[1:], seq + "A"]
+        reads += ["".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 30))) for _ in range(200)]
+        for r in reads:
+            want = po.sequence_index_lookup(r[::-1], trees[b][0])
+            want = 999 if want == -1 else trees[b][1][want]
+            hits = [sl for seq, sl in ends[b] if len(seq) <= len(r) and r.endswith(seq)]
+            assert len(hits) <= 1
+            assert (hits[0] if hits else 999) == want, (bc, r)
+
+
+def test_trie_survivors_rules():
+    from tagdigger_amd import tagdigger_fun as tf
+    assert tf._trie_survivors(["AC", "AC", "ACG", "T"]) == [("AC", 0), ("T", 3)]
+    with pytest.raises(AssertionError, match="Problematic sequence: 1"):
+        tf._trie_survivors(["ACG", "AC"])
+    assert tf._trie_survivors([]) == []
+
+
+# ------------------------------------------------------------------ GPU
+def run_product(tmp_path, c):
+    from tagdigger_amd import tagdigger_fun as tf
+    old = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        name = "in.fq.gz" if c["gz"] else "in.fq"
+        raw = base64.b64decode(c["fastq_b64"])
+        with open(name, "wb") as fh:
+            fh.write(gzip.compress(raw, mtime=0) if c["gz"] else raw)
+        outs = ["out%d.fq" % i for i in range(len(c["barcodes"]))]
+        kw = {"cutsite": c["cutsite"], "adapter": adapter_of(c["adapter"])}
+        if c["maxreads"] is not None:
+            kw["maxreads"] = c["maxreads"]
+        buf = io.StringIO()
+        rec = {}
+        try:
+            with contextlib.redirect_stdout(buf):
+                tf.barcodeSplitter(name, c["barcodes"], outs, **kw)
+        except Exception as e:
+            rec["raises"] = type(e).__name__
+            rec["message"] = str(e)
+        rec["stdout"] = buf.getvalue()
+        rec["outputs_b64"] = [base64.b64encode(open(o, "rb").read()).decode() if os.path.exists(o) else None for o in outs]
+        return rec
+    finally:
+        os.chdir(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(len(G["split"])))
+def test_gpu_splitter_matches_reference(k, tmp_path):
+    c = G["split"][k]
+    got = run_product(tmp_path, c)
+    assert got.get("raises") == c.get("raises")
+    if "raises" in c:
+        assert got["message"] == c["message"]
+    assert got["stdout"] == c["stdout"]
+    assert got["outputs_b64"] == c["outputs_b64"]
+
+
+def synth_reads(rng, barcodes, cutsite, ad, n, first_line_shift=0):
+    """FASTQ bytes with every kind of read end, plus the oracle's decisions."""
+    s0, s1 = ad[0][0].replace("^", ""), ad[1][0].replace("^", "")
+    recs = []
+    for i in range(n):
+        bc = rng.choice(barcodes)
+        body = "".join(rng.choice("ACGT") for _ in range(rng.randrange(20, 120)))
+        kind = rng.randrange(8)
+        if kind == 0:
+            seq = "".join(rng.choice("ACGTN") for _ in range(rng.randrange(0, 80)))
+        elif kind == 1:
+            seq = bc + cutsite + body + s0 + body[:7]
+        elif kind == 2:
+            seq = bc + cutsite + body + s1 + body[:5]
+        elif kind == 3:
+            full = ad[0][0][:ad[0][0].find("^")] + ad[0][1]
+            seq = bc + cutsite + body + full[:rng.randrange(1, len(full) + 1)]
+        elif kind == 4:
+            full = ad[1][0][:ad[1][0].find("^")] + ad[1][1].replace("[barcode]", po.reverse_complement(bc))
+            seq = bc + cutsite + body + full[:rng.randrange(1, len(full) + 1)]
+        elif kind == 5:
+            seq = (bc + cutsite + body).lower()
+        else:
+            seq = bc + cutsite + body
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, seq, "I" * len(seq)))
+    return ("\n" * first_line_shift + "".join(recs)).encode("ascii")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,adapter", [(1, "PstI-MspI-Hall"), (2, "NsiI-MspI-Clark"), (3, "repeat")])
+def test_gpu_split_device_decisions(seed, adapter):
+    """Several tiles of reads: every decision equals the oracle's, for any first_line."""
+    import tagdigger_amd
+    from tagdigger_amd import tagdigger_fun as tf
+    rng = random.Random(seed)
+    barcodes = ["AACG", "TTGACC", "CGT", "GATTACAG", "CCA"]
+    cutsite = "TGCAT" if adapter.startswith("Nsi") else "TGCAG"
+    ad = adapter_of(adapter)
+    data = synth_reads(rng, barcodes, cutsite, ad, 4000)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ends = tf._adapter_ends(ad, barcodes)
+    eng = tagdigger_amd.Engine(0)
+    try:
+        eng.set_splitter(barcodes, cutsite, ad[0][0].replace("^", ""), ad[1][0].replace("^", ""), ends)
+        d = eng.dev_alloc(len(data))
+        try:
+            eng.h2d(d, data)
+            for first_line in (0, 4, 8):
+                res, terms = eng.split_device(d, len(data), first_line=first_line)
+                assert terms == data.count(b"\n")
+                want = []
+                po.barcode_splitter_bytes(data, barcodes, cutsite, ad, decisions=want)
+                got = [(int(a), int(b)) for a, b in res[:len(want)]]
+                assert got == [(b, 999 if b < 0 else c) for b, c in want]
+            # a buffer that starts on a sequence line (first_line 1): same reads, same decisions
+            cut = data.index(b"\n") + 1
+            d2 = eng.dev_alloc(len(data))
+            try:
+                eng.h2d(d2, data[cut:])
+                res, _ = eng.split_device(d2, len(data) - cut, first_line=1)
+                want = []
+                po.barcode_splitter_bytes(data, barcodes, cutsite, ad, decisions=want)
+                got = [(int(a), int(b)) for a, b in res[:len(want)]]
+                assert got == [(b, 999 if b < 0 else c) for b, c in want]
+            finally:
+                eng.dev_free(d2)
+        finally:
+            eng.dev_free(d)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_split_file_large(tmp_path):
+    """More than one 32 MiB piece through td_split_file, CRLF line ends: files equal the oracle's."""
+    import tagdigger_amd
+    from tagdigger_amd import tagdigger_fun as tf
+    rng = random.Random(11)
+    barcodes = ["AACG", "TTGACC", "CGT", "GATTACAG"]
+    ad = adapter_of("PstI-MspI-Hall")
+    block = synth_reads(rng, barcodes, "TGCAG", ad, 3000).replace(b"\n", b"\r\n")
+    data = block * (((40 << 20) // len(block)) + 1)
+    src = tmp_path / "big.fq"
+    src.write_bytes(data)
+    outs = [str(tmp_path / ("o%d.fq" % i)) for i in range(len(barcodes))]
+    with contextlib.redirect_stdout(io.StringIO()):
+        tf.barcodeSplitter(str(src), barcodes, outs, cutsite="TGCAG", adapter=ad)
+    want, stats = po.barcode_splitter_bytes(block, barcodes, "TGCAG", ad)
+    reps = len(data) // len(block)
+    for o, w in zip(outs, want):
+        got = open(o, "rb").read()
+        assert len(got) == len(w) * reps
+        assert got[:len(w)] == w and got[-len(w):] == w
+        assert got == w * reps
