@@ -130,7 +130,8 @@ int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, co
 
 /* Decisions for a buffer in device memory: d_out[2r], d_out[2r+1] = barcode index (-1: none) and
  * findAdapterSeq's return value (999: nothing to clip) for the buffer's r-th sequence line (lines
- * whose global index first_line + k is 1 mod 4).  out_capacity (in results) >= nbytes / 4 + 2.
+ * whose global index first_line + k is 1 mod 4).  out_capacity (in results) must be at least
+ * (terminators + 1) / 4 + 2, terminators as td_count_lines_device reports them.
  * Synchronous; *n_terminators (optional) receives the buffer's line terminators. */
 int td_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line,
                     int32_t *d_out, uint64_t out_capacity, void *stream, uint64_t *n_terminators);

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -1072,8 +1073,8 @@ int td_synth_fill_device(td_handle *h, const void *params, uint64_t first_read, 
 // every read, the host writes the clipped records.
 namespace {
 
-// async part of td_split_device: line prefix + k_split on `s`; out must hold one int2 per sequence line
-int launch_split(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, int2 *d_out, hipStream_t s) {
+// line terminators before the end of every 16 KB tile -> d_state, their total -> d_cursor[0] (async on `s`)
+int launch_split_prefix(td_handle *h, const void *d_fastq, uint64_t nbytes, hipStream_t s) {
     const uint64_t tile = 16 * 1024;
     const uint64_t nt = (nbytes + tile - 1) / tile;
     if (nt > 0x7FFFFFFFull) return fail(TD_E_LIMIT, "buffer too large for one launch; split it");
@@ -1082,6 +1083,15 @@ int launch_split(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     const uint32_t g = (uint32_t)std::min<uint64_t>(nt, (uint64_t)h->num_cu * 8);
     hipLaunchKernelGGL((tdk::k_count_lines<4>), dim3(g), dim3(tdk::BLOCK), 0, s, (const uint8_t *)d_fastq, nbytes, (uint32_t)nt, h->d_tilecounts.p);
     hipLaunchKernelGGL(tdk::k_scan_tiles, dim3(1), dim3(1024), 0, s, h->d_tilecounts.p, (uint32_t)nt, h->d_state.p, h->d_cursor.p);
+    HIPCHK(hipGetLastError());
+    return TD_OK;
+}
+
+// k_split on `s` (after launch_split_prefix); out must hold one int2 per sequence line of the buffer
+int launch_split(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, int2 *d_out, hipStream_t s) {
+    const uint64_t tile = 16 * 1024;
+    const uint64_t nt = (nbytes + tile - 1) / tile;
+    const uint32_t g = (uint32_t)std::min<uint64_t>(nt, (uint64_t)h->num_cu * 8);
     tdk::SplitParams sp{};
     sp.buf = (const uint8_t *)d_fastq; sp.nbytes = nbytes; sp.first_line = first_line;
     sp.prefix = h->d_state.p; sp.ntiles = (uint32_t)nt;
@@ -1096,8 +1106,8 @@ int launch_split(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     return TD_OK;
 }
 
-// upper bound of the sequence lines of a buffer: a line holds at least its terminator
-inline uint64_t max_seq_lines(uint64_t nbytes) { return nbytes / 4 + 2; }
+// upper bound of the sequence lines among `lines` consecutive lines
+inline uint64_t max_seq_lines(uint64_t lines) { return lines / 4 + 2; }
 
 inline bool host_blank(uint8_t b) { return b == 0x20 || b == 0x09 || b == 0x0B || b == 0x0C || (b >= 0x1C && b <= 0x1F); }
 
@@ -1106,10 +1116,12 @@ inline bool host_blank(uint8_t b) { return b == 0x20 || b == 0x09 || b == 0x0B |
 struct SplitWriter {
     const std::vector<std::string> &barcodes;
     std::vector<FILE *> out;
+    std::vector<std::string> pend;            // per output file: bytes not yet handed to stdio
+    static constexpr size_t FLUSH_AT = 64 << 10;    // (x several hundred files: keep the buffers cache-resident)
     uint64_t lineindex = 0, reads = 0, barcut = 0, clipped = 0, max_reads = 0;
-    std::string comment1, sequence, comment2;
+    std::string comment1, sequence, comment2, quality;
     int cur_bar = -1, cur_slice = 999;
-    bool stop = false, nonascii = false;
+    bool stop = false, nonascii = false, io_error = false;
 
     explicit SplitWriter(const std::vector<std::string> &b) : barcodes(b) {}
     ~SplitWriter() { for (FILE *f : out) if (f) fclose(f); }
@@ -1119,15 +1131,21 @@ struct SplitWriter {
         while (a < b && host_blank(p[a])) a++;
         while (b > a && host_blank(p[b - 1])) b--;
         dst.assign((const char *)p + a, b - a);
-        if (upper) for (char &c : dst) if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+        if (upper) for (char &c : dst) c = (char)(c - (((unsigned)(c - 'a') < 26u) << 5));     // (branch-free: vectorises)
     }
     // s[a:b] with Python's rules for a >= 0 and any b
-    static void put_slice(FILE *f, const std::string &s, long a, long b) {
+    static void put_slice(std::string &o, const std::string &s, long a, long b) {
         const long n = (long)s.size();
         if (b < 0) { b += n; if (b < 0) b = 0; }
         if (b > n) b = n;
-        if (a < b) fwrite(s.data() + a, 1, (size_t)(b - a), f);
-        fputc('\n', f);
+        if (a < b) o.append(s.data() + a, (size_t)(b - a));
+        o.push_back('\n');
+    }
+    bool flush(size_t k) {
+        std::string &o = pend[k];
+        const bool ok = o.empty() || fwrite(o.data(), 1, o.size(), out[k]) == o.size();
+        o.clear();
+        return ok;
     }
     // one line (terminator excluded); `res` advances over the piece's sequence-line results
     void line(const uint8_t *p, size_t n, const int2 *&res) {
@@ -1138,19 +1156,19 @@ struct SplitWriter {
         default: {
             reads++;
             if (cur_bar > -1) {
-                std::string quality;
                 stripped(p, n, quality, false);
                 barcut++;
                 const std::string &bc = barcodes[(size_t)cur_bar];
                 const long slice1 = (long)bc.size();
                 long slice2 = cur_slice;
                 if (slice2 == 999) slice2 = (long)sequence.size(); else clipped++;
-                FILE *f = out[(size_t)cur_bar];
-                fwrite(comment1.data(), 1, comment1.size(), f); fwrite(bc.data(), 1, bc.size(), f); fputc('\n', f);
-                put_slice(f, sequence, slice1, slice2);
-                if (comment2 == "+") { fputc('+', f); fputc('\n', f); }
-                else { fwrite(comment1.data(), 1, comment1.size(), f); fwrite(bc.data(), 1, bc.size(), f); fputc('\n', f); }
-                put_slice(f, quality, slice1, slice2);
+                std::string &o = pend[(size_t)cur_bar];
+                o.append(comment1); o.append(bc); o.push_back('\n');
+                put_slice(o, sequence, slice1, slice2);
+                if (comment2 == "+") o.append("+\n");
+                else { o.append(comment1); o.append(bc); o.push_back('\n'); }
+                put_slice(o, quality, slice1, slice2);
+                if (o.size() >= FLUSH_AT && !flush((size_t)cur_bar)) io_error = true;
             }
             if (reads >= max_reads) stop = true;
         } }
@@ -1158,10 +1176,22 @@ struct SplitWriter {
     }
     // all lines of a piece that ends at a line end (or at the end of the file)
     void piece(const uint8_t *p, size_t n, const int2 *res) {
+        uint8_t any = 0;
+        for (size_t i = 0; i < n; i++) any |= p[i];                      // (vectorises)
+        if (any & 0x80) nonascii = true;
+        if (!memchr(p, '\r', n)) {                                       // the usual file: '\n' only
+            size_t start = 0;
+            while (start < n && !stop) {
+                const uint8_t *nl = (const uint8_t *)memchr(p + start, '\n', n - start);
+                const size_t end = nl ? (size_t)(nl - p) : n;
+                line(p + start, end - start, res);
+                start = end + 1;
+            }
+            return;
+        }
         size_t start = 0, i = 0;
         while (i < n && !stop) {
             const uint8_t c = p[i];
-            if (c >= 0x80) nonascii = true;
             if (c == '\n') { line(p + start, i - start, res); start = ++i; }
             else if (c == '\r') { line(p + start, i - start, res); i++; if (i < n && p[i] == '\n') i++; start = i; }
             else i++;
@@ -1239,13 +1269,15 @@ int td_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t
     HIPCHK(hipSetDevice(h->device));
     if (n_terminators) *n_terminators = 0;
     if (nbytes == 0) return TD_OK;
-    if (out_capacity < max_seq_lines(nbytes)) return fail(TD_E_ARG, "output must hold nbytes / 4 + 2 results");
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_split(h, d_fastq, nbytes, first_line, (int2 *)d_out, s); if (rc) return rc;
+    int rc = launch_split_prefix(h, d_fastq, nbytes, s); if (rc) return rc;
     unsigned long long v = 0;
     HIPCHK(hipMemcpyAsync(&v, h->d_cursor.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (n_terminators) *n_terminators = v;
+    if (out_capacity < max_seq_lines(v + 1)) return fail(TD_E_ARG, "output must hold (terminators + 1) / 4 + 2 results");
+    rc = launch_split(h, d_fastq, nbytes, first_line, (int2 *)d_out, s); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(s));
     unsigned long long st[TD_STAT_NSTATS];
     HIPCHK(hipMemcpy(st, h->d_stats.p, sizeof(st), hipMemcpyDeviceToHost));
     return check_device_errors(h, st);
@@ -1287,31 +1319,49 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
     for (auto &sl : slot) {
         SPCHK(hipHostMalloc((void **)&sl.pin, cap, hipHostMallocDefault));
         SPCHK(hipMalloc((void **)&sl.dev, cap));
-        SPCHK(hipMalloc((void **)&sl.res_dev, max_seq_lines(cap) * sizeof(int2)));
+        SPCHK(hipMalloc((void **)&sl.res_dev, max_seq_lines(cap) * sizeof(int2)));          // (a line holds at least its terminator)
         SPCHK(hipHostMalloc((void **)&sl.res_pin, max_seq_lines(cap) * sizeof(int2), hipHostMallocDefault));
         SPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     for (uint32_t b = 0; b < h->sp_barcodes.size(); b++) {
         FILE *f = fopen(out_paths[b], "wb");
         if (!f) { cleanup(); return fail(TD_E_IO, std::string("cannot open ") + out_paths[b] + " for writing"); }
-        setvbuf(f, nullptr, _IOFBF, 1 << 20);
+        setvbuf(f, nullptr, _IONBF, 0);          // (SplitWriter keeps its own buffer per file)
         w.out.push_back(f);
     }
+    w.pend.assign(w.out.size(), std::string());
     std::vector<uint8_t> carry;
     bool eof = false;
-    uint64_t gpu_line = 0;            // global index of the next piece's first line (what the GPU is told)
-    int cur = 0;
-    auto drain = [&](Slot &sl) -> int {      // wait for the slot's decisions, then write its records
+    // TAGDIG_SPLIT_TIMING=1: where the wall time of this call went, on stderr
+    const bool timing = getenv("TAGDIG_SPLIT_TIMING") != nullptr;
+    double t_read = 0, t_wait = 0, t_write = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto hipfail = [&](const char *what, hipError_t e) { return fail(TD_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
+    unsigned long long *terms_pin = nullptr;          // the piece's terminator count, read back before k_split
+    {
+        hipError_t e = hipHostMalloc((void **)&terms_pin, 16, hipHostMallocDefault);
+        if (e != hipSuccess) { cleanup(); return hipfail("hipHostMalloc", e); }
+    }
+    // wait for the slot's decisions, then write its records (the host's share of the loop)
+    auto write_out = [&](Slot &sl) -> int {
         if (!sl.pending) return TD_OK;
+        const double t0 = now();
         hipError_t e = hipEventSynchronize(sl.done);
-        if (e != hipSuccess) return fail(TD_E_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+        if (e != hipSuccess) return hipfail("hipEventSynchronize", e);
         sl.pending = false;
+        const double t1 = now();
         if (!w.stop) w.piece(sl.pin, sl.n, sl.res_pin);
+        t_wait += t1 - t0; t_write += now() - t1;
         return TD_OK;
     };
-    while (!eof && !w.stop) {
+    // Per piece: read it, start its copy and its line prefix on the GPU, write the PREVIOUS piece's
+    // records meanwhile (that also tells the exact line index this piece starts at), then have the
+    // GPU decide this piece's reads (a millisecond) and fetch the decisions.
+    int cur = 0;
+    Slot *prev = nullptr;
+    while (!eof && !w.stop && !rc) {
         Slot &sl = slot[cur];
-        rc = drain(sl); if (rc) break;                   // (its previous piece, two iterations ago)
+        const double tr0 = now();
         size_t have = carry.size();
         if (have) memcpy(sl.pin, carry.data(), have);
         carry.clear();
@@ -1329,37 +1379,44 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
             carry.assign(sl.pin + cut, sl.pin + have);
         }
         sl.n = cut;
+        t_read += now() - tr0;
         if (cut) {
-            // line count of the piece on the host (cheap next to the writing) keeps gpu_line exact
             hipError_t e = hipMemcpyAsync(sl.dev, sl.pin, cut, hipMemcpyHostToDevice, h->work_stream);
-            if (e != hipSuccess) { rc = fail(TD_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e)); break; }
-            rc = launch_split(h, sl.dev, cut, gpu_line, sl.res_dev, h->work_stream); if (rc) break;
-            e = hipMemcpyAsync(sl.res_pin, sl.res_dev, max_seq_lines(cut) * sizeof(int2), hipMemcpyDeviceToHost, h->work_stream);
-            if (e != hipSuccess) { rc = fail(TD_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e)); break; }
+            if (e != hipSuccess) { rc = hipfail("hipMemcpyAsync", e); break; }
+            rc = launch_split_prefix(h, sl.dev, cut, h->work_stream); if (rc) break;
+            e = hipMemcpyAsync(terms_pin, h->d_cursor.p, 8, hipMemcpyDeviceToHost, h->work_stream);
+            if (e != hipSuccess) { rc = hipfail("hipMemcpyAsync", e); break; }
+        }
+        if (prev) { rc = write_out(*prev); if (rc) break; }
+        prev = nullptr;
+        if (cut && !w.stop) {
+            const double t0 = now();
+            hipError_t e = hipStreamSynchronize(h->work_stream);          // (copy + prefix ran under the writing)
+            if (e != hipSuccess) { rc = hipfail("hipStreamSynchronize", e); break; }
+            t_wait += now() - t0;
+            const uint64_t lines = *terms_pin + 1;                        // (+1: an unterminated last line, at most)
+            rc = launch_split(h, sl.dev, cut, w.lineindex, sl.res_dev, h->work_stream); if (rc) break;
+            e = hipMemcpyAsync(sl.res_pin, sl.res_dev, max_seq_lines(lines) * sizeof(int2), hipMemcpyDeviceToHost, h->work_stream);
+            if (e != hipSuccess) { rc = hipfail("hipMemcpyAsync", e); break; }
             (void)hipEventRecord(sl.done, h->work_stream);
             sl.pending = true;
-            // lines in this piece = its terminators (+1 for an unterminated last line at the end of the file)
-            uint64_t nl = 0;
-            for (size_t i = 0; i < cut; i++) {
-                const uint8_t c = sl.pin[i];
-                if (c == '\n') nl++;
-                else if (c == '\r' && !(i + 1 < cut && sl.pin[i + 1] == '\n')) nl++;
-            }
-            if (cut && sl.pin[cut - 1] != '\n' && sl.pin[cut - 1] != '\r') nl++;
-            gpu_line += nl;
+            prev = &sl;
         }
         cur ^= 1;
-        rc = drain(slot[cur]); if (rc) break;            // write the previous piece while this one is decided
     }
-    if (!rc) rc = drain(slot[0]);
-    if (!rc) rc = drain(slot[1]);
+    if (!rc && prev) rc = write_out(*prev);
+    for (auto &sl : slot) if (sl.pending) { (void)hipEventSynchronize(sl.done); sl.pending = false; }
+    if (terms_pin) (void)hipHostFree(terms_pin);
     (void)hipStreamSynchronize(h->work_stream);
     unsigned long long st[TD_STAT_NSTATS];
     const bool have_st = hipMemcpy(st, h->d_stats.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess;
     cleanup();
 #undef SPCHK
-    for (FILE *&f : w.out) { if (f && fclose(f) != 0 && !rc) rc = fail(TD_E_IO, "error writing an output file"); f = nullptr; }
+    for (size_t k = 0; k < w.out.size(); k++) if (!w.flush(k)) w.io_error = true;
+    for (FILE *&f : w.out) { if (f && fclose(f) != 0) w.io_error = true; f = nullptr; }
+    if (w.io_error && !rc) rc = fail(TD_E_IO, "error writing an output file");
     if (stats) { stats[0] = w.reads; stats[1] = w.barcut; stats[2] = w.clipped; }
+    if (timing) fprintf(stderr, "td_split_file: read %.3f s, waiting for the GPU %.3f s, writing %.3f s\n", t_read, t_wait, t_write);
     if (rc) return rc;
     if (w.nonascii) return fail(TD_E_NONASCII, "the splitter accepts ASCII FASTQ only (a byte >= 0x80 was found)");
     if (have_st) return check_device_errors(h, st);

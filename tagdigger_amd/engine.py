@@ -172,7 +172,7 @@ class Engine:
     def split_device(self, d_ptr, nbytes, first_line=0, stream=0):
         """[(barcode index or -1, findAdapterSeq value), ...] for the sequence lines of a device buffer."""
         import numpy as np
-        cap = nbytes // 4 + 2
+        cap = (self.count_lines_device(d_ptr, nbytes, stream) + 1) // 4 + 2
         d_out = self.dev_alloc(cap * 8)
         try:
             terms = C.c_uint64(0)

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Throughput of the barcode splitter on the canonical synthetic stream:
+decisions only (k_count_lines + k_scan_tiles + k_split on a buffer resident in HBM) and end to end
+from a file (td_split_file: read, H2D, decide, D2H, host writes the clipped records), next to the
+oracle's pure-Python restatement on a sample."""
+import contextlib, io, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import tagdigger_amd
+from tagdigger_amd import tagdigger_fun as tf
+from tagdigger_amd.synth import SynthConfig
+
+reads = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+cfg = SynthConfig(nreads=reads, nbar=384, nmarkers=50_000, seed=3)
+ad = tf.adapters["PstI-MspI-Hall"]
+eng = tagdigger_amd.Engine(0)
+nb = cfg.nbytes()
+d = eng.dev_alloc(nb)
+cfg.fill_device(eng, d, 0, reads)
+with contextlib.redirect_stdout(io.StringIO()):
+    ends = tf._adapter_ends(ad, cfg.barcodes)
+eng.set_splitter(cfg.barcodes, cfg.cutsite, "CCGG", "CTGCAG", ends)
+eng.split_device(d, nb)                                   # warm
+t0 = time.perf_counter(); res, terms = eng.split_device(d, nb); dt = time.perf_counter() - t0
+eng.set_option("timing", 0)
+hit = int((res[:reads, 0] >= 0).sum()); clip = int(((res[:reads, 0] >= 0) & (res[:reads, 1] != 999)).sum())
+print("decisions, HBM-resident : %7.1f Mreads/s  %6.1f GB/s  (%d reads, %d with barcode+site, %d clipped; includes the D2H of 8 B per read)"
+      % (reads / dt / 1e6, nb / dt / 1e9, reads, hit, clip))
+tmp = os.environ.get("TMPDIR", "/tmp")
+src = os.path.join(tmp, "split_in.fq")
+n_file = min(reads, 8_000_000)
+open(src, "wb").write(eng.d2h(d, n_file * cfg.record_bytes))
+eng.dev_free(d)
+outs = [os.path.join(tmp, "split_out_%03d.fq" % i) for i in range(len(cfg.barcodes))]
+t0 = time.perf_counter(); st = eng.split_file(src, outs); dt = time.perf_counter() - t0
+outbytes = sum(os.path.getsize(o) for o in outs)
+print("file -> %d files        : %7.1f Mreads/s  %6.2f GB/s in, %.2f GB written  (reads %d, barcode+site %d, clipped %d)"
+      % (len(outs), n_file / dt / 1e6, n_file * cfg.record_bytes / dt / 1e9, outbytes / 1e9, *st))
+from oracle import tagdigger_oracle as po
+sample = open(src, "rb").read(100_000 * cfg.record_bytes)
+t0 = time.perf_counter(); po.barcode_splitter_bytes(sample, cfg.barcodes, cfg.cutsite, ad); dt = time.perf_counter() - t0
+print("python restatement      : %7.3f Mreads/s  (100 k reads, one core, index build included)" % (0.1 / dt))
+for o in outs: os.remove(o)
+os.remove(src)
