@@ -153,8 +153,22 @@ def main():
     cases.append(run_splitter(b"@a\nAACGTGCAGTT\n+\nIIIIIIIIIII\n", ["AACG", "AACGT"], "TGCAG", "PstI-MspI-Hall"))     # overlapping barcode+site
     cases.append(run_splitter(b"@a\nAACGTGCAGTT\n+\nIIIIIIIIIII\n", ["AACG", "AXG"], "TGCAG", "PstI-MspI-Hall"))       # bad barcode
     cases.append(run_splitter(b"@a\nAACGTGCAGTT\n+\nIIIIIIIIIII\n", ["AACG"], "TGCWG", "PstI-MspI-Hall"))              # bad cut site
+    # ---- the reference's barcode_splitter_script.py end to end (key file with Input/Barcode/Output columns)
+    import subprocess
+    fq = random_fastq(rng, bcs, "TGCAG", "PstI-MspI-Hall", 150, "lf")
+    key = "Input File,Barcode,Output File\n" + "".join("lane1.fq,%s,s%d.fq\n" % (b, i) for i, b in enumerate(bcs))
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "lane1.fq"), "wb").write(fq)
+        open(os.path.join(d, "key.csv"), "w").write(key)
+        argv = ["-b", "key.csv", "-a", "PstI-MspI-Hall"]
+        p = subprocess.run([sys.executable, os.path.join(REF, "barcode_splitter_script.py")] + argv, cwd=d, capture_output=True,
+                           text=True, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+        assert p.returncode == 0, p.stderr
+        cli = {"argv": argv, "key_csv": key, "fastq_b64": base64.b64encode(fq).decode(), "stdout": p.stdout,
+               "outputs_b64": {"s%d.fq" % i: base64.b64encode(open(os.path.join(d, "s%d.fq" % i), "rb").read()).decode()
+                               for i in range(len(bcs))}}
     with open(os.path.join(HERE, "splitter.json"), "w") as fh:
-        json.dump({"adapters": ADAPTERS, "find": find_cases(), "split": cases}, fh, separators=(",", ":"))
+        json.dump({"adapters": ADAPTERS, "find": find_cases(), "split": cases, "cli": cli}, fh, separators=(",", ":"))
         fh.write("\n")
     print("wrote splitter.json:", len(cases), "split cases,", os.path.getsize(os.path.join(HERE, "splitter.json")), "bytes")
 

@@ -215,3 +215,23 @@ def test_gpu_split_file_large(tmp_path):
         assert len(got) == len(w) * reps
         assert got[:len(w)] == w and got[-len(w):] == w
         assert got == w * reps
+
+
+@pytest.mark.gpu
+def test_gpu_splitter_cli_matches_reference(tmp_path):
+    """barcode_splitter_script.py of the reference, same key file and FASTQ: same files, same stdout."""
+    from tagdigger_amd import barcode_splitter_script
+    c = G["cli"]
+    (tmp_path / "lane1.fq").write_bytes(base64.b64decode(c["fastq_b64"]))
+    (tmp_path / "key.csv").write_text(c["key_csv"])
+    old = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            barcode_splitter_script.main(c["argv"])
+        assert buf.getvalue() == c["stdout"]
+        for name, want in c["outputs_b64"].items():
+            assert base64.b64encode(open(name, "rb").read()).decode() == want
+    finally:
+        os.chdir(old)
