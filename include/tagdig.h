@@ -108,6 +108,13 @@ int td_count_host(td_handle *h, const void *fastq, uint64_t nbytes,
  * 'gz' in any case), streamed and inflated on the host.  Synchronous. */
 int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weights);
 
+/* The gzip reader td_count_file / td_split_file use, on its own (host only, no GPU; for tests):
+ * inflates `path` into dst[0..capacity), asking the reader for `chunk` bytes at a time (0 = 1 MiB).
+ * BGZF files (bgzip) are inflated member-parallel on TAGDIG_INFLATE_THREADS threads (default: the
+ * host's cores, at most 16); any other gzip stream, multi-member included, goes through zlib on
+ * the calling thread, as gzip.open does at tagdigger_fun.py:241. */
+int td_gunzip_file(const char *path, void *dst, uint64_t capacity, uint64_t chunk, uint64_t *n_out);
+
 /* Line terminators (\n, \r\n, bare \r) in a device buffer -- what a shard of a
  * byte-split file must know about the shards before it.  Synchronous. */
 int td_count_lines_device(td_handle *h, const void *d_fastq, uint64_t nbytes,

@@ -96,3 +96,19 @@ def small_index(rnd, cutsite, nbar=10, ntag=40, taglens=(20, 70)):
             continue
         tags.append(t)
     return barcodes, tags, cutsites
+
+
+def bgzf_bytes(data, block=0xFF00, level=6):
+    """`data` as a BGZF file (what bgzip writes): gzip members of at most 64 KiB, each with the
+    'BC' extra field holding its compressed size, closed by the empty end-of-file member."""
+    import struct
+    import zlib
+    out = []
+    for i in range(0, len(data), block):
+        chunk = data[i:i + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp
+                   + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return b"".join(out)

@@ -269,3 +269,23 @@ def test_idempotent_relaunch_and_accumulate(eng):
     assert (eng.counts_numpy() == 2 * once).all()
     eng.reset()
     assert eng.counts_numpy().sum() == 0
+
+
+@pytest.mark.gpu
+def test_bgzf_file_counts_like_plain(tmp_path):
+    """A bgzip-style file goes through the member-parallel inflate: same matrix as the plain bytes."""
+    import tagdigger_amd
+    from tagdigger_amd.synth import SynthConfig
+    from helpers import bgzf_bytes, synth_host_bytes, synth_expected
+    cfg = SynthConfig(nreads=300_000, nbar=8, nmarkers=50, seed=1234)      # 66 MB: several staging pieces
+    data = bytes(synth_host_bytes(cfg, 0, cfg.nreads))
+    p = tmp_path / "lib.fq.gz"
+    p.write_bytes(bgzf_bytes(data, level=1))
+    eng = tagdigger_amd.Engine(0)
+    try:
+        eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        eng.count_file(str(p))
+        want, _ = synth_expected(cfg, 0, cfg.nreads)
+        assert (eng.counts_numpy() == want).all()
+    finally:
+        eng.close()
