@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--barcodes", type=int, default=384)
     ap.add_argument("--markers", type=int, default=50_000, help="tags = 2 x markers")
     ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--cutsite", default="TGCAG", help="cut site, IUPAC codes allowed (BASELINE config 5: CWGC)")
+    ap.add_argument("--bclen-max", type=int, default=8, help="barcodes are 4..N bases long (config 5: 10)")
     ap.add_argument("--tile-kb", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="reads in the cpu_baseline sample (0 = skip)")
@@ -75,7 +77,8 @@ def main():
     import tagdigger_amd
     from tagdigger_amd.synth import SynthConfig
 
-    cfg = SynthConfig(nreads=args.reads, nbar=args.barcodes, nmarkers=args.markers, seed=args.seed)
+    cfg = SynthConfig(nreads=args.reads, nbar=args.barcodes, nmarkers=args.markers, seed=args.seed,
+                      cutsite=args.cutsite, bclen=(4, args.bclen_max))
     eng = tagdigger_amd.Engine(local_rank)
     if args.tile_kb:
         eng.set_option("tile_kb", args.tile_kb)
