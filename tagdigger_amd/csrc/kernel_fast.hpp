@@ -392,8 +392,6 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                 }
                 return false;
             };
-            // (closed forms assume every terminator's successor lies inside the buffer: not in its last tile)
-            const bool simple = !use_limit && !own_first && nw <= 1 && tbase + TILE + p.halo <= p.nbytes;
             if (p.dbg & DBG_NO_PHASE2) nw = 0;
             auto commit = [&](uint64_t res) {
                 const uint32_t kind = (uint32_t)(res >> 62);
@@ -406,27 +404,68 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                                                __HIP_MEMORY_SCOPE_AGENT);
                 }
             };
+            // A regular tile -- inside the buffer, not its first, no limit to apply, at most one wanted
+            // line per thread of the workgroup -- is matched with FULL lanes: wanted line number j of
+            // the tile (the one after the j-th terminator whose ordinal is r0 mod 4; a closed form of
+            // the scan, no second scan) goes to thread j, through a list in LDS (the masks' space,
+            // dead since the scan barrier).  Only about 58 % of the threads find a wanted line in
+            // their own 128-byte span; compacted, the matcher's instructions are issued for 2.3
+            // waves' worth of lines instead of 4.  Which wave takes which quarter of the list rotates
+            // with the tile number, so that no SIMD is favoured.
+            const uint32_t nwant = (total + 3u - r0) >> 2;              // wanted ordinals below `total`
+            const bool regular = !use_limit && t != 0 && nwant <= (uint32_t)BLOCK && tbase + TILE + p.halo <= p.nbytes &&
+                                 !(p.dbg & DBG_NO_PHASE2);
+            bool general = !regular && !(p.dbg & DBG_NO_PHASE2);
             TD_MSTAMP(cx, 12, 0);   // wanted-line selection
-            // hot: the thread's single wanted line, matched from the packed chunks.  No loop and no
-            // other memory access here: in the pipelined form the bucket loads stay in flight.
-            bool general = !simple && !(p.dbg & DBG_NO_PHASE2);
-            if (simple && nw) {
-                // (a 32-bit status: 1 pending, 0 no barcode, 2 barcode only, 6 raw bytes needed)
-                const uint32_t k = (uint32_t)(match_prepare<W, ML_FAST>(p, cx, tbase + w0, w0, false, pd) >> 61);
-                if (k == 1u) {
-                    if (PIPE) pd_valid = true;
-                    else commit(match_finish<W>(p, pd));
-                } else if (k == 6u) {
-                    general = true;             // needs its raw bytes
-                } else {
-                    st_reads += sign;
-                    if (k == 2u) st_bar += sign;
+            if (regular) {
+                uint16_t *L_list = L_mask;
+                if (nw) {
+                    const uint32_t slot0 = (excl + 3u - r0) >> 2;           // wanted ordinals below this thread's first
+                    L_list[slot0] = (uint16_t)w0;
+                    if (__builtin_expect(nw > 1, 0)) {                        // (short lines: rare)
+                        uint32_t li = 0;
+#pragma unroll
+                        for (int k = 0; k < CPT / 2; k++) {
+                            uint32_t m = mm[k];
+                            while (m) {
+                                const uint32_t bit = __builtin_ctz(m);
+                                m &= m - 1;
+                                if (li > lc && ((li - lc) & 3u) == 0) L_list[slot0 + ((li - lc) >> 2)] = (uint16_t)(span0 + 32u * k + bit + 1u);
+                                li++;
+                            }
+                        }
+                    }
+                }
+                lds_barrier();
+                // hot: one line per thread, matched from the packed chunks.  No loop and no other
+                // memory access here: in the pipelined form the bucket loads stay in flight.
+                const uint32_t j = ((uint32_t)tid + 64u * (t & 3u)) & (uint32_t)(BLOCK - 1);
+                bool slow = false;
+                uint32_t srel = 0;
+                if (j < nwant) {
+                    srel = L_list[j];
+                    // (a 32-bit status: 1 pending, 0 no barcode, 2 barcode only, 6 raw bytes needed)
+                    const uint32_t k = (uint32_t)(match_prepare<W, ML_FAST>(p, cx, tbase + srel, srel, false, pd) >> 61);
+                    if (k == 1u) {
+                        if (PIPE) pd_valid = true;
+                        else commit(match_finish<W>(p, pd));
+                    } else if (k == 6u) {
+                        slow = true;                // needs its raw bytes
+                    } else {
+                        st_reads += sign;
+                        if (k == 2u) st_bar += sign;
+                    }
+                }
+                TD_STAMP(15);           // hot part done
+                // cold: a line that needs its raw bytes (leading blanks to strip, a first byte that is
+                // not a base; a non-blank non-base first byte simply comes back as "no barcode")
+                if (__builtin_expect(slow, 0)) {
+                    commit(match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true));
+                    vm_settled();
                 }
             }
-            TD_STAMP(15);           // hot part done
-            // cold: threads with several wanted lines, the buffer's ends, the maxreads limit (fix-up
-            // pass), and lines that need their raw bytes (leading blanks to strip, a first byte that
-            // is not a base, a window beyond the staged chunks)
+            // cold: the buffer's first and last tiles, the maxreads limit (fix-up pass), tiles of very
+            // short lines: every thread walks the wanted lines of its own span
             if (__builtin_expect(general, 0)) {
 #pragma nounroll
                 for (uint32_t q = 0;; q++) {
@@ -434,8 +473,6 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                     if (!nth_wanted(q, srel)) break;
                     const uint32_t c0f = srel >> 4;
                     const bool deferred = c0f + p.nch > win_ch || ((L_conv[c0f].y >> (srel & 15u)) & 1u);
-                    if (simple && !deferred) continue;
-                    // (a non-blank non-base first byte simply comes back as "no barcode")
                     commit(match_line<W, ML_BOTH>(p, cx, tbase + srel, srel, deferred));
                 }
                 vm_settled();
