@@ -48,10 +48,8 @@ def main():
                     help="reads for the pure-Python restatement's timing inside cpu_baseline (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--stagger", type=int, default=-1)
-    ap.add_argument("--slabs", type=int, default=0)
     ap.add_argument("--table-load", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
-    ap.add_argument("--split", type=int, default=-1)
     ap.add_argument("--prio", type=int, default=-1)
     ap.add_argument("--debug-ablate", type=int, default=0, help="timing-only kernel ablation bits (implies --no-check)")
     args = ap.parse_args()
@@ -86,14 +84,10 @@ def main():
         eng.set_option("blocks_per_cu", args.blocks_per_cu)
     if args.stagger >= 0:
         eng.set_option("stagger", args.stagger)
-    if args.slabs:
-        eng.set_option("slabs", args.slabs)
     if args.table_load:
         eng.set_option("table_load_pct", args.table_load)
     if args.nt >= 0:
         eng.set_option("nt_loads", args.nt)
-    if args.split >= 0:
-        eng.set_option("split", args.split)
     if args.prio >= 0:
         eng.set_option("prio", args.prio)
     if args.debug_ablate:

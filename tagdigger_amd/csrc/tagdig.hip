@@ -18,7 +18,6 @@
 #include "../../include/td_synth_spec.h"
 #include "kernels.hpp"
 #include "kernel_fast.hpp"
-#include "kernel_split.hpp"
 #include "kernel_splitter.hpp"
 
 namespace {
@@ -165,13 +164,9 @@ struct td_handle {
     DevBuf<tdk::SplitEntry> d_sp_entries;
     DevBuf<uint8_t> d_sp_pool;
     DevBuf<uint4> d_fixlist;
-    DevBuf<uint32_t> d_rec, d_region_count;   // split path: packed read records per wave region (two slab buffers)
-    hipStream_t side_stream = nullptr;        //             k_match runs here, beside the next slab's k_emit
-    std::vector<hipEvent_t> slab_ev;          //             emit-done / match-done events per slab
-    DevBuf<unsigned long long> d_slow;        //             positions of lines that need raw bytes
     uint32_t max_need = 0;                    // bases from a read's start that the matcher may look at
     // options
-    int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1, split = 0, slabs = 2, nt_loads = 1;
+    int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1, nt_loads = 1;
     uint32_t debug_ablate = 0;
     double table_load = 0.5;
     int stagger = 0;
@@ -180,7 +175,6 @@ struct td_handle {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     const void *occ_fn = nullptr; size_t occ_lds = 0; int occ_val = 1;
-    const void *occ_efn = nullptr; size_t occ_elds = 0; int occ_eval = 1;
 };
 
 namespace {
@@ -215,43 +209,6 @@ template <int CPT, bool FIX> FFn pick_fast_w(int W) {
 FFn pick_fast(int tile_kb, int W, bool fix) {
     if (fix) return tile_kb == 32 ? pick_fast_w<8, true>(W) : pick_fast_w<4, true>(W);
     return tile_kb == 32 ? pick_fast_w<8, false>(W) : pick_fast_w<4, false>(W);
-}
-
-using SFn = void (*)(const tdk::SParams);
-template <int CPT> SFn pick_emit_w(int W) {
-    switch (W) {
-    case 1: return tdk::k_emit<CPT, 1>;
-    case 2: return tdk::k_emit<CPT, 2>;
-    case 3: return tdk::k_emit<CPT, 3>;
-    case 4: return tdk::k_emit<CPT, 4>;
-    case 6: return tdk::k_emit<CPT, 6>;
-    default: return tdk::k_emit<CPT, 10>;
-    }
-}
-SFn pick_emit(int tile_kb, int W) { return tile_kb == 32 ? pick_emit_w<8>(W) : pick_emit_w<4>(W); }
-SFn pick_match(int W) {
-    switch (W) {
-    case 1: return tdk::k_match<1>;
-    case 2: return tdk::k_match<2>;
-    case 3: return tdk::k_match<3>;
-    case 4: return tdk::k_match<4>;
-    case 6: return tdk::k_match<6>;
-    default: return tdk::k_match<10>;
-    }
-}
-SFn pick_slow(int W) {
-    switch (W) {
-    case 1: return tdk::k_slow<1>;
-    case 2: return tdk::k_slow<2>;
-    case 3: return tdk::k_slow<3>;
-    case 4: return tdk::k_slow<4>;
-    case 6: return tdk::k_slow<6>;
-    default: return tdk::k_slow<10>;
-    }
-}
-size_t lds_bytes_emit(const td_handle *h, int tile_kb) {
-    size_t tile_ch = (size_t)tile_kb * 1024 / 16, halo_ch = h->halo / 16;
-    return (tile_ch + halo_ch) * 8 + tile_ch * 4 + 256;
 }
 
 size_t lds_bytes_fast(const td_handle *h, int tile_kb) {
@@ -390,65 +347,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
             e0 = h->ev_pool[h->ev_used].first; e1 = h->ev_pool[h->ev_used].second; h->ev_used++;
             HIPCHK(hipEventRecord(e0, stream));
         }
-        if (h->split) {
-            // main pass cut in two: k_emit (stream, pack, vote, one record per wanted line) + k_match
-            // (one lane per record) + k_slow (lines that need raw bytes)
-            SFn efn = pick_emit(tile_kb, h->W);
-            const size_t elds = lds_bytes_emit(h, tile_kb);
-            if (elds > 48 * 1024)
-                HIPCHK(hipFuncSetAttribute((const void *)efn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
-            if (h->occ_efn != (const void *)efn || h->occ_elds != elds) {
-                int occ = 0;
-                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)efn, tdk::BLOCK, elds));
-                h->occ_efn = (const void *)efn; h->occ_elds = elds; h->occ_eval = std::max(1, occ);
-            }
-            const int ebpc = h->blocks_per_cu > 0 ? h->blocks_per_cu : h->occ_eval;
-            const uint32_t egrid = (uint32_t)std::min<uint64_t>(ntiles, (uint64_t)h->num_cu * ebpc);
-            // The tiles are processed in slabs: k_emit(slab s+1) on the caller's stream runs beside
-            // k_match(slab s) on a side stream -- one is bound by instruction issue, the other by random
-            // memory traffic and atomics -- with two record buffers taking turns.
-            const uint32_t nslab = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)h->slabs, ntiles / (4ull * egrid) + 1));
-            const uint32_t slab_tiles = (ntiles + nslab - 1) / nslab;
-            tdk::SParams sp{};
-            sp.f = fp;
-            sp.rec_words = (h->max_need + 15) / 16;
-            sp.rec_stride = (sp.rec_words + 2) & ~1u;
-            sp.region_cap = ((slab_tiles + egrid - 1) / egrid) * 64u;
-            const uint32_t regions = egrid * (tdk::BLOCK / 64);
-            sp.slow_cap = ntiles * 256u;
-            const size_t buf_dw = (size_t)regions * sp.region_cap * sp.rec_stride;
-            rc = h->d_rec.ensure(2 * buf_dw); if (rc) return rc;
-            rc = h->d_region_count.ensure(2 * (size_t)regions + 4); if (rc) return rc;
-            rc = h->d_slow.ensure(sp.slow_cap); if (rc) return rc;
-            sp.slow = (uint64_t *)h->d_slow.p;
-            sp.nslow = h->d_region_count.p + 2 * (size_t)regions;
-            while (h->slab_ev.size() < 2 * (size_t)nslab) {
-                hipEvent_t e;
-                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                h->slab_ev.push_back(e);
-            }
-            HIPCHK(hipMemsetAsync(sp.nslow, 0, 4, stream));
-            SFn mfn = pick_match(h->W);
-            for (uint32_t sl = 0; sl < nslab; sl++) {
-                sp.tile_begin = sl * slab_tiles;
-                sp.tile_end = std::min<uint32_t>(ntiles, sp.tile_begin + slab_tiles);
-                if (sp.tile_begin >= sp.tile_end) break;
-                sp.rec = h->d_rec.p + (sl & 1) * buf_dw;
-                sp.region_count = h->d_region_count.p + (sl & 1) * (size_t)regions;
-                if (sl >= 2) HIPCHK(hipStreamWaitEvent(stream, h->slab_ev[2 * (sl - 2) + 1], 0));   // its buffer is free again
-                hipLaunchKernelGGL(efn, dim3(egrid), dim3(tdk::BLOCK), elds, stream, sp);
-                HIPCHK(hipEventRecord(h->slab_ev[2 * sl], stream));
-                HIPCHK(hipStreamWaitEvent(h->side_stream, h->slab_ev[2 * sl], 0));
-                hipLaunchKernelGGL(mfn, dim3(egrid * tdk::MATCH_SPLIT), dim3(tdk::BLOCK), h->bblob_bytes, h->side_stream, sp);
-                HIPCHK(hipEventRecord(h->slab_ev[2 * sl + 1], h->side_stream));
-            }
-            const uint32_t used = std::min<uint32_t>(nslab, (ntiles + slab_tiles - 1) / slab_tiles);
-            for (uint32_t sl = used >= 2 ? used - 2 : 0; sl < used; sl++)
-                HIPCHK(hipStreamWaitEvent(stream, h->slab_ev[2 * sl + 1], 0));
-            hipLaunchKernelGGL(pick_slow(h->W), dim3(std::min<uint32_t>(egrid, (uint32_t)h->num_cu)), dim3(tdk::BLOCK), h->bblob_bytes, stream, sp);
-        } else {
-            hipLaunchKernelGGL(ffn, dim3(grid), dim3(tdk::BLOCK), flds, stream, fp);
-        }
+        hipLaunchKernelGGL(ffn, dim3(grid), dim3(tdk::BLOCK), flds, stream, fp);
         {   // exact line phase of every tile (d_state is free on this path: it holds the block sums)
             const uint32_t rblocks = (ntiles + tdk::RESOLVE_SPAN - 1) / tdk::RESOLVE_SPAN;
             unsigned long long *super = reinterpret_cast<unsigned long long *>(h->d_state.p);
@@ -584,7 +483,6 @@ int td_create(td_handle **out, int device_id) {
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->work_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     int rc = h->d_stats.ensure(STATS_SLOTS); if (rc) { delete h; return rc; }
     rc = h->d_ticket.ensure(4); if (rc) { delete h; return rc; }
     rc = h->d_cursor.ensure(2); if (rc) { delete h; return rc; }
@@ -599,12 +497,10 @@ void td_destroy(td_handle *h) {
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
-    h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release(); h->d_rec.release(); h->d_region_count.release(); h->d_slow.release();
+    h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release();
     for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->work_stream) (void)hipStreamDestroy(h->work_stream);
-    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
-    for (auto &e : h->slab_ev) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -1113,10 +1009,8 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     else if (n == "fastpath") h->fastpath = value ? 1 : 0;
     else if (n == "stagger") h->stagger = (int)value;
     else if (n == "prio") h->prio = (int)value & 255;
-    else if (n == "split") h->split = value ? 1 : 0;
     else if (n == "table_load_pct") h->table_load = std::max<int64_t>(10, std::min<int64_t>(value, 95)) / 100.0;
     else if (n == "nt_loads") h->nt_loads = value ? 1 : 0;
-    else if (n == "slabs") h->slabs = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
     else if (n == "debug_ablate") h->debug_ablate = (uint32_t)value;   // timing-only ablations, wrong results
     else return fail(TD_E_ARG, "unknown option " + n);
     return TD_OK;

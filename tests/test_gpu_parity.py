@@ -137,21 +137,19 @@ def test_tile_boundary_sweep(eng):
         assert (eng.counts_numpy() == ora.count_bytes(data)).all(), pad
 
 
-def test_split_path_matches_fused(eng):
-    """The optional two-kernel form of the fast path (k_emit + k_match + k_slow) gives the same matrix."""
+def test_long_lines_and_phase_shifts(eng):
+    """Lines longer than a tile and permanent line-phase shifts (every later tile mispredicts its
+    neighbours' phase at the shift): the fix-up pass puts the matrix right."""
     rnd = random.Random(77)
     barcodes, tags, cutsites = small_index(rnd, "TGCAG", nbar=12, ntag=60)
     data = dirty_fastq(rnd, barcodes, tags, cutsites, nrec=4000, long_lines=True, permanent_shifts=True)
     want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data)
-    try:
-        for split, slabs in ((1, 1), (1, 3), (0, 1)):
-            eng.set_index(barcodes, tags, "TGCAG")
-            eng.set_option("split", split)
-            eng.set_option("slabs", slabs)
-            eng.count_bytes(data)
-            assert (eng.counts_numpy() == want).all(), (split, slabs)
-    finally:
-        eng.set_option("split", 0)
+    for tile_kb in (16, 32):
+        eng.set_index(barcodes, tags, "TGCAG")
+        eng.set_option("tile_kb", tile_kb)
+        eng.count_bytes(data)
+        assert (eng.counts_numpy() == want).all(), tile_kb
+    eng.set_option("tile_kb", 32)
 
 
 def test_many_short_lines_overflow_rounds(eng):
