@@ -412,7 +412,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
             // waves' worth of lines instead of 4.  Which wave takes which quarter of the list rotates
             // with the tile number, so that no SIMD is favoured.
             const uint32_t nwant = (total + 3u - r0) >> 2;              // wanted ordinals below `total`
-            const bool regular = !use_limit && t != 0 && nwant <= (uint32_t)BLOCK && tbase + TILE + p.halo <= p.nbytes &&
+            const bool regular = !use_limit && t != 0 && nwant <= (uint32_t)TILE_CH && tbase + TILE + p.halo <= p.nbytes &&
                                  !(p.dbg & DBG_NO_PHASE2);
             bool general = !regular && !(p.dbg & DBG_NO_PHASE2);
             TD_MSTAMP(cx, 12, 0);   // wanted-line selection
@@ -436,35 +436,33 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                     }
                 }
                 lds_barrier();
-                // hot: one line per thread, matched from the packed chunks.  No loop and no other
-                // memory access here: in the pipelined form the bucket loads stay in flight.
-                const uint32_t j = ((uint32_t)tid + 64u * (t & 3u)) & (uint32_t)(BLOCK - 1);
-                bool slow = false;
-                uint32_t srel = 0;
-                if (j < nwant) {
-                    srel = L_list[j];
+                // hot: one line per thread and round (one round unless the lines are shorter than
+                // ~60 bytes), matched from the packed chunks.  A thread's LAST line is left pending
+                // in the pipelined form: no other memory access follows it here, the bucket loads
+                // stay in flight.
+                const uint32_t j0 = ((uint32_t)tid + 64u * (t & 3u)) & (uint32_t)(BLOCK - 1);
+#pragma nounroll
+                for (uint32_t j = j0; j < nwant; j += BLOCK) {
+                    const uint32_t srel = L_list[j];
                     // (a 32-bit status: 1 pending, 0 no barcode, 2 barcode only, 6 raw bytes needed)
                     const uint32_t k = (uint32_t)(match_prepare<W, ML_FAST>(p, cx, tbase + srel, srel, false, pd) >> 61);
                     if (k == 1u) {
-                        if (PIPE) pd_valid = true;
-                        else commit(match_finish<W>(p, pd));
-                    } else if (k == 6u) {
-                        slow = true;                // needs its raw bytes
+                        if (PIPE && j + BLOCK >= nwant) pd_valid = true;
+                        else { commit(match_finish<W>(p, pd)); vm_settled(); }
+                    } else if (__builtin_expect(k == 6u, 0)) {
+                        // cold: needs its raw bytes (leading blanks to strip, a first byte that is not a
+                        // base; a non-blank non-base first byte simply comes back as "no barcode")
+                        commit(match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true));
+                        vm_settled();
                     } else {
                         st_reads += sign;
                         if (k == 2u) st_bar += sign;
                     }
                 }
                 TD_STAMP(15);           // hot part done
-                // cold: a line that needs its raw bytes (leading blanks to strip, a first byte that is
-                // not a base; a non-blank non-base first byte simply comes back as "no barcode")
-                if (__builtin_expect(slow, 0)) {
-                    commit(match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true));
-                    vm_settled();
-                }
             }
-            // cold: the buffer's first and last tiles, the maxreads limit (fix-up pass), tiles of very
-            // short lines: every thread walks the wanted lines of its own span
+            // cold: the buffer's first and last tiles, the maxreads limit (fix-up pass), tiles with more
+            // wanted lines than the list holds: every thread walks the wanted lines of its own span
             if (__builtin_expect(general, 0)) {
 #pragma nounroll
                 for (uint32_t q = 0;; q++) {
