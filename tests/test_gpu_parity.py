@@ -287,3 +287,32 @@ def test_bgzf_file_counts_like_plain(tmp_path):
         assert (eng.counts_numpy() == want).all()
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_byte_sharded_file_on_the_gpu(tmp_path):
+    """One file cut into byte shards at line starts (tagdigger_amd.multi): counted shard by shard
+    with each shard's own first line index, the GPU gives the whole file's matrix; and the
+    single-rank form of count_file_sharded equals find_tags_fastq."""
+    import tagdigger_amd
+    from tagdigger_amd import multi, tagdigger_fun as tf
+    rnd = random.Random(31)
+    barcodes, tags, cutsites = small_index(rnd, "TGCAG", nbar=6, ntag=40)
+    data = dirty_fastq(rnd, barcodes, tags, cutsites, nrec=3000)
+    path = str(tmp_path / "one.fq")
+    open(path, "wb").write(data)
+    want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data)
+    eng = tagdigger_amd.Engine(0)
+    try:
+        for world in (2, 3, 7):
+            eng.set_index(barcodes, tags, "TGCAG")
+            first_line = 0
+            for a, b in multi.shard_bounds(path, world):
+                if b > a:
+                    eng.count_bytes(data[a:b], first_line=first_line)
+                    first_line += multi.count_terminators(data[a:b])
+            assert (eng.counts_numpy() == want).all(), world
+    finally:
+        eng.close()
+    assert multi.count_file_sharded(path, barcodes, tags, "TGCAG") == tf.find_tags_fastq(path, barcodes, tags, cutsite="TGCAG")
+    assert multi.count_file_sharded(path, barcodes, tags, "TGCAG") == want.tolist()

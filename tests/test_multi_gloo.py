@@ -69,3 +69,73 @@ def test_single_process_path(tmp_path):
     bckeys, tags = _make_inputs(str(tmp_path))
     countsdict = {f: _oracle_counter(f, bckeys[f][0], tags, "TGCAG") for f in bckeys}
     assert multi.count_libraries(bckeys, tags, "TGCAG", counter=_oracle_counter) == tf.combineReadCounts(countsdict, bckeys)
+
+
+# ---------------------------------------------------------------- one file, byte-sharded
+def _oracle_shard_counter(data, barcodes, tags, cutsite, first_line, maxreads):
+    from oracle import c_oracle
+    return c_oracle.COracle(barcodes, tags, cutsite).count_bytes(data, maxreads=maxreads, first_line=first_line).tolist()
+
+
+def _dirty_file(tmp_path, style, seed=7):
+    from helpers import dirty_fastq, small_index
+    rnd = random.Random(seed)
+    barcodes, tags, cutsites = small_index(rnd, "TGCAG", nbar=5, ntag=30)
+    data = dirty_fastq(rnd, barcodes, tags, cutsites, nrec=400)
+    if style == "crlf":
+        data = data.replace(b"\r\n", b"\n").replace(b"\r", b"\n").replace(b"\n", b"\r\n")
+    elif style == "cr":
+        data = data.replace(b"\r\n", b"\n").replace(b"\n", b"\r")
+    elif style == "nofinal":
+        data = data.rstrip(b"\r\n")
+    path = str(tmp_path / ("one_%s.fq" % style))
+    open(path, "wb").write(data)
+    return path, data, barcodes, tags
+
+
+@pytest.mark.parametrize("style", ["mixed", "crlf", "cr", "nofinal"])
+def test_shard_bounds_and_line_index(tmp_path, style):
+    """Shards tile the file, start at line starts, and counted with their own first line index
+    add up to the whole file's matrix -- for every number of ranks."""
+    from oracle import c_oracle
+    from tagdigger_amd import multi
+    path, data, barcodes, tags = _dirty_file(tmp_path, style)
+    ora = c_oracle.COracle(barcodes, tags, "TGCAG")
+    want = ora.count_bytes(data)
+    assert want.sum() > 50
+    for world in (1, 2, 3, 5, 16):
+        bounds = multi.shard_bounds(path, world)
+        assert bounds[0][0] == 0 and bounds[-1][1] == len(data)
+        assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+        total = 0 * want
+        first_line = 0
+        for a, b in bounds:
+            if a > 0 and a < len(data):
+                assert data[a - 1:a] in (b"\n", b"\r") and not (data[a - 1:a] == b"\r" and data[a:a + 1] == b"\n")
+            piece = data[a:b]
+            if piece:
+                total = total + c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(piece, first_line=first_line)
+            first_line += multi.count_terminators(piece) if piece else 0
+        assert (total == want).all(), world
+
+
+def _shard_worker(rank, world, port, path, barcodes, tags, maxreads, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tagdigger_amd import multi
+    res = multi.count_file_sharded(path, barcodes, tags, "TGCAG", maxreads=maxreads, counter=_oracle_shard_counter)
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("maxreads", [5e9, 150, 3])
+def test_two_ranks_shard_one_file(tmp_path, maxreads):
+    from oracle import c_oracle
+    path, data, barcodes, tags = _dirty_file(tmp_path, "mixed", seed=11)
+    want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data, maxreads=maxreads).tolist()
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_shard_worker, args=(2, _free_port(), path, barcodes, tags, maxreads, out), nprocs=2, join=True)
+    assert torch.load(out) == want
