@@ -156,8 +156,20 @@ int td_get_counts(td_handle *h, uint64_t *out_rows_by_cols);   /* barnum*ntags, 
 int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
 
 /* ---- tuning / introspection ------------------------------------------------ */
-/* name: "tile_kb" (16|32), "blocks_per_cu", "prescan" (0|1: two-pass line
- * phase instead of in-kernel look-back).  Returns TD_E_ARG for unknown names. */
+/* Defaults are the measured best; every setting gives the same counts.  name:
+ *   "tile_kb"        16 | 32 (default)           bytes of FASTQ per workgroup step
+ *   "blocks_per_cu"  0 = what the occupancy query allows (default)
+ *   "fastpath"       1 (default): predicted line phase + resolve + fix-up (kernel_fast.hpp);
+ *                    0: the exact in-flight kernel with decoupled look-back (kernels.hpp)
+ *   "prescan"        1: the exact kernel with a separate line-count pass instead of look-back
+ *   "nt_loads"       1 (default): stream the FASTQ with non-temporal loads
+ *   "prio"           wave priority per phase of the fast path, two bits each: phase A | B-C << 2 |
+ *                    D << 4 | end of A << 6 (default 0xD4)
+ *   "table_load_pct" fill of the tag hash table, 10..95 (default 50); applies to the next td_set_index
+ *   "stagger"        start-up stagger of co-resident workgroups, in 4096-cycle units (default 0)
+ *   "timing"         1: record HIP events around every launch for td_kernel_time_ms
+ *   "debug_ablate"   timing-only ablation bits -- the counts are WRONG when non-zero
+ * Returns TD_E_ARG for unknown names. */
 int td_set_option(td_handle *h, const char *name, int64_t value);
 /* Average device time (ms) of the count kernel over the launches since the
  * last call (HIP events on the launch stream); launches_out optional. */
