@@ -66,11 +66,19 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
                   file=sys.stderr)
         sys.exit(2)
+    # TD_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- a correctness rehearsal of the N > 1 code
+    # path on a one-GPU box (never a measurement)
+    rehearsal = os.environ.get("TD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import tagdigger_amd
     from tagdigger_amd.synth import SynthConfig
@@ -97,18 +105,36 @@ def main():
     fastq = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     first_read = rank * cfg.nreads                      # this GPU's library = its own slice of the stream
     cfg.fill_device(eng, fastq.data_ptr(), first_read, cfg.nreads)
-    counts = torch.zeros(len(cfg.barcodes) * len(cfg.tags), dtype=torch.int32, device=dev)
-    eng.bind_counts(counts.data_ptr())               # the matrix lives in a torch tensor so RCCL can reduce it
+    # The matrix lives in torch tensors so that RCCL can reduce it in place.  With several GPUs there are
+    # two: the all-reduce of one pass (the path's one exchange: an integer sum over xGMI) runs on RCCL's
+    # stream while the next pass counts into the other matrix.
+    nmat = 2 if world > 1 else 1
+    mats = [torch.zeros(len(cfg.barcodes) * len(cfg.tags), dtype=torch.int32, device=dev) for _ in range(nmat)]
+    reducing = [None] * nmat
+    counts = mats[0]
+    eng.bind_counts(counts.data_ptr())
     eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
     stream = torch.cuda.current_stream().cuda_stream
+    passes = [0]
 
     def step():
-        counts.zero_()
+        b = passes[0] % nmat
+        passes[0] += 1
+        if reducing[b] is not None:       # this matrix's previous all-reduce (two passes ago)
+            reducing[b].wait()
+            reducing[b] = None
+        mats[b].zero_()
+        eng.bind_counts(mats[b].data_ptr())
         eng.count_device(fastq.data_ptr(), nbytes, stream=stream)
         if world > 1:
-            dist.all_reduce(counts)       # the path's one exchange: integer sum over xGMI (RCCL)
+            reducing[b] = dist.all_reduce(mats[b], async_op=True)
+        return mats[b]
 
     def fence():
+        for b in range(nmat):
+            if reducing[b] is not None:
+                reducing[b].wait()
+                reducing[b] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -124,6 +150,7 @@ def main():
         from helpers import synth_expected
         counts.zero_()
         eng.reset()
+        eng.bind_counts(counts.data_ptr())
         eng.count_device(fastq.data_ptr(), nbytes, stream=stream)
         torch.cuda.synchronize()
         got = counts.cpu().numpy().astype(np.int64).reshape(len(cfg.barcodes), len(cfg.tags))
@@ -138,8 +165,9 @@ def main():
     eng.set_option("timing", 1)
     fence()
     t0 = time.perf_counter()
+    last = counts
     for _ in range(args.steps):
-        step()
+        last = step()
     fence()
     elapsed = time.perf_counter() - t0
     kms, klaunches = eng.kernel_time_ms()
@@ -151,7 +179,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kms = float(t[0]), float(t[1])
         # every rank now holds the same summed matrix: its total must equal the sum of all shards' hits
-        tot = torch.tensor([int(counts.to(torch.int64).sum())], dtype=torch.int64, device=dev)
+        tot = torch.tensor([int(last.to(torch.int64).sum())], dtype=torch.int64, device=dev)
         mine = torch.tensor([check["tag"] if check else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(mine)
         if check and int(tot[0]) != int(mine[0]):
@@ -180,7 +208,7 @@ def main():
                                    "per GPU, 100 bp reads, %d B/record, one library per GPU"
                                    % (cfg.nreads, len(cfg.barcodes), len(cfg.tags), cfg.record_bytes),
                        "reads_per_gpu": cfg.nreads, "barcodes": len(cfg.barcodes), "tags": len(cfg.tags),
-                       "fastq_bytes_per_gpu": nbytes, "sharding": "library-per-GPU + RCCL all-reduce(int32 count matrix)"
+                       "fastq_bytes_per_gpu": nbytes, "sharding": "library-per-GPU + RCCL all-reduce(int32 count matrix) per pass, overlapped with the next pass"
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
