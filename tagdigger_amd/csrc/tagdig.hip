@@ -1025,18 +1025,32 @@ inline bool host_blank(uint8_t b) { return b == 0x20 || b == 0x09 || b == 0x0B |
 
 // The reference's record loop (:1328-1363) on the host side: lines as text mode yields them,
 // str.strip() on each, the clipped record written to its barcode's file.
-struct SplitWriter {
+// The output side shared by the writer threads: barcode b's file and buffer belong to thread
+// b % nthreads alone, so nothing is locked.
+struct SplitFiles {
     const std::vector<std::string> &barcodes;
     std::vector<FILE *> out;
     std::vector<std::string> pend;            // per output file: bytes not yet handed to stdio
+    explicit SplitFiles(const std::vector<std::string> &b) : barcodes(b) {}
+    ~SplitFiles() { for (FILE *f : out) if (f) fclose(f); }
+};
+
+// One writer thread: walks EVERY line of a piece (so that all threads agree on line numbers and on
+// where maxreads stops) but copies, clips and writes only the records of its own barcodes.
+struct SplitWriter {
+    SplitFiles &files;
+    const std::vector<std::string> &barcodes;
+    std::vector<FILE *> &out;
+    std::vector<std::string> &pend;
+    uint32_t tid = 0, nthreads = 1;
     static constexpr size_t FLUSH_AT = 64 << 10;    // (x several hundred files: keep the buffers cache-resident)
     uint64_t lineindex = 0, reads = 0, barcut = 0, clipped = 0, max_reads = 0;
     std::string comment1, sequence, comment2, quality;
     int cur_bar = -1, cur_slice = 999;
     bool stop = false, nonascii = false, io_error = false;
 
-    explicit SplitWriter(const std::vector<std::string> &b) : barcodes(b) {}
-    ~SplitWriter() { for (FILE *f : out) if (f) fclose(f); }
+    SplitWriter(SplitFiles &f, uint32_t t, uint32_t n) : files(f), barcodes(f.barcodes), out(f.out), pend(f.pend), tid(t), nthreads(n) {}
+    bool mine() const { return cur_bar > -1 && (uint32_t)cur_bar % nthreads == tid; }
 
     static void stripped(const uint8_t *p, size_t n, std::string &dst, bool upper) {
         size_t a = 0, b = n;
@@ -1063,11 +1077,11 @@ struct SplitWriter {
     void line(const uint8_t *p, size_t n, const int2 *&res) {
         switch (lineindex & 3) {
         case 0: stripped(p, n, comment1, false); break;
-        case 1: stripped(p, n, sequence, true); cur_bar = res->x; cur_slice = res->y; res++; break;
-        case 2: stripped(p, n, comment2, false); break;
+        case 1: cur_bar = res->x; cur_slice = res->y; res++; if (mine()) stripped(p, n, sequence, true); break;
+        case 2: if (mine()) stripped(p, n, comment2, false); break;
         default: {
             reads++;
-            if (cur_bar > -1) {
+            if (mine()) {
                 stripped(p, n, quality, false);
                 barcut++;
                 const std::string &bc = barcodes[(size_t)cur_bar];
@@ -1088,9 +1102,11 @@ struct SplitWriter {
     }
     // all lines of a piece that ends at a line end (or at the end of the file)
     void piece(const uint8_t *p, size_t n, const int2 *res) {
-        uint8_t any = 0;
-        for (size_t i = 0; i < n; i++) any |= p[i];                      // (vectorises)
-        if (any & 0x80) nonascii = true;
+        if (tid == 0) {
+            uint8_t any = 0;
+            for (size_t i = 0; i < n; i++) any |= p[i];                  // (vectorises)
+            if (any & 0x80) nonascii = true;
+        }
         if (!memchr(p, '\r', n)) {                                       // the usual file: '\n' only
             size_t start = 0;
             while (start < n && !stop) {
@@ -1211,8 +1227,19 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
         if (n == 0 && ferror(pf)) return -1;
         return (long)n;
     };
-    SplitWriter w(h->sp_barcodes);
-    w.max_reads = std::max<uint64_t>(1, max_reads);
+    SplitFiles files(h->sp_barcodes);
+    const char *tenv = getenv("TAGDIG_SPLIT_THREADS");
+    const uint32_t nthr = (uint32_t)std::max<long>(1, std::min<long>({tenv ? atol(tenv) : 8L, (long)h->sp_barcodes.size(),
+                                                                      (long)std::max<unsigned>(1, std::thread::hardware_concurrency())}));
+    std::vector<SplitWriter> writers;
+    for (uint32_t t = 0; t < nthr; t++) { writers.emplace_back(files, t, nthr); writers.back().max_reads = std::max<uint64_t>(1, max_reads); }
+    SplitWriter &w = writers[0];                 // (every writer sees the same lines: thread 0 speaks for the line numbers)
+    auto write_piece = [&](const uint8_t *p, size_t n, const int2 *res) {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < nthr; t++) pool.emplace_back([&, t]() { writers[t].piece(p, n, res); });
+        writers[0].piece(p, n, res);
+        for (auto &th : pool) th.join();
+    };
     int rc = TD_OK;
     const size_t cap = (size_t)32 << 20;
     // two slots: the GPU decides piece k + 1 while the host writes piece k
@@ -1241,9 +1268,9 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
         FILE *f = fopen(out_paths[b], "wb");
         if (!f) { cleanup(); return fail(TD_E_IO, std::string("cannot open ") + out_paths[b] + " for writing"); }
         setvbuf(f, nullptr, _IONBF, 0);          // (SplitWriter keeps its own buffer per file)
-        w.out.push_back(f);
+        files.out.push_back(f);
     }
-    w.pend.assign(w.out.size(), std::string());
+    files.pend.assign(files.out.size(), std::string());
     std::vector<uint8_t> carry;
     bool eof = false;
     // TAGDIG_SPLIT_TIMING=1: where the wall time of this call went, on stderr
@@ -1264,7 +1291,7 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
         if (e != hipSuccess) return hipfail("hipEventSynchronize", e);
         sl.pending = false;
         const double t1 = now();
-        if (!w.stop) w.piece(sl.pin, sl.n, sl.res_pin);
+        if (!w.stop) write_piece(sl.pin, sl.n, sl.res_pin);
         t_wait += t1 - t0; t_write += now() - t1;
         return TD_OK;
     };
@@ -1326,10 +1353,13 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
     const bool have_st = hipMemcpy(st, h->d_stats.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess;
     cleanup();
 #undef SPCHK
-    for (size_t k = 0; k < w.out.size(); k++) if (!w.flush(k)) w.io_error = true;
-    for (FILE *&f : w.out) { if (f && fclose(f) != 0) w.io_error = true; f = nullptr; }
-    if (w.io_error && !rc) rc = fail(TD_E_IO, "error writing an output file");
-    if (stats) { stats[0] = w.reads; stats[1] = w.barcut; stats[2] = w.clipped; }
+    bool io_error = false;
+    uint64_t n_barcut = 0, n_clipped = 0;
+    for (size_t k = 0; k < files.out.size(); k++) if (!w.flush(k)) io_error = true;
+    for (FILE *&f : files.out) { if (f && fclose(f) != 0) io_error = true; f = nullptr; }
+    for (auto &wr : writers) { io_error |= wr.io_error; n_barcut += wr.barcut; n_clipped += wr.clipped; }
+    if (io_error && !rc) rc = fail(TD_E_IO, "error writing an output file");
+    if (stats) { stats[0] = w.reads; stats[1] = n_barcut; stats[2] = n_clipped; }
     if (timing) fprintf(stderr, "td_split_file: read %.3f s, waiting for the GPU %.3f s, writing %.3f s\n", t_read, t_wait, t_write);
     if (rc) return rc;
     if (w.nonascii) return fail(TD_E_NONASCII, "the splitter accepts ASCII FASTQ only (a byte >= 0x80 was found)");
