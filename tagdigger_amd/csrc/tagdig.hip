@@ -1,6 +1,9 @@
 // Host side of libtagdig: handle, index builder, launches, streaming, C-ABI.
 // See include/tagdig.h for the contract and kernels.hpp for the device code.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -729,6 +732,32 @@ size_t cut_at_line_end(const uint8_t *p, size_t n) {
     return 0;
 }
 
+// Staging a piece into pinned memory on several host threads (one memcpy or pread stream does not
+// reach PCIe speed): `part(offset, n)` fills bytes [offset, offset + n) of the piece.
+inline int stage_threads() {
+    static const int n = []() {
+        const char *env = getenv("TAGDIG_STAGE_THREADS");
+        const long v = env ? atol(env) : 8;
+        return (int)std::max<long>(1, std::min<long>(v, 16));
+    }();
+    return n;
+}
+template <typename Part>
+bool stage_parallel(size_t total, Part &&part) {
+    const int nt = (int)std::min<size_t>((size_t)stage_threads(), (total >> 20) + 1);      // (a thread per MiB at most)
+    if (nt <= 1) return part(0, total);
+    std::atomic<bool> ok{true};
+    std::vector<std::thread> pool;
+    const size_t chunk = ((total + nt - 1) / nt + 4095) & ~(size_t)4095;
+    for (int t = 1; t < nt; t++) {
+        const size_t off = std::min(total, (size_t)t * chunk), n = std::min(total, off + chunk) - off;
+        if (n) pool.emplace_back([&, off, n]() { if (!part(off, n)) ok = false; });
+    }
+    if (!part(0, std::min(total, chunk))) ok = false;
+    for (auto &th : pool) th.join();
+    return ok;
+}
+
 // generic pump: `reader(dst, want)` returns bytes produced (0 at end, <0 on error)
 template <typename Reader>
 int pump(td_handle *h, Reader &&reader, uint64_t size_hint, uint64_t first_line, uint64_t max_reads, int weights,
@@ -773,7 +802,7 @@ int td_count_host(td_handle *h, const void *fastq, uint64_t nbytes, uint64_t fir
     uint64_t pos = 0;
     auto reader = [&](uint8_t *dst, size_t want) -> long {
         size_t n = (size_t)std::min<uint64_t>(want, nbytes - pos);
-        if (n) memcpy(dst, src + pos, n);
+        if (n) stage_parallel(n, [&](size_t off, size_t len) { memcpy(dst + off, src + pos + off, len); return true; });
         pos += n;
         return (long)n;
     };
@@ -815,15 +844,33 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
         auto reader = [&](uint8_t *dst, size_t want) -> long { return src.read(dst, want); };
         return pump(h, reader, 0, 0, max_reads, weights, nullptr);
     }
-    FILE *f = fopen(path, "rb");
-    if (!f) return fail(TD_E_IO, std::string("cannot open ") + path);
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(TD_E_IO, std::string("cannot open ") + path);
+    struct stat sb;
+    const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+    uint64_t fpos = 0;
     auto reader = [&](uint8_t *dst, size_t want) -> long {
-        size_t n = fread(dst, 1, want, f);
-        if (n == 0 && ferror(f)) return -1;
+        if (!regular) {                                    // a pipe or device: plain sequential reads
+            const ssize_t n = read(fd, dst, want);
+            return (long)n;
+        }
+        const uint64_t size = (uint64_t)sb.st_size;
+        const size_t n = (size_t)std::min<uint64_t>(want, fpos < size ? size - fpos : 0);
+        if (n == 0) return 0;
+        const bool ok = stage_parallel(n, [&](size_t off, size_t len) {
+            while (len) {
+                const ssize_t got = pread(fd, dst + off, len, (off_t)(fpos + off));
+                if (got <= 0) return false;
+                off += (size_t)got; len -= (size_t)got;
+            }
+            return true;
+        });
+        if (!ok) return -1;
+        fpos += n;
         return (long)n;
     };
     int rc = pump(h, reader, 0, 0, max_reads, weights, nullptr);
-    fclose(f);
+    close(fd);
     return rc;
 }
 
