@@ -155,6 +155,12 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
 int td_get_counts(td_handle *h, uint64_t *out_rows_by_cols);   /* barnum*ntags, row-major */
 int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
 
+/* ---- environment ------------------------------------------------------------
+ * TAGDIG_STAGE_THREADS    host threads that copy / pread a piece into pinned memory (default 8, 1..16)
+ * TAGDIG_INFLATE_THREADS  host threads for BGZF member-parallel inflate (default: cores, at most 16)
+ * TAGDIG_SPLIT_THREADS    writer threads of td_split_file (default 8, at most the number of barcodes)
+ * TAGDIG_SPLIT_TIMING     set: td_split_file reports where its wall time went, on stderr */
+
 /* ---- tuning / introspection ------------------------------------------------ */
 /* Defaults are the measured best; every setting gives the same counts.  name:
  *   "tile_kb"        16 | 32 (default)           bytes of FASTQ per workgroup step
