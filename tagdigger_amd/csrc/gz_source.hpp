@@ -1,6 +1,10 @@
 // Host-side gzip reader of libtagdig (no GPU code): what td_count_file, td_split_file and
 // td_gunzip_file read .gz inputs through.
 #pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -12,15 +16,21 @@
 #include <thread>
 #include <vector>
 
+#include "fast_inflate.hpp"
+
 namespace tdhost {
 
-// Gzip input.  Ordinary .gz streams go through zlib's gzread on the calling thread (one core:
-// ~0.6 GB/s of FASTQ).  BGZF files (bgzip: a series of <= 64 KiB gzip members, each announcing its
+// Gzip input.  Ordinary .gz streams are memory-mapped and decoded by FastInflate on the calling
+// thread (TAGDIG_ZLIB=1: zlib's gzread instead, ~0.6 GB/s of FASTQ on one core).  BGZF files (bgzip: a series of <= 64 KiB gzip members, each announcing its
 // compressed size in a 'BC' extra field and ending with its uncompressed size) are inflated
 // member-parallel: the members of one request are located first, then worker threads inflate
 // them straight into the destination at their prefix offsets, each checking size and CRC-32.
 struct GzSource {
-    gzFile zf = nullptr;        // plain gzip
+    gzFile zf = nullptr;        // plain gzip through zlib
+    FastInflate fi;             // plain gzip through the decoder of fast_inflate.hpp, over a mapping of the file
+    uint8_t *map = nullptr;
+    size_t map_len = 0;
+    bool use_fi = false;
     FILE *bf = nullptr;         // BGZF
     int threads = 1;
     std::vector<uint8_t> comp;  // compressed bytes of the request being served
@@ -58,15 +68,43 @@ struct GzSource {
             return true;
         }
         fclose(f);
+        if (!getenv("TAGDIG_ZLIB") && map_file(path)) return true;
         zf = gzopen(path, "rb");
         if (zf) gzbuffer(zf, 1 << 20);
         return zf != nullptr;
     }
-    void close() { if (zf) gzclose(zf); if (bf) fclose(bf); zf = nullptr; bf = nullptr; }
+    // the file followed by at least FastInflate::PAD readable zero bytes: an anonymous mapping one
+    // page longer than the file, the file mapped over its beginning
+    bool map_file(const char *path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size == 0) { ::close(fd); return false; }
+        const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+        const size_t n = (size_t)sb.st_size;
+        const size_t total = (n + page - 1) / page * page + page;
+        void *base = mmap(nullptr, total, PROT_READ, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (base == MAP_FAILED) { ::close(fd); return false; }
+        void *over = mmap(base, n, PROT_READ, MAP_PRIVATE | MAP_FIXED, fd, 0);
+        ::close(fd);
+        if (over == MAP_FAILED) { munmap(base, total); return false; }
+        (void)madvise(base, n, MADV_SEQUENTIAL);
+        map = (uint8_t *)base; map_len = total;
+        fi.open(map, n);
+        use_fi = true;
+        return true;
+    }
+    void close() {
+        if (zf) gzclose(zf);
+        if (bf) fclose(bf);
+        if (map) munmap(map, map_len);
+        zf = nullptr; bf = nullptr; map = nullptr; use_fi = false;
+    }
     ~GzSource() { close(); }
 
     // up to `want` uncompressed bytes into dst; 0 at the end, < 0 on error
     long read(uint8_t *dst, size_t want) {
+        if (use_fi) return fi.read(dst, want);
         if (zf) return gzread(zf, dst, (unsigned)std::min<size_t>(want, 1u << 30));
         if (bad) return -1;
         if (spill_pos < spill.size()) {

@@ -66,3 +66,112 @@ def test_gunzip_destination_too_small(tmp_path, fastq):
     p.write_bytes(bgzf_bytes(fastq))
     rc, _ = gunzip(p, len(fastq) - 1)
     assert rc != 0
+
+
+# ------------------------------------------------------------------ the library's own DEFLATE decoder
+def _gz(data, level=6, strategy=0, mem=8):
+    import zlib
+    co = zlib.compressobj(level, zlib.DEFLATED, 31, mem, strategy)
+    return co.compress(data) + co.flush()
+
+
+_PAYLOADS = {}
+
+
+def _payloads():
+    if not _PAYLOADS:
+        _PAYLOADS.update(_make_payloads())
+    return _PAYLOADS
+
+
+def _make_payloads():
+    rng = random.Random(99)
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(100)),
+                                          bytes(rng.choice(b"FFFFFF:,#") for _ in range(100))) for i in range(12000))
+    return {
+        "empty": b"",
+        "one": b"A",
+        "fastq": fq,                                                     # 2.6 MB: several staging refills
+        "random": rng.randbytes(300000),                                 # incompressible: stored blocks at level 0, long codes
+        "zeros": bytes(3_000_000),                                       # distance-1 runs, length 258
+        "period3": b"abc" * 400000,                                      # distances 2..7
+        "period7": b"abcdefg" * 200000,
+        "far": rng.randbytes(32768) * 40,                                # matches at distance 32768
+        "text": (b"the quick brown fox jumps over the lazy dog; " * 3000) + fq[:50000],
+    }
+
+
+@pytest.mark.parametrize("name", ["empty", "one", "fastq", "random", "zeros", "period3", "period7", "far", "text"])
+@pytest.mark.parametrize("level,strategy", [(0, 0), (1, 0), (6, 0), (9, 0), (6, 4), (6, 2), (6, 3), (1, 1)])
+def test_fast_inflate_equals_zlib(tmp_path, monkeypatch, name, level, strategy):
+    """Z_FIXED (4) gives fixed-Huffman blocks, Z_HUFFMAN_ONLY (2) literal-only dynamic blocks, Z_RLE (3)
+    distance-1 matches, level 0 stored blocks."""
+    monkeypatch.delenv("TAGDIG_ZLIB", raising=False)
+    data = _payloads()[name]
+    p = tmp_path / "x.gz"
+    p.write_bytes(_gz(data, level, strategy))
+    for chunk in (0, 1 << 22, 4097):
+        rc, got = gunzip(p, len(data), chunk)
+        assert rc == 0 and got == data, (name, level, strategy, chunk)
+
+
+def test_fast_inflate_header_fields_and_members(tmp_path, monkeypatch):
+    import struct
+    import zlib
+    monkeypatch.delenv("TAGDIG_ZLIB", raising=False)
+    rng = random.Random(3)
+    parts = [bytes(rng.choice(b"ACGTN\n") for _ in range(n)) for n in (70000, 1, 0, 1500000)]
+
+    def member(data, flg):
+        raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = raw.compress(data) + raw.flush()
+        head = b"\x1f\x8b\x08" + bytes([flg]) + b"\0\0\0\0\x00\x03"
+        if flg & 4:
+            head += struct.pack("<H", 5) + b"hello"
+        if flg & 8:
+            head += b"reads.fq\0"
+        if flg & 16:
+            head += b"a comment\0"
+        if flg & 2:
+            head += struct.pack("<H", zlib.crc32(head) & 0xFFFF)
+        return head + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+    blob = b"".join(member(d, f) for d, f in zip(parts, (4 | 8 | 16 | 2, 8, 0, 4)))
+    p = tmp_path / "m.gz"
+    p.write_bytes(blob + b"\0" * 100)                      # trailing zero padding is ignored, as by gzread
+    rc, got = gunzip(p, sum(map(len, parts)))
+    assert rc == 0 and got == b"".join(parts)
+    assert gzip.decompress(blob) == b"".join(parts)
+
+
+def test_fast_inflate_rejects_damage(tmp_path, monkeypatch):
+    """Flipped bytes and truncation: an error (never a crash, a hang or silently wrong data)."""
+    monkeypatch.delenv("TAGDIG_ZLIB", raising=False)
+    data = _payloads()["fastq"][:400000]
+    good = _gz(data)
+    rng = random.Random(17)
+    p = tmp_path / "d.gz"
+    wrong = 0
+    for trial in range(150):
+        blob = bytearray(good)
+        if trial % 3 == 0:
+            blob = blob[:rng.randrange(1, len(blob))]
+        else:
+            for _ in range(rng.randrange(1, 4)):
+                blob[rng.randrange(10, len(blob))] ^= 1 << rng.randrange(8)
+        p.write_bytes(bytes(blob))
+        rc, got = gunzip(p, len(data) + 1000)
+        if rc == 0:
+            assert got == data               # (a flip that only touched the header's mtime, say)
+        else:
+            wrong += 1
+    assert wrong > 120
+
+
+def test_zlib_fallback_env(tmp_path, monkeypatch):
+    data = _payloads()["text"]
+    p = tmp_path / "x.gz"
+    p.write_bytes(_gz(data))
+    monkeypatch.setenv("TAGDIG_ZLIB", "1")
+    rc, got = gunzip(p, len(data))
+    assert rc == 0 and got == data
