@@ -24,7 +24,7 @@ class FastInflate {
         in_ = data; in_end_ = data + n;
         bitbuf_ = 0; bitcnt_ = 0;
         state_ = S_MEMBER; failed_ = false;
-        buf_.assign(HIST + CAP + SLACK, 0);
+        if (buf_.size() != HIST + CAP + SLACK) buf_.assign(HIST + CAP + SLACK, 0);     // (kept across open() calls)
         obuf_ = buf_.data();
         wpos_ = rpos_ = crc_pos_ = HIST;
         crc_ = 0; isize_ = 0;

@@ -113,7 +113,7 @@ struct GzSource {
             spill_pos += n;
             return (long)n;
         }
-        struct Member { size_t in_off, in_len, out_off; uint32_t out_len, crc; };
+        struct Member { size_t in_off, in_len, out_off; uint32_t out_len, crc; size_t at, size; };   // at/size: the whole member
         std::vector<Member> mem;
         comp.clear();
         size_t out_total = 0;
@@ -147,13 +147,27 @@ struct GzSource {
                 comp.clear();
                 return read(dst, want);
             }
-            mem.push_back({base + hs, (size_t)bs - hs - 8, out_total, isize, crc});
+            mem.push_back({base + hs, (size_t)bs - hs - 8, out_total, isize, crc, base, (size_t)bs});
             out_total += isize;
         }
         if (mem.empty()) return 0;
+        comp.resize(comp.size() + FastInflate::PAD, 0);              // (the decoder may read that far past a member)
         std::atomic<size_t> next{0};
         std::atomic<bool> failed{false};
+        const bool own_decoder = !getenv("TAGDIG_ZLIB");
+        auto work_fast = [&]() {                                      // every member is a complete gzip member
+            FastInflate dec;
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= mem.size() || failed) break;
+                const Member &m = mem[k];
+                dec.open(comp.data() + m.at, m.size);
+                uint8_t extra;
+                if (dec.read(dst + m.out_off, m.out_len) != (long)m.out_len || dec.read(&extra, 1) != 0) { failed = true; break; }
+            }
+        };
         auto work = [&]() {
+            if (own_decoder) { work_fast(); return; }
             z_stream zs;
             memset(&zs, 0, sizeof(zs));
             if (inflateInit2(&zs, -15) != Z_OK) { failed = true; return; }
