@@ -245,6 +245,31 @@ def cpu_baseline(cfg, sample_reads, python_reads=0):
                      "trie build %.2f s timed separately; scalar C restatement oracle/oracle.c"
                      % (sample_reads, data.nbytes / 1e9, build_s),
            "index_build_s": build_s, "loop_s": loop_s}
+    # the same C restatement on every core this process may use (at most 16: the GPU box's share per GPU),
+    # one shard of whole records per thread, matrices summed -- the "own CPU path at all cores" line of SURVEY 8d
+    try:
+        ncore = max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        ncore = max(1, min(16, os.cpu_count() or 1))
+    if ncore > 1:
+        import numpy as np
+        from concurrent.futures import ThreadPoolExecutor
+        per = (sample_reads + ncore - 1) // ncore
+        shards = [(k * per, min(sample_reads, (k + 1) * per)) for k in range(ncore) if k * per < sample_reads]
+        oracles = [c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite) for _ in shards]
+        mats = [np.zeros((len(cfg.barcodes), len(cfg.tags)), dtype=np.uint64) for _ in shards]
+        for m in mats:
+            m.fill(0)                     # (pages touched before the clock starts)
+
+        def run(k):
+            a, b = shards[k]
+            return oracles[k].count_bytes(data[a * cfg.record_bytes:b * cfg.record_bytes], first_line=4 * a, counts=mats[k])
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(len(shards)) as ex:
+            parts = list(ex.map(run, range(len(shards))))
+        par_s = time.perf_counter() - t0
+        out["all_cores"] = {"value": sample_reads / par_s, "unit": "reads/s", "cores": len(shards), "loop_s": par_s,
+                            "matrix_total": int(sum(int(m.sum()) for m in parts))}
     if python_reads > 0:
         from oracle import tagdigger_oracle as po
         pdata = bytes(data[:python_reads * cfg.record_bytes])
