@@ -33,6 +33,7 @@ struct SplitParams {
     unsigned long long site0, site1;   // the two full restriction sites, last character in the low byte
     uint32_t site0_len, site1_len;
     const uint32_t *ent_begin; // [barnum + 1] entries of barcode b: entries[ent_begin[b] .. ent_begin[b + 1])
+    const uint32_t *ent_group; // [barnum][4] within those, where the entries whose LAST base has code c begin (sorted by it)
     const SplitEntry *entries;
     const uint8_t *pool;
     int2 *out;
@@ -41,29 +42,64 @@ struct SplitParams {
 
 __device__ __forceinline__ uint32_t upper_ascii(uint32_t c) { return (c >= 0x61u && c <= 0x7Au) ? c - 0x20u : c; }
 
+// 16 bytes of the buffer at any alignment (zeros past its end)
+__device__ __forceinline__ uint4 load16_any(const SplitParams &p, uint64_t g) {
+    if (g + 16 <= p.nbytes) {
+        const uint8_t *q = p.buf + g;
+        if (((uintptr_t)q & 3u) == 0) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(q);
+            return make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        // unaligned: two aligned 16-byte windows would do, but byte assembly keeps it simple and L2-hot
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = q[4 * k] | (q[4 * k + 1] << 8) | (q[4 * k + 2] << 16) | ((uint32_t)q[4 * k + 3] << 24);
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < 16 && g + k < p.nbytes; k++) w[k >> 2] |= (uint32_t)p.buf[g + k] << (8 * (k & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // One sequence line starting at gpos.
 __device__ __forceinline__ int2 split_line(const SplitParams &p, const unsigned long long *L_bval, const uint32_t *L_bmeta,
                                            const uint16_t *L_bdir, uint64_t gpos) {
     const uint8_t *b = p.buf;
-    // line.strip(): blanks off both ends; the line ends at the first terminator (or the buffer's end)
+    // line.strip(): blanks off both ends; the line ends at the first terminator (or the buffer's end).
+    // The scan for the terminator goes 16 bytes at a time.
     uint64_t s = gpos;
     while (s < p.nbytes && is_blank(b[s])) s++;
     uint64_t e = s;
-    bool hi = false;
-    while (e < p.nbytes && b[e] != 0x0Au && b[e] != 0x0Du) { hi |= b[e] >= 0x80u; e++; }
+    uint32_t hiacc = 0;
+    for (;;) {
+        if (e >= p.nbytes) { e = p.nbytes; break; }
+        const uint4 v = load16_any(p, e);
+        const uint32_t term = eq_mask16(v, 0x0A0A0A0Au) | eq_mask16(v, 0x0D0D0D0Du);
+        const uint32_t left = (uint32_t)std::min<uint64_t>(16, p.nbytes - e);
+        const uint32_t t2 = term & ((1u << left) - 1u);
+        if (t2) {
+            const uint32_t k = __builtin_ctz(t2);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};                // bytes >= 0x80 before the terminator only
+            for (uint32_t q = 0; q < k; q++) hiacc |= (w[q >> 2] >> (8 * (q & 3))) & 0x80u;
+            e += k;
+            break;
+        }
+        hiacc |= (v.x | v.y | v.z | v.w) & 0x80808080u;
+        if (left < 16) { e = p.nbytes; break; }
+        e += 16;
+    }
     while (e > s && is_blank(b[e - 1])) e--;
-    if (hi) atomicOr(p.stats + ST_ERR, ERR_NONASCII);
+    if (hiacc) atomicOr(p.stats + ST_ERR, ERR_NONASCII);
     const uint64_t len = e - s;
 
     // ---- barcode + cut site: the first (up to 32) valid bases, packed like the index
-    unsigned long long K = 0;
-    uint32_t nvalid = 0;
-    for (; nvalid < 32 && nvalid < len; nvalid++) {
-        const uint32_t c = upper_ascii(b[s + nvalid]);
-        const uint32_t code = (c >> 1) & 3u;
-        if (c != ((0x47544341u >> (8 * code)) & 0xFFu)) break;       // "ACTG"[code]
-        K |= (unsigned long long)code << (62 - 2 * nvalid);
-    }
+    const uint2 c0 = convert_chunk(load16_any(p, s)), c1 = convert_chunk(load16_any(p, s + 16));
+    const unsigned long long Kfull = ((unsigned long long)c0.x << 32) | c1.x;
+    const uint32_t invalid = (c0.y & 0xFFFFu) | (c1.y << 16);
+    uint32_t nvalid = invalid ? (uint32_t)__builtin_ctz(invalid) : 32u;
+    if (nvalid > len) nvalid = (uint32_t)len;
+    // (bases past the valid ones must not take part: the index compares whole prefixes)
+    const unsigned long long K = nvalid >= 32 ? Kfull : nvalid == 0 ? 0ull : Kfull & (~0ull << (64 - 2 * nvalid));
     uint32_t ci = L_bdir[(uint32_t)(K >> (64 - 2 * BDIR_BASES))];
     uint32_t meta = 0;
     bool hit = false;
@@ -81,17 +117,23 @@ __device__ __forceinline__ int2 split_line(const SplitParams &p, const unsigned 
     const uint64_t start = ((meta >> 6) & 63u) + p.cutlen;           // searchstart = len(barcode) + len(cutsite)
 
     // ---- first full restriction site at or after `start` (str.find): a rolling window of the
-    // last eight characters against both sites
+    // last eight characters against both sites, the characters taken from 16-byte loads
     long long rs0 = -1, rs1 = -1;
     {
         const unsigned long long m0 = p.site0_len >= 8 ? ~0ull : ((1ull << (8 * p.site0_len)) - 1ull);
         const unsigned long long m1 = p.site1_len >= 8 ? ~0ull : ((1ull << (8 * p.site1_len)) - 1ull);
         unsigned long long win = 0;
-        for (uint64_t i = start; i < len && (rs0 < 0 || rs1 < 0); i++) {
-            win = (win << 8) | upper_ascii(b[s + i]);
-            const uint64_t have = i - start + 1;
-            if (rs0 < 0 && have >= p.site0_len && (win & m0) == p.site0) rs0 = (long long)(i + 1 - p.site0_len);
-            if (rs1 < 0 && have >= p.site1_len && (win & m1) == p.site1) rs1 = (long long)(i + 1 - p.site1_len);
+        for (uint64_t i0 = start; i0 < len && (rs0 < 0 || rs1 < 0); i0 += 16) {
+            const uint4 v = load16_any(p, s + i0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t n = (uint32_t)std::min<uint64_t>(16, len - i0);
+            for (uint32_t q = 0; q < n; q++) {
+                const uint64_t i = i0 + q;
+                win = (win << 8) | upper_ascii((w[q >> 2] >> (8 * (q & 3))) & 0xFFu);
+                const uint64_t have = i - start + 1;
+                if (rs0 < 0 && have >= p.site0_len && (win & m0) == p.site0) rs0 = (long long)(i + 1 - p.site0_len);
+                if (rs1 < 0 && have >= p.site1_len && (win & m1) == p.site1) rs1 = (long long)(i + 1 - p.site1_len);
+            }
         }
         // (an empty site is found at `start` itself whenever start <= len, as str.find does)
         if (p.site0_len == 0 && start <= len) rs0 = (long long)start;
@@ -106,18 +148,26 @@ __device__ __forceinline__ int2 split_line(const SplitParams &p, const unsigned 
         return make_int2((int)bar, (int)cut);
     }
     // ---- no full site: does the read END with the start of an adapter?  (the reference walks a
-    // trie over the reversed read; its stored set is prefix-free, so at most one entry matches)
-    const uint32_t e0 = p.ent_begin[bar], e1 = p.ent_begin[bar + 1];
-    for (uint32_t k = e0; k < e1; k++) {
-        const SplitEntry en = p.entries[k];
-        if (en.len > len || en.len == 0) continue;
-        const uint8_t *a = p.pool + en.off;
+    // trie over the reversed read; its stored set is prefix-free, so at most one entry matches.)
+    // Only the entries whose last base is the read's last base can match: they are stored together.
+    if (len == 0) return make_int2((int)bar, 999);
+    const uint32_t lastc = upper_ascii(b[e - 1]);
+    const uint32_t lcode = (lastc >> 1) & 3u;
+    if (lastc != ((0x47544341u >> (8 * lcode)) & 0xFFu)) return make_int2((int)bar, 999);     // not a base: no entry ends with it
+    const uint32_t e0 = p.ent_group[4 * bar + lcode];
+    const uint32_t e1 = lcode == 3 ? p.ent_begin[bar + 1] : p.ent_group[4 * bar + lcode + 1];
+    int found = 999;
+    for (uint32_t k = e0; k < e1 && found == 999; k++) {
+        const uint4 raw = reinterpret_cast<const uint4 *>(p.entries)[k];     // {off, len, slice, -}
+        const uint32_t elen = raw.y;
+        if (elen > len || elen == 0) continue;
+        const uint8_t *a = p.pool + raw.x;
         bool same = true;
-        for (uint32_t q = 0; q < en.len && same; q++)                 // from the read's last character backwards
-            same = upper_ascii(b[e - 1 - q]) == a[en.len - 1 - q];
-        if (same) return make_int2((int)bar, en.slice);
+        for (uint32_t q = 1; q < elen && same; q++)                   // from the read's second-last character backwards
+            same = upper_ascii(b[e - 1 - q]) == a[elen - 1 - q];
+        if (same) found = (int)raw.z;
     }
-    return make_int2((int)bar, 999);
+    return make_int2((int)bar, found);
 }
 
 template <int CPT>

@@ -164,7 +164,7 @@ struct td_handle {
     uint32_t sp_bblob_bytes = 0, sp_off_bmeta = 0, sp_off_bdir = 0, sp_cutlen = 0;
     unsigned long long sp_site[2] = {0, 0};
     uint32_t sp_site_len[2] = {0, 0};
-    DevBuf<uint32_t> d_sp_bblob, d_sp_ent_begin;
+    DevBuf<uint32_t> d_sp_bblob, d_sp_ent_begin, d_sp_ent_group;
     DevBuf<tdk::SplitEntry> d_sp_entries;
     DevBuf<uint8_t> d_sp_pool;
     DevBuf<uint4> d_fixlist;
@@ -1057,7 +1057,7 @@ int launch_split(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     sp.bblob = h->d_sp_bblob.p; sp.bblob_bytes = h->sp_bblob_bytes; sp.off_bmeta = h->sp_off_bmeta; sp.off_bdir = h->sp_off_bdir;
     sp.cutlen = h->sp_cutlen;
     sp.site0 = h->sp_site[0]; sp.site1 = h->sp_site[1]; sp.site0_len = h->sp_site_len[0]; sp.site1_len = h->sp_site_len[1];
-    sp.ent_begin = h->d_sp_ent_begin.p; sp.entries = h->d_sp_entries.p; sp.pool = h->d_sp_pool.p;
+    sp.ent_begin = h->d_sp_ent_begin.p; sp.ent_group = h->d_sp_ent_group.p; sp.entries = h->d_sp_entries.p; sp.pool = h->d_sp_pool.p;
     sp.out = d_out; sp.stats = h->d_stats.p;
     const size_t lds = (size_t)4 * tdk::BLOCK * 2 + 64 + h->sp_bblob_bytes;
     hipLaunchKernelGGL((tdk::k_split<4>), dim3(g), dim3(tdk::BLOCK), lds, s, sp);
@@ -1215,18 +1215,36 @@ int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, co
         for (size_t q = 0; q < L; q++) v = (v << 8) | (uint8_t)sites[k][q];
         h->sp_site[k] = v; h->sp_site_len[k] = (uint32_t)L;
     }
-    std::vector<tdk::SplitEntry> ents(nent);
-    std::vector<uint8_t> pool;
-    for (uint32_t e = 0; e < nent; e++) {
-        const size_t L = strlen(ent_seq[e]);
-        ents[e].off = (uint32_t)pool.size(); ents[e].len = (uint32_t)L; ents[e].slice = ent_slice[e]; ents[e].pad = 0;
-        pool.insert(pool.end(), (const uint8_t *)ent_seq[e], (const uint8_t *)ent_seq[e] + L);
-    }
     if (ent_begin[nbar] != nent) return fail(TD_E_ARG, "ent_begin[nbar] must equal nent");
+    // per barcode the entries are stored by the code of their LAST base (A C T G = (byte >> 1) & 3): only
+    // the group of the read's last base has to be looked at
+    std::vector<tdk::SplitEntry> ents;
+    std::vector<uint32_t> groups((size_t)nbar * 4, 0);
+    std::vector<uint8_t> pool;
+    ents.reserve(nent);
+    for (uint32_t b = 0; b < nbar; b++) {
+        if (ent_begin[b] > ent_begin[b + 1] || ent_begin[b + 1] > nent) return fail(TD_E_ARG, "ent_begin must not decrease");
+        for (uint32_t code = 0; code < 4; code++) {
+            groups[(size_t)b * 4 + code] = (uint32_t)ents.size();
+            for (uint32_t e = ent_begin[b]; e < ent_begin[b + 1]; e++) {
+                const size_t L = strlen(ent_seq[e]);
+                const uint32_t c = L ? (((uint8_t)ent_seq[e][L - 1] >> 1) & 3u) : 0u;
+                if (c != code) continue;
+                for (size_t q = 0; q < L; q++)
+                    if (!strchr("ACGT", ent_seq[e][q])) return fail(TD_E_ALPHABET, "adapter entries must be upper-case ACGT");
+                tdk::SplitEntry en;
+                en.off = (uint32_t)pool.size(); en.len = (uint32_t)L; en.slice = ent_slice[e]; en.pad = 0;
+                ents.push_back(en);
+                pool.insert(pool.end(), (const uint8_t *)ent_seq[e], (const uint8_t *)ent_seq[e] + L);
+            }
+        }
+    }
     rc = h->d_sp_bblob.ensure(blob.size() / 4); if (rc) return rc;
     HIPCHK(hipMemcpy(h->d_sp_bblob.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     rc = h->d_sp_ent_begin.ensure(nbar + 1); if (rc) return rc;
     HIPCHK(hipMemcpy(h->d_sp_ent_begin.p, ent_begin, (size_t)(nbar + 1) * 4, hipMemcpyHostToDevice));
+    rc = h->d_sp_ent_group.ensure((size_t)nbar * 4); if (rc) return rc;
+    HIPCHK(hipMemcpy(h->d_sp_ent_group.p, groups.data(), groups.size() * 4, hipMemcpyHostToDevice));
     rc = h->d_sp_entries.ensure(std::max<size_t>(1, nent)); if (rc) return rc;
     if (nent) HIPCHK(hipMemcpy(h->d_sp_entries.p, ents.data(), (size_t)nent * sizeof(tdk::SplitEntry), hipMemcpyHostToDevice));
     rc = h->d_sp_pool.ensure(std::max<size_t>(1, pool.size())); if (rc) return rc;
