@@ -156,6 +156,8 @@ __device__ __forceinline__ int2 split_line(const SplitParams &p, const unsigned 
     if (lastc != ((0x47544341u >> (8 * lcode)) & 0xFFu)) return make_int2((int)bar, 999);     // not a base: no entry ends with it
     const uint32_t e0 = p.ent_group[4 * bar + lcode];
     const uint32_t e1 = lcode == 3 ? p.ent_begin[bar + 1] : p.ent_group[4 * bar + lcode + 1];
+    // (the result is carried out of the loop in `found`: with a `return` from inside these nested,
+    // divergent loops hipcc 7.2 -O3 returned the slice of the wrong entry)
     int found = 999;
     for (uint32_t k = e0; k < e1 && found == 999; k++) {
         const uint4 raw = reinterpret_cast<const uint4 *>(p.entries)[k];     // {off, len, slice, -}
