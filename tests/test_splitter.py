@@ -235,3 +235,19 @@ def test_gpu_splitter_cli_matches_reference(tmp_path):
             assert base64.b64encode(open(name, "rb").read()).decode() == want
     finally:
         os.chdir(old)
+
+
+def test_splitter_cpu_restatement_rate(capsys):
+    """Not a check: prints the pure-Python restatement's rate on 20 k canonical reads (what DESIGN.md
+    quotes beside the GPU path's numbers; run with -s to see it)."""
+    import time
+    from tagdigger_amd.synth import SynthConfig
+    from helpers import synth_host_bytes
+    cfg = SynthConfig(nreads=20_000, nbar=96, nmarkers=500, seed=3)
+    data = bytes(synth_host_bytes(cfg, 0, cfg.nreads))
+    t0 = time.perf_counter()
+    outs, stats = po.barcode_splitter_bytes(data, cfg.barcodes, cfg.cutsite, adapter_of("PstI-MspI-Hall"))
+    dt = time.perf_counter() - t0
+    assert stats[0] == cfg.nreads and sum(map(len, outs)) > 0
+    with capsys.disabled():
+        print(" [python restatement of barcodeSplitter: %.1f k reads/s] " % (cfg.nreads / dt / 1e3), end="")

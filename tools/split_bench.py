@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the barcode splitter on the canonical synthetic stream:
 decisions only (k_count_lines + k_scan_tiles + k_split on a buffer resident in HBM) and end to end
-from a file (td_split_file: read, H2D, decide, D2H, host writes the clipped records), next to the
-oracle's pure-Python restatement on a sample."""
+from a file (td_split_file: read, H2D, decide, D2H, host writes the clipped records).  (The CPU
+restatement of the same loop is timed by tests/test_splitter.py::test_splitter_cpu_restatement_rate.)"""
 import contextlib, io, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -36,9 +36,5 @@ t0 = time.perf_counter(); st = eng.split_file(src, outs); dt = time.perf_counter
 outbytes = sum(os.path.getsize(o) for o in outs)
 print("file -> %d files        : %7.1f Mreads/s  %6.2f GB/s in, %.2f GB written  (reads %d, barcode+site %d, clipped %d)"
       % (len(outs), n_file / dt / 1e6, n_file * cfg.record_bytes / dt / 1e9, outbytes / 1e9, *st))
-from oracle import tagdigger_oracle as po
-sample = open(src, "rb").read(100_000 * cfg.record_bytes)
-t0 = time.perf_counter(); po.barcode_splitter_bytes(sample, cfg.barcodes, cfg.cutsite, ad); dt = time.perf_counter() - t0
-print("python restatement      : %7.3f Mreads/s  (100 k reads, one core, index build included)" % (0.1 / dt))
 for o in outs: os.remove(o)
 os.remove(src)
