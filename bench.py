@@ -147,16 +147,17 @@ def main():
     # ---- correctness of what is being timed (rank-local shard, before any all-reduce)
     check = None
     if not args.no_check:
-        from helpers import synth_expected
+        # the whole matrix against the one the generator's own choices imply (built on the device from
+        # the shared spec include/td_synth_spec.h; nothing is parsed, nothing of oracle/ is involved)
         counts.zero_()
         eng.reset()
         eng.bind_counts(counts.data_ptr())
         eng.count_device(fastq.data_ptr(), nbytes, stream=stream)
         torch.cuda.synchronize()
-        got = counts.cpu().numpy().astype(np.int64).reshape(len(cfg.barcodes), len(cfg.tags))
-        want, hits = synth_expected(cfg, first_read, cfg.nreads)
+        want = torch.zeros_like(counts)
+        hits = cfg.expected_device(eng, want.data_ptr(), first_read, cfg.nreads)
         st = eng.stats()
-        ok = bool((got == want.astype(np.int64)).all()) and st["tag"] == hits and st["reads"] == cfg.nreads
+        ok = bool(torch.equal(counts, want)) and st["tag"] == hits and st["reads"] == cfg.nreads
         check = {"bit_exact_vs_expected": ok, "reads": int(st["reads"]), "barcut": int(st["barcut"]), "tag": int(st["tag"])}
         if not ok:
             print("bench.py: rank %d COUNT MISMATCH against the generator's expected matrix" % rank, file=sys.stderr)

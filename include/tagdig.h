@@ -201,6 +201,13 @@ int td_synth_fill_device(td_handle *h, const void *params /* td_synth_params* */
                          const char *tag_tab, const uint16_t *tag_len,
                          void *d_out, void *stream);
 
+/* The count matrix that stream implies by the generator's own choices (td_synth_hit: read i is a
+ * counted hit of barcode j and tag k), ADDED to d_counts (uint32 [nbar][ntags]); *hits_out = hits.
+ * What the bench checks the counting kernels against at full size, without parsing any FASTQ. */
+int td_synth_expected_device(td_handle *h, const void *params /* td_synth_params* */,
+                             uint64_t first_read, uint64_t nreads, uint32_t *d_counts,
+                             uint64_t *hits_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,7 @@ def load():
     sig("td_memcpy_d2h", i32, vp, vp, vp, u64)
     sig("td_device_sync", i32, vp)
     sig("td_synth_fill_device", i32, vp, vp, u64, u64, C.c_char_p, vp, C.c_char_p, C.c_char_p, vp, vp, vp)
+    sig("td_synth_expected_device", i32, vp, vp, u64, u64, vp, C.POINTER(u64), vp)
     _lib = L
     return L
 
@@ -130,7 +131,7 @@ EXPORTS = [
     "td_bind_counts", "td_reset", "td_count_device", "td_count_host", "td_count_file",
     "td_count_lines_device", "td_gunzip_file", "td_set_splitter", "td_split_device", "td_split_file", "td_get_counts", "td_get_stats", "td_set_option",
     "td_kernel_time_ms", "td_debug_counters", "td_dev_alloc", "td_dev_free", "td_memcpy_h2d", "td_memcpy_d2h",
-    "td_device_sync", "td_synth_fill_device",
+    "td_device_sync", "td_synth_fill_device", "td_synth_expected_device",
 ]
 
 

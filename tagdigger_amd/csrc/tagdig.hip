@@ -994,6 +994,16 @@ __global__ void k_synth(td_synth_params P, uint64_t first_read, uint64_t nreads,
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (uint64_t)gridDim.x * blockDim.x)
         td_synth_record(&P, first_read + r, bar_tab, bar_len, cut_tab, tag_tab, tag_len, out + r * rb);
 }
+// the count matrix the generator's own choices imply (td_synth_hit): no FASTQ is parsed
+__global__ void k_synth_expected(td_synth_params P, uint64_t first_read, uint64_t nreads, uint32_t *counts,
+                                 unsigned long long *hits) {
+    unsigned long long mine = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t j, k;
+        if (td_synth_hit(&P, first_read + r, &j, &k)) { atomicAdd(counts + (size_t)j * P.ntags + k, 1u); mine++; }
+    }
+    if (mine) atomicAdd(hits, mine);
+}
 }  // namespace
 
 extern "C" {
@@ -1021,6 +1031,26 @@ int td_synth_fill_device(td_handle *h, const void *params, uint64_t first_read, 
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     (void)hipFree(d_bar); (void)hipFree(d_bl); (void)hipFree(d_cut); (void)hipFree(d_tag); (void)hipFree(d_tl);
+    return TD_OK;
+}
+
+int td_synth_expected_device(td_handle *h, const void *params, uint64_t first_read, uint64_t nreads,
+                             uint32_t *d_counts, uint64_t *hits_out, void *stream) {
+    if (!h || !params || !d_counts) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    const td_synth_params P = *(const td_synth_params *)params;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *d_hits = nullptr;
+    HIPCHK(hipMalloc((void **)&d_hits, 8));
+    HIPCHK(hipMemsetAsync(d_hits, 0, 8, s));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((nreads + 255) / 256, (uint64_t)h->num_cu * 32);
+    if (nreads) hipLaunchKernelGGL(k_synth_expected, dim3(grid), dim3(256), 0, s, P, first_read, nreads, d_counts, d_hits);
+    HIPCHK(hipGetLastError());
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, d_hits, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    (void)hipFree(d_hits);
+    if (hits_out) *hits_out = v;
     return TD_OK;
 }
 

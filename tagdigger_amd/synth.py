@@ -115,3 +115,12 @@ class SynthConfig:
         B.check(engine._L.td_synth_fill_device(engine._h, C.byref(P), first_read, nreads, self.bar_tab, bl,
                                                self.cut_tab, self.tag_tab, tl, C.c_void_p(d_ptr),
                                                C.c_void_p(stream) if stream else None))
+
+    def expected_device(self, engine, d_counts, first_read, nreads, stream=0):
+        """Add the matrix the generator's own choices imply (uint32 [barcodes][tags] at d_counts, device
+        memory) -- no FASTQ is parsed; returns the number of hits."""
+        P = self.params()
+        hits = C.c_uint64(0)
+        B.check(engine._L.td_synth_expected_device(engine._h, C.byref(P), first_read, nreads, C.c_void_p(d_counts),
+                                                   C.byref(hits), C.c_void_p(stream) if stream else None))
+        return hits.value

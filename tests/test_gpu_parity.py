@@ -316,3 +316,25 @@ def test_byte_sharded_file_on_the_gpu(tmp_path):
         eng.close()
     assert multi.count_file_sharded(path, barcodes, tags, "TGCAG") == tf.find_tags_fastq(path, barcodes, tags, cutsite="TGCAG")
     assert multi.count_file_sharded(path, barcodes, tags, "TGCAG") == want.tolist()
+
+
+@pytest.mark.gpu
+def test_device_expected_matrix_equals_host_reference():
+    """td_synth_expected_device (what bench.py checks the kernels against) against the oracle side's
+    synth_expected for the same shard of the canonical stream."""
+    import tagdigger_amd
+    from tagdigger_amd.synth import SynthConfig
+    from helpers import synth_expected
+    cfg = SynthConfig(nreads=500_000, nbar=24, nmarkers=300, seed=9, cutsite="CWGC", bclen=(4, 10))
+    eng = tagdigger_amd.Engine(0)
+    try:
+        n = len(cfg.barcodes) * len(cfg.tags)
+        d = eng.dev_alloc(n * 4)
+        eng.h2d(d, bytes(n * 4))
+        hits = cfg.expected_device(eng, d, 12345, cfg.nreads)
+        got = np.frombuffer(eng.d2h(d, n * 4), dtype=np.uint32).reshape(len(cfg.barcodes), len(cfg.tags))
+        eng.dev_free(d)
+        want, whits = synth_expected(cfg, 12345, cfg.nreads)
+        assert hits == whits and (got == want).all()
+    finally:
+        eng.close()

@@ -3,7 +3,7 @@
 general terminator / packing forms) and lower-case bases.  Result compared with the LF original."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import numpy as np
 import tagdigger_amd
 from tagdigger_amd.synth import SynthConfig

@@ -5,7 +5,7 @@ from a file (td_split_file: read, H2D, decide, D2H, host writes the clipped reco
 restatement of the same loop is timed by tests/test_splitter.py::test_splitter_cpu_restatement_rate.)"""
 import contextlib, io, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import tagdigger_amd
 from tagdigger_amd import tagdigger_fun as tf
 from tagdigger_amd.synth import SynthConfig

@@ -4,11 +4,10 @@ T2 host buffer -> pinned staging -> hipMemcpyAsync overlapped with counting (td_
 T3 end to end from a file, plain, gzip (fast_inflate.hpp on one host thread) and BGZF (member-parallel)."""
 import gzip, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import numpy as np
 import tagdigger_amd
 from tagdigger_amd.synth import SynthConfig
-from helpers import synth_expected
 
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 cfg = SynthConfig(nreads=reads, nbar=384, nmarkers=50_000, seed=3)
@@ -18,8 +17,12 @@ d = eng.dev_alloc(nb)
 cfg.fill_device(eng, d, 0, reads)
 host = eng.d2h(d, nb)
 eng.dev_free(d)
-want, _ = synth_expected(cfg, 0, reads)
 eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+d_want = eng.dev_alloc(len(cfg.barcodes) * len(cfg.tags) * 4)
+eng.h2d(d_want, bytes(len(cfg.barcodes) * len(cfg.tags) * 4))
+cfg.expected_device(eng, d_want, 0, reads)            # the matrix the generator's own choices imply
+want = np.frombuffer(eng.d2h(d_want, len(cfg.barcodes) * len(cfg.tags) * 4), dtype=np.uint32).reshape(len(cfg.barcodes), len(cfg.tags))
+eng.dev_free(d_want)
 
 def check():
     assert (eng.counts_numpy() == want).all()
@@ -40,7 +43,17 @@ tz = time.perf_counter() - t0
 eng.reset(); t0 = time.perf_counter(); eng.count_file(gzp); eng.sync(); dt = time.perf_counter() - t0; check()
 print("T3 gzip file     : %6.2f Mreads/s  %6.2f GB/s uncompressed (one thread: the library's own DEFLATE decoder, CRC-32 checked; %.2f GB gz, made in %.1f s)" % (
     reads / dt / 1e6, nb / dt / 1e9, os.path.getsize(gzp) / 1e9, tz))
-from helpers import bgzf_bytes
+def bgzf_bytes(data, block=0xFF00, level=6):
+    import struct, zlib
+    out = []
+    for i in range(0, len(data), block):
+        chunk = data[i:i + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp
+                   + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return b"".join(out)
 bz = plain + ".bgzf.gz"
 part = bytes(host[: (len(host) // 4 // cfg.record_bytes) * cfg.record_bytes])      # (python-side compression is slow: a quarter)
 t0 = time.perf_counter(); open(bz, "wb").write(bgzf_bytes(part, level=1)); tz = time.perf_counter() - t0
