@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A clean checkout has no libtagdig.so (built files stay out of history): build it once -- hipcc
+    cross-compiles for gfx950 without a GPU -- so that the C-ABI tests can load it."""
+    import subprocess
+    lib = os.path.join(ROOT, "tagdigger_amd", "libtagdig.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tagdigger_amd", "csrc")])
+
+
 def load_golden(name):
     with open(os.path.join(GOLDEN, name)) as fh:
         return json.load(fh)
