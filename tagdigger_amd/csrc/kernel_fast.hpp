@@ -16,11 +16,13 @@
 //
 // Per tile (tile = CPT*4 KiB, one workgroup of 256 threads; the next tile's bytes are already
 // in flight into registers while this one is processed):
-//   A  masks (line terminators) + 2-bit packing of every 16-byte chunk, all lanes   -> LDS
-//   B  block scan of terminator counts: in-tile ordinal of every terminator
-//   C  phase vote (LDS counters), or the given phase in fix-up mode
-//   D  each thread matches the wanted lines that start in its own 16*CPT-byte span
-//      (match_line: barcode directory in LDS, tag buckets in L2) and commits with atomics
+//   A  masks (line terminators) + 2-bit packing of every 16-byte chunk, all lanes   -> LDS;
+//      at its end the line each thread left PENDING in the previous tile is finished (its tag
+//      bucket has arrived meanwhile), the next tile's loads are issued, then the pending count
+//   B  block scan of terminator counts: in-tile ordinal of every terminator; each thread's vote
+//   C  phase vote (the waves' packed votes rotated by their running totals), or the given phase
+//   D  the tile's wanted lines, compacted through an LDS list so that all lanes work, are matched
+//      up to the tag-bucket loads (barcode directory in LDS, tag buckets in L2), which stay in flight
 #pragma once
 #include "kernels.hpp"
 
@@ -44,8 +46,8 @@ struct FParams {
 };
 
 // Wave priority per phase (KParams::prio: bits 1:0 phase A and the tile's end, 3:2 phases B-C,
-// 5:4 phase D, 7:6 the end of phase A: pending line, next tile's loads).  The short, serial, latency-bound phases (scan, vote, matching) run above the long
-// arithmetic one: a wave that gets through them sooner has its memory requests out sooner, and
+// 5:4 phase D, 7:6 the end of phase A: pending line, next tile's loads).  The short, serial,
+// latency-bound phases (scan, vote, matching) run above the long arithmetic one: a wave that gets through them sooner has its memory requests out sooner, and
 // phase A of the co-resident workgroups fills the issue slots it leaves.
 __device__ __forceinline__ void set_prio(uint32_t level) {
     if (level == 0) __builtin_amdgcn_s_setprio(0);
