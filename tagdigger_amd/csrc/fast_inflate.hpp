@@ -52,6 +52,33 @@ class FastInflate {
         return (long)done;
     }
 
+    // ---- pieces the chunk-parallel decoder (par_inflate.hpp) shares
+    // Huffman table entry: bits 0..7 code length (total bits to drop), 8..15 extra bits (or, for a
+    // pointer, the subtable's index width), 16..30 value (literal, base length, base distance or
+    // subtable start), flags in the top bits.
+    // literal/length table: F_LIT, F_SUB, F_EOB above a 13-bit value; distance table: D_SUB above a 15-bit value.
+    // F_LIT2: the primary index decodes TWO literals at once (first in bits 16..23, second in bits 8..15,
+    // both code lengths summed in bits 0..7) -- FASTQ bases have 2-3 bit codes
+    static constexpr uint32_t F_LIT = 1u << 31, F_SUB = 1u << 30, F_EOB = 1u << 29, F_LIT2 = 1u << 28, D_SUB = 1u << 31;
+    static constexpr int LTB = 11, DTB = 8;
+    static constexpr size_t LIT_ENTRIES = (1 << LTB) + 288 * 16, DIST_ENTRIES = (1 << DTB) + 32 * 128;
+    static const uint16_t *length_base() {
+        static const uint16_t t[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+        return t;
+    }
+    static const uint8_t *length_extra() {
+        static const uint8_t t[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+        return t;
+    }
+    static const uint16_t *dist_base() {
+        static const uint16_t t[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+        return t;
+    }
+    static const uint8_t *dist_extra() {
+        static const uint8_t t[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+        return t;
+    }
+
   private:
     // ---- staging: [HIST bytes of history | CAP bytes being produced | SLACK for over-long copies]
     static constexpr size_t HIST = 32768, CAP = 1 << 20, SLACK = 320;
@@ -70,16 +97,9 @@ class FastInflate {
     uint32_t stored_left_ = 0;
     uint32_t crc_ = 0, isize_ = 0;
     const char *err_ = "";
-    // ---- Huffman tables.  Entry: bits 0..7 code length (total bits to drop), 8..15 extra bits (or,
-    // for a pointer, the subtable's index width), 16..30 value (literal, base length, base distance
-    // or subtable start), flags in the top bits.
-    // literal/length table: F_LIT, F_SUB, F_EOB above a 13-bit value; distance table: D_SUB above a 15-bit value
-    // F_LIT2: the primary index decodes TWO literals at once (first in bits 16..23, second in bits 8..15,
-    // both code lengths summed in bits 0..7) -- FASTQ bases have 2-3 bit codes
-    static constexpr uint32_t F_LIT = 1u << 31, F_SUB = 1u << 30, F_EOB = 1u << 29, F_LIT2 = 1u << 28, D_SUB = 1u << 31;
-    static constexpr int LTB = 11, DTB = 8;
-    uint32_t lit_[(1 << LTB) + 288 * 16];
-    uint32_t dist_[(1 << DTB) + 32 * 128];
+    // ---- Huffman tables of the current block
+    uint32_t lit_[LIT_ENTRIES];
+    uint32_t dist_[DIST_ENTRIES];
 
     bool fail(const char *m) { err_ = m; return false; }
 
@@ -171,6 +191,7 @@ class FastInflate {
         x1 = _mm_xor_si128(x1, x2);
         return (uint32_t)_mm_extract_epi32(x1, 1);
     }
+  public:
     // zlib's convention (inverted going in and coming out)
     static uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n) {
         static const bool clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
@@ -187,23 +208,36 @@ class FastInflate {
         return crc;
     }
 
+  private:
+
     // ---- gzip framing
+  public:
+    // the member header at p: 1 and *body (the first byte of the deflate stream); 0 where the stream ends
+    // (trailing zero bytes some tools leave and anything that is not a gzip header end it, as zlib's gzread
+    // treats them); -1 and *err on a bad header
+    static int parse_member_header(const uint8_t *p, const uint8_t *end, const uint8_t **body, const char **err) {
+        if (p + 18 > end || p[0] != 0x1f || p[1] != 0x8b) return 0;
+        if (p[2] != 8) { *err = "unknown compression method in a gzip header"; return -1; }
+        const uint32_t flg = p[3];
+        if (flg & 0xE0) { *err = "reserved flag bits set in a gzip header"; return -1; }
+        p += 10;
+        if (flg & 4) { if (p + 2 > end) { *err = "truncated gzip header"; return -1; } p += 2 + (p[0] | (p[1] << 8)); }
+        if (flg & 8) { while (p < end && *p) p++; p++; }
+        if (flg & 16) { while (p < end && *p) p++; p++; }
+        if (flg & 2) p += 2;
+        if (p >= end) { *err = "truncated gzip header"; return -1; }
+        *body = p;
+        return 1;
+    }
+
+  private:
     bool member_header() {
         byte_align();
-        // trailing zero bytes (padding some tools leave) and anything that is not a gzip header end the stream,
-        // as zlib's gzread treats them
-        const uint8_t *p = in_;
-        if (p + 18 > in_end_ || p[0] != 0x1f || p[1] != 0x8b) { state_ = S_END; return true; }
-        if (p[2] != 8) return fail("unknown compression method in a gzip header");
-        const uint32_t flg = p[3];
-        if (flg & 0xE0) return fail("reserved flag bits set in a gzip header");
-        p += 10;
-        if (flg & 4) { if (p + 2 > in_end_) return fail("truncated gzip header"); p += 2 + (p[0] | (p[1] << 8)); }
-        if (flg & 8) { while (p < in_end_ && *p) p++; p++; }
-        if (flg & 16) { while (p < in_end_ && *p) p++; p++; }
-        if (flg & 2) p += 2;
-        if (p >= in_end_) return fail("truncated gzip header");
-        in_ = p;
+        const uint8_t *body = nullptr;
+        const int r = parse_member_header(in_, in_end_, &body, &err_);
+        if (r < 0) return false;
+        if (r == 0) { state_ = S_END; return true; }
+        in_ = body;
         crc_ = 0; isize_ = 0; member_done_ = false;
         crc_pos_ = wpos_;
         valid_from_ = wpos_;                                         // (a member cannot reach into the one before it)
@@ -223,9 +257,12 @@ class FastInflate {
         return true;
     }
 
-    // ---- table construction from code lengths (canonical Huffman, RFC 1951 3.2.2)
+  public:
+    // ---- table construction from code lengths (canonical Huffman, RFC 1951 3.2.2); `complete`
+    // (optional) reports whether the code uses its whole code space
     template <typename Make>
-    static bool build(uint32_t *table, int tb, const uint8_t *lens, int nsym, uint32_t sub_flag, Make &&make) {
+    static bool build(uint32_t *table, int tb, const uint8_t *lens, int nsym, uint32_t sub_flag, Make &&make,
+                      bool *complete = nullptr) {
         int count[16] = {0};
         for (int s = 0; s < nsym; s++) count[lens[s]]++;
         count[0] = 0;
@@ -239,6 +276,7 @@ class FastInflate {
             next[l] = code;
             if (count[l]) maxlen = l;
         }
+        if (complete) *complete = left == 0;
         const uint32_t psize = 1u << tb;
         for (uint32_t i = 0; i < psize; i++) table[i] = 0;          // 0 = invalid code
         uint32_t used = psize;
@@ -264,25 +302,26 @@ class FastInflate {
         }
         return true;
     }
-    bool build_tables(const uint8_t *ll, int nlit, const uint8_t *dl, int ndist) {
-        static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-        static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-        static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-        static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-        if (!build(lit_, LTB, ll, nlit, F_SUB, [&](int s, int l) -> uint32_t {
+    // both tables of a block from its code lengths; false: over-subscribed.  pair_literals: see F_LIT2
+    static bool build_block_tables(uint32_t *lit, uint32_t *dist, const uint8_t *ll, int nlit, const uint8_t *dl, int ndist,
+                                   bool pair_literals, bool *lit_complete = nullptr, bool *dist_complete = nullptr) {
+        const uint16_t *lbase = length_base(), *dbase = dist_base();
+        const uint8_t *lext = length_extra(), *dext = dist_extra();
+        if (!build(lit, LTB, ll, nlit, F_SUB, [&](int s, int l) -> uint32_t {
                 if (s < 256) return F_LIT | ((uint32_t)s << 16) | (uint32_t)l;
                 if (s == 256) return F_EOB | (uint32_t)l;
                 if (s > 285) return 0;                              // (never valid in a stream)
                 return ((uint32_t)lbase[s - 257] << 16) | ((uint32_t)lext[s - 257] << 8) | (uint32_t)l;
-            })) return fail("over-subscribed literal/length code");
-        if (!build(dist_, DTB, dl, ndist, D_SUB, [&](int s, int l) -> uint32_t {
+            }, lit_complete)) return false;
+        if (!build(dist, DTB, dl, ndist, D_SUB, [&](int s, int l) -> uint32_t {
                 if (s > 29) return 0;
                 return ((uint32_t)dbase[s] << 16) | ((uint32_t)dext[s] << 8) | (uint32_t)l;
-            })) return fail("over-subscribed distance code");
+            }, dist_complete)) return false;
+        if (!pair_literals) return true;
         // pair up literals: where the bits left in a primary index after one literal decode a second
         // literal completely, the entry yields both
         uint32_t single[1u << LTB];
-        memcpy(single, lit_, sizeof(single));
+        memcpy(single, lit, sizeof(single));
         for (uint32_t i = 0; i < (1u << LTB); i++) {
             const uint32_t e = single[i];
             if (!(e & F_LIT)) continue;
@@ -290,8 +329,14 @@ class FastInflate {
             const uint32_t e2 = single[i >> l1];          // (index: the stream's next LTB - l1 bits, zeros above them)
             const uint32_t l2 = e2 & 0xFF;
             if ((e2 & F_LIT) && l1 + l2 <= (uint32_t)LTB)  // decided by those bits alone
-                lit_[i] = F_LIT | F_LIT2 | (e & 0x00FF0000u) | (((e2 >> 16) & 0xFFu) << 8) | (l1 + l2);
+                lit[i] = F_LIT | F_LIT2 | (e & 0x00FF0000u) | (((e2 >> 16) & 0xFFu) << 8) | (l1 + l2);
         }
+        return true;
+    }
+
+  private:
+    bool build_tables(const uint8_t *ll, int nlit, const uint8_t *dl, int ndist) {
+        if (!build_block_tables(lit_, dist_, ll, nlit, dl, ndist, true)) return fail("over-subscribed Huffman code");
         return true;
     }
 

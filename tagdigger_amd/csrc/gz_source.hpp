@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "fast_inflate.hpp"
+#include "par_inflate.hpp"
 
 namespace tdhost {
 
@@ -28,6 +29,8 @@ namespace tdhost {
 struct GzSource {
     gzFile zf = nullptr;        // plain gzip through zlib
     FastInflate fi;             // plain gzip through the decoder of fast_inflate.hpp, over a mapping of the file
+    ParInflate pi;              // ... or through the chunk-parallel decoder of par_inflate.hpp
+    bool use_pi = false;
     uint8_t *map = nullptr;
     size_t map_len = 0;
     bool use_fi = false;
@@ -68,14 +71,14 @@ struct GzSource {
             return true;
         }
         fclose(f);
-        if (!getenv("TAGDIG_ZLIB") && map_file(path)) return true;
+        if (!getenv("TAGDIG_ZLIB") && map_file(path, want)) return true;
         zf = gzopen(path, "rb");
         if (zf) gzbuffer(zf, 1 << 20);
         return zf != nullptr;
     }
     // the file followed by at least FastInflate::PAD readable zero bytes: an anonymous mapping one
     // page longer than the file, the file mapped over its beginning
-    bool map_file(const char *path) {
+    bool map_file(const char *path, int want_threads) {
         const int fd = ::open(path, O_RDONLY);
         if (fd < 0) return false;
         struct stat sb;
@@ -90,20 +93,29 @@ struct GzSource {
         if (over == MAP_FAILED) { munmap(base, total); return false; }
         (void)madvise(base, n, MADV_SEQUENTIAL);
         map = (uint8_t *)base; map_len = total;
-        fi.open(map, n);
-        use_fi = true;
+        const char *par = getenv("TAGDIG_PAR_INFLATE");
+        if (par && atoi(par) > 0 && want_threads > 1) {
+            const char *cb = getenv("TAGDIG_INFLATE_CHUNK");
+            pi.open(map, n, want_threads, cb ? (size_t)atol(cb) : (size_t)2 << 20);
+            use_pi = true;
+        } else {
+            fi.open(map, n);
+            use_fi = true;
+        }
         return true;
     }
     void close() {
+        pi.close();
         if (zf) gzclose(zf);
         if (bf) fclose(bf);
         if (map) munmap(map, map_len);
-        zf = nullptr; bf = nullptr; map = nullptr; use_fi = false;
+        zf = nullptr; bf = nullptr; map = nullptr; use_fi = false; use_pi = false;
     }
     ~GzSource() { close(); }
 
     // up to `want` uncompressed bytes into dst; 0 at the end, < 0 on error
     long read(uint8_t *dst, size_t want) {
+        if (use_pi) return pi.read(dst, want);
         if (use_fi) return fi.read(dst, want);
         if (zf) return gzread(zf, dst, (unsigned)std::min<size_t>(want, 1u << 30));
         if (bad) return -1;

@@ -1,0 +1,622 @@
+// Chunk-parallel decoder for ordinary (single-stream) gzip on the host side of libtagdig (no GPU code).
+//
+// A DEFLATE stream has no index, and a block may copy from the 32 KiB before it, so a stream is
+// normally decoded by one thread.  This decoder works through the compressed file in batches of one
+// chunk per thread:
+//   1. every thread but the first looks for a block start inside its chunk: it tries bit positions
+//      in turn for a non-final dynamic-Huffman header that only a compressor would write (all three
+//      codes complete), decodes that block, and requires a second valid header behind it;
+//   2. it then decodes from there into 16-bit symbols: literals as themselves, and a copy that reaches
+//      into the unknown 32 KiB before the chunk as a marker 0x8000 | position-in-that-window (markers
+//      are copied around like literals).  The first thread starts at the known position with the
+//      known window and decodes bytes.  Every thread stops at the first block boundary at or past the
+//      start its successor found;
+//   3. the chunks are chained on the calling thread: a chunk counts only if its predecessor stopped
+//      exactly on its start (so a false start from step 1 is dropped with everything behind it, and
+//      the next batch begins where the chain ended -- the result never depends on the search), and
+//      each chunk's window follows from its predecessor's window and last 32 KiB;
+//   4. all threads turn markers into bytes and take the CRC-32 of their part; the parts' CRCs are
+//      combined, and CRC and length of every member are checked.
+// Batches are decoded ahead of the reader by a producer thread (two output buffers), so read() is a
+// copy that overlaps the next batch.
+// Files without findable block starts (stored or fixed-Huffman blocks only) are decoded by the first
+// thread alone.  After: Kerbiriou & Chikhi, "Parallel decompression of gzip-compressed files and random
+// access to DNA sequences" (2019), without its text heuristics -- step 3 makes the search exact.
+#pragma once
+#include <emmintrin.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "fast_inflate.hpp"
+
+namespace tdhost {
+
+class ParInflate {
+  public:
+    static constexpr size_t PAD = FastInflate::PAD;          // readable bytes the caller guarantees behind the input
+    struct Stats { uint64_t batches = 0, chunks = 0, dropped = 0, rejected = 0; double t_decode = 0, t_chain = 0, t_resolve = 0, t_find = 0, t_busy = 0; } stats;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+    ~ParInflate() { close(); }
+    void open(const uint8_t *data, size_t n, int threads, size_t chunk_bytes) {
+        close();
+        data_ = data; n_ = n;
+        threads_ = std::max(1, std::min(threads, 64));
+        chunk_ = std::max<size_t>(chunk_bytes, 1024);
+        cap_ = std::max<size_t>(chunk_ * 48, (size_t)1 << 22);
+        cur_ = threads_;
+        chunks_.reset(new Chunk[threads_]);
+        failed_ = false; end_ = false; err_ = "";
+        member_out_ = 0; crc_ = 0;
+        stats = Stats();
+        for (Slot &o : slot_) { o.len = o.pos = 0; o.ready = false; o.last = false; o.failed = false; }
+        rd_ = 0; stop_ = false; drained_ = false; read_failed_ = false;
+        begin_member(0);
+    }
+    // stops the producer (the input must stay mapped until then)
+    void close() {
+        if (producer_.joinable()) {
+            { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+            cv_.notify_all();
+            producer_.join();
+        }
+    }
+    const char *error() const { return err_; }
+
+    // up to `want` decompressed bytes into dst; 0 at the end of the stream, < 0 on error
+    long read(uint8_t *dst, size_t want) {
+        if (!producer_.joinable() && !drained_) producer_ = std::thread([this]() { produce(); });
+        size_t done = 0;
+        while (done < want) {
+            if (read_failed_) return done ? (long)done : -1;
+            if (drained_) break;
+            Slot &o = slot_[rd_];
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&]() { return o.ready; });
+            }
+            const size_t n = std::min(want - done, o.len - o.pos);
+            memcpy(dst + done, o.b.p + o.pos, n);
+            o.pos += n; done += n;
+            if (o.pos == o.len) {
+                if (o.failed) read_failed_ = true;
+                else if (o.last) drained_ = true;
+                else {
+                    { std::lock_guard<std::mutex> g(mu_); o.ready = false; }
+                    cv_.notify_all();
+                    rd_ ^= 1;
+                }
+            }
+        }
+        return (long)done;
+    }
+
+  private:
+    using FI = FastInflate;
+    static constexpr uint32_t WIN = 32768;
+    static constexpr uint64_t PENDING = ~0ull, NONE = ~0ull - 1;
+
+    template <typename T>
+    struct Buf {                                              // (uninitialised storage that can grow)
+        T *p = nullptr; size_t cap = 0;
+        ~Buf() { free(p); }
+        void reserve(size_t n) {
+            if (n <= cap) return;
+            T *q = (T *)realloc(p, n * sizeof(T));
+            if (!q) abort();
+            p = q; cap = n;
+        }
+    };
+    struct Tables { uint32_t lit[FI::LIT_ENTRIES]; uint32_t dist[FI::DIST_ENTRIES]; };
+
+    // the stream's next bits in the low end of a 64-bit word (as in FastInflate)
+    struct Bits {
+        const uint8_t *in = nullptr;
+        uint64_t buf = 0; uint32_t cnt = 0;
+        static uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+        void seek(const uint8_t *base, uint64_t bitpos) {
+            in = base + (bitpos >> 3); buf = 0; cnt = 0;
+            refill();
+            buf >>= (bitpos & 7); cnt -= (uint32_t)(bitpos & 7);
+        }
+        uint64_t bitpos(const uint8_t *base) const { return (uint64_t)(in - base) * 8 - cnt; }
+        void refill() { buf |= load64(in) << cnt; in += (63 - cnt) >> 3; cnt |= 56; }
+        uint32_t bits(uint32_t n) { const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1)); buf >>= n; cnt -= n; return v; }
+        void drop(uint32_t n) { buf >>= n; cnt -= n; }
+    };
+
+    struct Chunk {
+        uint64_t search_from = 0, search_to = 0;     // its territory in bits (first chunk: search_from is its exact start)
+        std::atomic<uint64_t> start{PENDING};        // the first block it decodes (bit position), or NONE
+        uint64_t stop = 0;                           // the block boundary it stopped on
+        bool member_done = false, failed = false;
+        const char *err = "";
+        int next = 0;                                // the chunk whose start it is heading for
+        Buf<uint16_t> wide; Buf<uint8_t> narrow;     // [WIN elements before the chunk | its output]
+        size_t out_len = 0;
+        size_t valid_back = 0;                       // how far before the chunk a copy may reach (elements)
+        std::unique_ptr<Tables> tables;
+        // after chaining
+        uint8_t window[WIN];                         // the 32 KiB of output before it
+        uint64_t member_before = 0;                  // bytes of the current member before it
+        uint8_t *dest = nullptr;
+        uint32_t crc = 0;
+        bool bad_marker = false;
+    };
+
+    const uint8_t *data_ = nullptr; size_t n_ = 0;
+    int threads_ = 1, cur_ = 1, nch_ = 0;
+    size_t chunk_ = 0, cap_ = 0;
+    std::unique_ptr<Chunk[]> chunks_;
+    uint64_t pos_ = 0;                               // bit position of the next block of the current member
+    uint64_t batch_end_ = 0;
+    uint64_t member_out_ = 0; uint32_t crc_ = 0;
+    uint8_t window_[WIN];
+    bool failed_ = false, end_ = false;              // (producer side)
+    const char *err_ = "";
+    // the two output buffers between the producer and read()
+    struct Slot { Buf<uint8_t> b; size_t len = 0, pos = 0; bool ready = false, last = false, failed = false; } slot_[2];
+    std::thread producer_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+    int rd_ = 0;
+    bool drained_ = false, read_failed_ = false;     // (reader side)
+
+    void produce() {
+        for (int w = 0;; w ^= 1) {
+            Slot &o = slot_[w];
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&]() { return !o.ready || stop_; });
+                if (stop_) return;
+            }
+            o.len = o.pos = 0;
+            if (!failed_ && !end_) batch(o);
+            o.failed = failed_; o.last = failed_ || end_;
+            const bool fin = o.last;
+            { std::lock_guard<std::mutex> g(mu_); o.ready = true; }
+            cv_.notify_all();
+            if (fin) return;
+        }
+    }
+
+    void begin_member(size_t at_byte) {
+        const uint8_t *body = nullptr;
+        const int r = FI::parse_member_header(data_ + at_byte, data_ + n_, &body, &err_);
+        if (r < 0) { failed_ = true; return; }
+        if (r == 0) { end_ = true; return; }
+        pos_ = (uint64_t)(body - data_) * 8;
+        member_out_ = 0; crc_ = 0;
+    }
+
+    // ---- block headers.  strict: accept only what a compressor writes (complete codes)
+    enum { H_BAD = -1, H_STORED = 0, H_FIXED = 1, H_DYNAMIC = 2 };
+    int block_header(Bits &b, Tables &t, bool strict, bool &final, uint32_t &stored_len, const char *&err) const {
+        if (b.in > data_ + n_ + 16) { err = "truncated deflate stream"; return H_BAD; }
+        b.refill();
+        final = b.bits(1) != 0;
+        const uint32_t type = b.bits(2);
+        if (type == 0) {
+            b.drop(b.cnt & 7);
+            if (b.cnt < 32) b.refill();
+            const uint32_t len = b.bits(16), nlen = b.bits(16);
+            if ((len ^ 0xFFFFu) != nlen) { err = "stored block length check failed"; return H_BAD; }
+            stored_len = len;
+            return H_STORED;
+        }
+        if (type == 1) {
+            uint8_t ll[288], dl[30];
+            for (int i = 0; i < 144; i++) ll[i] = 8;
+            for (int i = 144; i < 256; i++) ll[i] = 9;
+            for (int i = 256; i < 280; i++) ll[i] = 7;
+            for (int i = 280; i < 288; i++) ll[i] = 8;
+            for (int i = 0; i < 30; i++) dl[i] = 5;
+            FI::build_block_tables(t.lit, t.dist, ll, 288, dl, 30, true);
+            return H_FIXED;
+        }
+        if (type == 3) { err = "reserved deflate block type"; return H_BAD; }
+        const uint32_t nlit = b.bits(5) + 257, ndist = b.bits(5) + 1, nclen = b.bits(4) + 4;
+        if (nlit > 286 || ndist > 30) { err = "too many length or distance codes"; return H_BAD; }
+        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        uint8_t cl[19] = {0};
+        b.refill();
+        for (uint32_t i = 0; i < nclen; i++) { if (b.cnt < 8) b.refill(); cl[order[i]] = (uint8_t)b.bits(3); }
+        uint32_t cltab[128 + 19];
+        bool complete = false;
+        if (!FI::build(cltab, 7, cl, 19, FI::F_SUB, [&](int s, int l) -> uint32_t { return ((uint32_t)s << 16) | (uint32_t)l; }, &complete)) {
+            err = "over-subscribed code-length code"; return H_BAD;
+        }
+        if (strict && !complete) return H_BAD;
+        uint8_t lens[286 + 30];
+        uint32_t i = 0;
+        while (i < nlit + ndist) {
+            b.refill();
+            if (b.in > data_ + n_ + 16) { err = "truncated deflate stream"; return H_BAD; }
+            const uint32_t e = cltab[b.buf & 127];
+            if (!(e & 0xFF)) { err = "invalid code-length code"; return H_BAD; }
+            b.drop(e & 0xFF);
+            const uint32_t s = e >> 16;
+            if (s < 16) { lens[i++] = (uint8_t)s; continue; }
+            uint32_t rep, val = 0;
+            if (s == 16) { if (i == 0) { err = "repeat with no previous length"; return H_BAD; } val = lens[i - 1]; rep = 3 + b.bits(2); }
+            else if (s == 17) rep = 3 + b.bits(3);
+            else rep = 11 + b.bits(7);
+            if (i + rep > nlit + ndist) { err = "code lengths run past the end"; return H_BAD; }
+            while (rep--) lens[i++] = (uint8_t)val;
+        }
+        if (lens[256] == 0) { err = "no end-of-block code"; return H_BAD; }
+        if (strict) {                                            // (before the tables are built: most guesses end here)
+            uint32_t lsum = 0, dsum = 0, used = 0;
+            for (uint32_t k = 0; k < nlit; k++) lsum += lens[k] ? 32768u >> lens[k] : 0;
+            for (uint32_t k = 0; k < ndist; k++) { dsum += lens[nlit + k] ? 32768u >> lens[nlit + k] : 0; used += lens[nlit + k] != 0; }
+            if (lsum != 32768u || !(dsum == 32768u || used <= 1)) return H_BAD;
+        }
+        if (!FI::build_block_tables(t.lit, t.dist, lens, (int)nlit, lens + nlit, (int)ndist, true)) {
+            err = "over-subscribed Huffman code"; return H_BAD;
+        }
+        return H_DYNAMIC;
+    }
+
+    // the first bit position in [p, to) where a non-final dynamic block with a complete code-length
+    // code could begin (its first 17 + 3 * nclen bits say so); `to` if there is none
+    uint64_t next_plausible(uint64_t p, uint64_t to) const {
+        static const KraftTable kraft;
+        for (uint64_t q = p >> 3; q * 8 < to; q++) {
+            const uint64_t v = Bits::load64(data_ + q);
+            // BFINAL = 0, BTYPE = 2: bits 0, 0, 1 -- for all eight starts in this byte at once
+            uint32_t m = (uint32_t)(~v & ~(v >> 1) & (v >> 2)) & 0xFFu;
+            if (q * 8 < p) m &= 0xFFu << (p - q * 8);
+            while (m) {
+                const uint32_t sh = (uint32_t)__builtin_ctz(m);
+                m &= m - 1;
+                const uint64_t x = v >> sh;
+                if (((x >> 3) & 31) > 29 || ((x >> 8) & 31) > 29) continue;
+                const uint32_t nclen = (uint32_t)((x >> 13) & 15) + 4;
+                const uint64_t at = q * 8 + sh + 17;
+                uint64_t w = (Bits::load64(data_ + (at >> 3)) >> (at & 7)) & ((1ull << (3 * nclen)) - 1);
+                uint32_t sum = 0;
+                for (int j = 0; j < 7; j++, w >>= 9) sum += kraft.t[w & 511];
+                if (sum == 128 && q * 8 + sh < to) return q * 8 + sh;
+            }
+        }
+        return to;
+    }
+    struct KraftTable {                                        // three 3-bit code lengths -> their sum of 2^(7 - length)
+        uint8_t t[512];
+        KraftTable() {
+            for (uint32_t i = 0; i < 512; i++) {
+                uint32_t s = 0;
+                for (uint32_t k = 0; k < 3; k++) { const uint32_t l = (i >> (3 * k)) & 7; s += l ? 128u >> l : 0; }
+                t[i] = (uint8_t)std::min(s, 255u);
+            }
+        }
+    };
+
+    template <typename T> static Buf<T> &buffer(Chunk &c);
+
+    // ---- one Huffman block into out (growing the buffer as needed).  0: ended on its end-of-block code
+    template <typename T>
+    int huff_block(Bits &b, const Tables &t, Buf<T> &buf, T *&out, size_t valid_back, size_t limit, const char *&err) const {
+        const uint64_t lmask = (1u << FI::LTB) - 1, dmask = (1u << FI::DTB) - 1;
+        const uint8_t *const in_stop = data_ + n_ + 16;
+        constexpr size_t MARGIN = 320;
+        T *out_stop = buf.p + buf.cap - MARGIN;
+        const T *begin = buf.p + WIN - valid_back;
+        for (;;) {
+            if (out >= out_stop) {
+                const size_t off = (size_t)(out - buf.p);
+                if (off > limit) { err = "block too long"; return -1; }
+                buf.reserve(buf.cap + buf.cap / 2);
+                out = buf.p + off; out_stop = buf.p + buf.cap - MARGIN; begin = buf.p + WIN - valid_back;
+            }
+            if (b.in > in_stop) { err = "truncated deflate stream"; return -1; }
+            b.refill();
+            uint32_t e = t.lit[b.buf & lmask];
+            if (e & FI::F_SUB) e = t.lit[((e >> 16) & 0x1FFFu) + (uint32_t)((b.buf >> FI::LTB) & ((1u << ((e >> 8) & 0xFF)) - 1))];
+            if (e & FI::F_LIT) {
+                b.drop(e & 0xFF);
+                out[0] = (T)(uint8_t)(e >> 16); out[1] = (T)(uint8_t)(e >> 8);
+                out += 1 + ((e >> 28) & 1u);
+                uint32_t e2 = t.lit[b.buf & lmask];
+                if (e2 & FI::F_LIT) {
+                    b.drop(e2 & 0xFF);
+                    out[0] = (T)(uint8_t)(e2 >> 16); out[1] = (T)(uint8_t)(e2 >> 8);
+                    out += 1 + ((e2 >> 28) & 1u);
+                    e2 = t.lit[b.buf & lmask];
+                    if (e2 & FI::F_LIT) {
+                        b.drop(e2 & 0xFF);
+                        out[0] = (T)(uint8_t)(e2 >> 16); out[1] = (T)(uint8_t)(e2 >> 8);
+                        out += 1 + ((e2 >> 28) & 1u);
+                    }
+                }
+                continue;
+            }
+            const uint32_t clen = e & 0xFF;
+            if (clen == 0) { err = "invalid literal/length code"; return -1; }
+            b.drop(clen);
+            if (e & FI::F_EOB) return 0;
+            const uint32_t lext = (e >> 8) & 0xFF;
+            const uint32_t length = ((e >> 16) & 0x1FF) + (uint32_t)(b.buf & ((1u << lext) - 1));
+            b.drop(lext);
+            if (b.cnt < 32) b.refill();
+            uint32_t d = t.dist[b.buf & dmask];
+            if (d & FI::D_SUB) d = t.dist[((d >> 16) & 0x1FFFu) + (uint32_t)((b.buf >> FI::DTB) & ((1u << ((d >> 8) & 0xFF)) - 1))];
+            const uint32_t dlen = d & 0xFF;
+            if (dlen == 0) { err = "invalid distance code"; return -1; }
+            b.drop(dlen);
+            const uint32_t dext = (d >> 8) & 0xFF;
+            const uint32_t distance = ((d >> 16) & 0x7FFF) + (uint32_t)(b.buf & ((1u << dext) - 1));
+            b.drop(dext);
+            if (distance > (size_t)(out - begin)) { err = "distance reaches before the start of the output"; return -1; }
+            const T *src = out - distance;
+            T *const end = out + length;
+            constexpr uint32_t W = 16 / sizeof(T);               // elements per 16-byte copy
+            if (distance >= 16) {
+                do { memcpy(out, src, 16 * sizeof(T)); out += 16; src += 16; } while (out < end);
+            } else if (distance >= W) {
+                do { memcpy(out, src, 16); out += W; src += W; } while (out < end);
+            } else if (distance == 1) {
+                const T v = *src;
+                T pat[W];
+                for (uint32_t k = 0; k < W; k++) pat[k] = v;
+                do { memcpy(out, pat, 16); out += W; } while (out < end);
+            } else {
+                // a short period: lay the pattern down by elements until a multiple of the period that is at
+                // least W lies behind, then copy from that far back sixteen bytes at a time
+                T *q = out;
+                const uint32_t head = distance * ((W - 1 + distance) / distance);
+                for (uint32_t k = 0; k < head && q < end; k++) *q++ = *src++;
+                if (q < end) {
+                    const T *s2 = q - head;
+                    do { memcpy(q, s2, 16); q += W; s2 += W; } while (q < end);
+                }
+            }
+            out = end;
+        }
+    }
+
+    // has chunk k, at block boundary `here` with `produced` elements out, reached where it should stop?
+    bool should_stop(int k, uint64_t here, size_t produced) {
+        Chunk &c = chunks_[k];
+        if (produced > cap_) return true;
+        if (here < c.search_to) return false;
+        while (c.next < nch_) {
+            std::atomic<uint64_t> &a = chunks_[c.next].start;
+            uint64_t s = a.load(std::memory_order_acquire);
+            while (s == PENDING) { std::this_thread::yield(); s = a.load(std::memory_order_acquire); }
+            if (s == NONE) { c.next++; continue; }
+            return here >= s;
+        }
+        return here >= batch_end_;
+    }
+
+    // decodes chunk k from bit p.  verify: p is a guess -- 1 when it turns out not to be a block start
+    // (nothing has been published then); otherwise 0 with the chunk's results filled in
+    template <typename T>
+    int decode_from(int k, uint64_t p, bool verify) {
+        Chunk &c = chunks_[k];
+        Buf<T> &buf = buffer<T>(c);
+        Tables &t = *c.tables;
+        Bits b;
+        b.seek(data_, p);
+        T *out = buf.p + WIN;
+        size_t nblocks = 0;
+        bool published = !verify;
+        const char *err = "";
+        for (;;) {
+            const uint64_t here = b.bitpos(data_);
+            if (verify && nblocks == 1) {                          // a second header must follow the first block
+                Bits b2 = b;
+                bool f2; uint32_t s2 = 0;
+                if (block_header(b2, t, true, f2, s2, err) == H_BAD) return 1;
+                c.start.store(p, std::memory_order_release);
+                published = true;
+            }
+            if (nblocks > 0 && should_stop(k, here, (size_t)(out - buf.p) - WIN)) { c.stop = here; break; }
+            bool final = false; uint32_t slen = 0;
+            const int h = block_header(b, t, verify && nblocks == 0, final, slen, err);
+            if (h == H_BAD || (!published && (h != H_DYNAMIC || final))) {
+                if (!published) return 1;
+                c.failed = true; c.err = err; c.stop = here; break;
+            }
+            if (h == H_STORED) {
+                const uint8_t *s = b.in - (b.cnt >> 3);
+                if (s + slen > data_ + n_) { c.failed = true; c.err = "truncated stored block"; c.stop = here; break; }
+                const size_t off = (size_t)(out - buf.p);
+                buf.reserve(off + slen + 1024);
+                out = buf.p + off;
+                for (uint32_t i = 0; i < slen; i++) out[i] = (T)s[i];
+                out += slen;
+                b.in = s + slen; b.buf = 0; b.cnt = 0;
+            } else {
+                const size_t limit = published ? ~(size_t)0 : WIN + ((size_t)1 << 22);
+                if (huff_block<T>(b, t, buf, out, c.valid_back, limit, err) != 0) {
+                    if (!published) return 1;
+                    c.failed = true; c.err = err; c.stop = here; break;
+                }
+            }
+            nblocks++;
+            if (final) { c.member_done = true; c.stop = b.bitpos(data_); break; }
+        }
+        c.out_len = (size_t)(out - buf.p) - WIN;
+        return 0;
+    }
+
+    void run_chunk(int k) {
+        Chunk &c = chunks_[k];
+        if (!c.tables) c.tables.reset(new Tables);
+        if (k == 0) {
+            c.narrow.reserve(WIN + chunk_ * 6 + 4096);
+            memcpy(c.narrow.p, window_, WIN);
+            c.valid_back = (size_t)std::min<uint64_t>(WIN, member_out_);
+            c.start.store(c.search_from, std::memory_order_release);
+            decode_from<uint8_t>(0, c.search_from, false);
+            return;
+        }
+        c.wide.reserve(WIN + chunk_ * 6 + 4096);
+        for (uint32_t i = 0; i < WIN; i++) c.wide.p[i] = (uint16_t)(0x8000u | i);
+        c.valid_back = WIN;
+        uint64_t rejected = 0;
+        const double t0 = now();
+        for (uint64_t p = c.search_from; (p = next_plausible(p, c.search_to)) < c.search_to; p++) {
+            const double t1 = now();
+            if (decode_from<uint16_t>(k, p, true) == 0) {
+                rejected_.fetch_add(rejected);
+                std::lock_guard<std::mutex> g(mu_);
+                stats.t_find += t1 - t0; stats.t_busy += now() - t1;
+                return;
+            }
+            rejected++;
+        }
+        rejected_.fetch_add(rejected);
+        c.start.store(NONE, std::memory_order_release);
+    }
+    std::atomic<uint64_t> rejected_{0};
+
+    template <typename F>
+    void parallel(int n, F &&fn) {
+        if (n <= 0) return;
+        std::vector<std::thread> pool;
+        for (int i = 1; i < n; i++) pool.emplace_back([&fn, i]() { fn(i); });
+        fn(0);
+        for (auto &t : pool) t.join();
+    }
+
+    // markers -> bytes through a 64 Ki-entry table (a literal is its own entry, marker 0x8000 | i is the
+    // window's byte i), sixteen marker-free symbols at a time by a pack.  min_idx: window positions below
+    // it lie before the member's start, and a marker pointing there makes the stream invalid
+    static bool resolve(const uint16_t *src, size_t n, const uint8_t *win, uint8_t *dst, uint32_t min_idx) {
+        std::unique_ptr<uint8_t[]> lut(new uint8_t[65536]);
+        for (uint32_t v = 0; v < 256; v++) lut[v] = (uint8_t)v;
+        memcpy(lut.get() + 0x8000, win, WIN);
+        bool ok = true;
+        if (min_idx) {                                           // (only in the first 32 KiB of a member)
+            for (size_t i = 0; i < n; i++) ok &= !(src[i] & 0x8000u) || (src[i] & 0x7FFFu) >= min_idx;
+        }
+        const uint8_t *t = lut.get();
+        size_t i = 0;
+        for (; i + 16 <= n; i += 16) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)(src + i)), b = _mm_loadu_si128((const __m128i *)(src + i + 8));
+            if ((_mm_movemask_epi8(_mm_or_si128(a, b)) & 0xAAAA) == 0) {
+                _mm_storeu_si128((__m128i *)(dst + i), _mm_packus_epi16(a, b));
+            } else {
+                for (size_t k = i; k < i + 16; k++) dst[k] = t[src[k]];
+            }
+        }
+        for (; i < n; i++) dst[i] = t[src[i]];
+        return ok;
+    }
+
+    // one batch into an output buffer
+    void batch(Slot &o) {
+        // ---- territories
+        const size_t first = (size_t)(pos_ >> 3);
+        nch_ = 0;
+        for (int k = 0; k < cur_; k++) {
+            const size_t lo = first + (size_t)k * chunk_;
+            if (k > 0 && lo >= n_) break;
+            Chunk &c = chunks_[k];
+            c.search_from = k == 0 ? pos_ : (uint64_t)lo * 8;
+            c.search_to = (uint64_t)std::min(lo + chunk_, n_) * 8;
+            c.start.store(PENDING, std::memory_order_relaxed);
+            c.stop = 0; c.member_done = false; c.failed = false; c.err = ""; c.out_len = 0;
+            c.next = k + 1; c.bad_marker = false;
+            nch_++;
+        }
+        batch_end_ = chunks_[nch_ - 1].search_to;
+        // ---- steps 1 and 2
+        const double t0 = now();
+        double tend[64] = {0};
+        parallel(nch_, [this, &tend](int k) { run_chunk(k); tend[k] = now(); });
+        const double t1 = now();
+        if (getenv("PI_DEBUG")) { fprintf(stderr, "batch:"); for (int k = 0; k < nch_; k++) fprintf(stderr, " %.1f(%zu)", (tend[k] - t0) * 1e3, chunks_[k].out_len >> 10); fprintf(stderr, " | %.1f\n", (t1 - t0) * 1e3); }
+        stats.t_decode += t1 - t0;
+        stats.batches++;
+        stats.rejected += rejected_.exchange(0);
+        // ---- step 3: the chain, windows, destinations
+        int chain[64], nchain = 0;
+        size_t total = 0;
+        const uint8_t *win = window_;
+        uint8_t next_win[WIN];
+        for (int k = 0;;) {
+            Chunk &c = chunks_[k];
+            if (c.failed) {                                         // (a chunk on the chain decoded true blocks: the stream is bad)
+                failed_ = true; err_ = c.err;
+                break;
+            }
+            chain[nchain++] = k;
+            c.member_before = member_out_ + total;
+            if (k > 0) {
+                memcpy(c.window, win, WIN);
+                for (uint32_t i = 0; i < WIN; i++) { const uint32_t v = c.wide.p[c.out_len + i]; next_win[i] = v & 0x8000u ? c.window[v & 0x7FFFu] : (uint8_t)v; }
+            } else {
+                memcpy(next_win, c.narrow.p + c.out_len, WIN);
+            }
+            memcpy(window_, next_win, WIN);
+            win = window_;
+            total += c.out_len;
+            pos_ = c.stop;
+            if (c.member_done) break;
+            int j = k + 1;
+            while (j < nch_ && chunks_[j].start.load(std::memory_order_acquire) == NONE) j++;
+            if (j >= nch_ || chunks_[j].start.load(std::memory_order_acquire) != c.stop) break;
+            k = j;
+        }
+        stats.chunks += (uint64_t)nchain;
+        const double t2 = now();
+        stats.t_chain += t2 - t1;
+        const int last = nchain ? chain[nchain - 1] : 0;
+        // chunks behind the end of the chain were decoded for nothing (a false start, or a member ended
+        // inside the batch): try fewer next time, more again when all were used
+        const bool whole = nchain > 0 && (pos_ >= batch_end_ || last == nch_ - 1);
+        if (!whole) stats.dropped += (uint64_t)(nch_ - 1 - last);
+        cur_ = whole ? std::min(threads_, cur_ * 2) : std::max(1, last + 1);
+        o.b.reserve(total + 1);
+        o.len = total;
+        size_t off = 0;
+        for (int i = 0; i < nchain; i++) {
+            Chunk &c = chunks_[chain[i]];
+            c.dest = o.b.p + off;
+            off += c.out_len;
+        }
+        // ---- step 4
+        parallel(nchain, [this, &chain](int i) {
+            Chunk &c = chunks_[chain[i]];
+            if (chain[i] == 0) memcpy(c.dest, c.narrow.p + WIN, c.out_len);
+            else {
+                const uint32_t min_idx = WIN - (uint32_t)std::min<uint64_t>(WIN, c.member_before);
+                c.bad_marker = !resolve(c.wide.p + WIN, c.out_len, c.window, c.dest, min_idx);
+            }
+            c.crc = FI::crc32_update(0, c.dest, c.out_len);
+        });
+        stats.t_resolve += now() - t2;
+        for (int i = 0; i < nchain; i++) {
+            Chunk &c = chunks_[chain[i]];
+            if (c.bad_marker && !failed_) { failed_ = true; err_ = "distance reaches before the start of the output"; }
+            crc_ = (uint32_t)crc32_combine(crc_, c.crc, (z_off_t)c.out_len);
+        }
+        member_out_ += total;
+        if (!failed_ && nchain && chunks_[last].member_done) finish_member();
+    }
+
+    void finish_member() {
+        const size_t at = (size_t)((pos_ + 7) >> 3);
+        if (at + 8 > n_) { failed_ = true; err_ = "truncated gzip member (no CRC / length)"; return; }
+        uint32_t want_crc, want_len;
+        memcpy(&want_crc, data_ + at, 4); memcpy(&want_len, data_ + at + 4, 4);
+        if (want_crc != crc_) { failed_ = true; err_ = "gzip member fails its CRC-32 check"; return; }
+        if (want_len != (uint32_t)member_out_) { failed_ = true; err_ = "gzip member fails its length check"; return; }
+        begin_member(at + 8);
+    }
+};
+
+template <> inline ParInflate::Buf<uint8_t> &ParInflate::buffer<uint8_t>(Chunk &c) { return c.narrow; }
+template <> inline ParInflate::Buf<uint16_t> &ParInflate::buffer<uint16_t>(Chunk &c) { return c.wide; }
+
+}  // namespace tdhost
