@@ -111,8 +111,10 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
 /* The gzip reader td_count_file / td_split_file use, on its own (host only, no GPU; for tests):
  * inflates `path` into dst[0..capacity), asking the reader for `chunk` bytes at a time (0 = 1 MiB).
  * BGZF files (bgzip) are inflated member-parallel on TAGDIG_INFLATE_THREADS threads (default: the
- * host's cores, at most 16); any other gzip stream, multi-member included, goes through zlib on
- * the calling thread, as gzip.open does at tagdigger_fun.py:241. */
+ * host's cores, at most 16); any other gzip stream (what gzip.open reads at tagdigger_fun.py:241,
+ * multi-member included) by the library's own DEFLATE decoder: on the calling thread below 8 MiB
+ * of compressed data, chunk-parallel on the same number of threads from there (csrc/par_inflate.hpp).
+ * Every member's CRC-32 and length are checked. */
 int td_gunzip_file(const char *path, void *dst, uint64_t capacity, uint64_t chunk, uint64_t *n_out);
 
 /* Line terminators (\n, \r\n, bare \r) in a device buffer -- what a shard of a
@@ -157,7 +159,11 @@ int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
 
 /* ---- environment ------------------------------------------------------------
  * TAGDIG_STAGE_THREADS    host threads that copy / pread a piece into pinned memory (default 8, 1..16)
- * TAGDIG_INFLATE_THREADS  host threads for BGZF member-parallel inflate (default: cores, at most 16)
+ * TAGDIG_INFLATE_THREADS  host threads for BGZF member-parallel and gzip chunk-parallel inflate (default: cores, at most 16)
+ * TAGDIG_PAR_INFLATE      0: ordinary gzip always on one thread; 1: always chunk-parallel (default: from 8 MiB compressed)
+ * TAGDIG_INFLATE_CHUNK    compressed bytes per chunk of the chunk-parallel decoder (default 1 MiB; two chunks per thread and batch)
+ * TAGDIG_INFLATE_STATS    set: the chunk-parallel decoder reports batches, chunks and where its time went, on stderr
+ * TAGDIG_ZLIB             set: ordinary gzip through zlib's gzread, BGZF members through zlib's inflate
  * TAGDIG_SPLIT_THREADS    writer threads of td_split_file (default 8, at most the number of barcodes)
  * TAGDIG_SPLIT_TIMING     set: td_split_file reports where its wall time went, on stderr */
 

@@ -21,8 +21,10 @@
 
 namespace tdhost {
 
-// Gzip input.  Ordinary .gz streams are memory-mapped and decoded by FastInflate on the calling
-// thread (TAGDIG_ZLIB=1: zlib's gzread instead, ~0.6 GB/s of FASTQ on one core).  BGZF files (bgzip: a series of <= 64 KiB gzip members, each announcing its
+// Gzip input.  Ordinary .gz streams are memory-mapped and decoded by the library's own DEFLATE
+// decoder: small files by FastInflate on the calling thread, files from 8 MiB by ParInflate on
+// TAGDIG_INFLATE_THREADS threads (chunks of TAGDIG_INFLATE_CHUNK compressed bytes, default 1 MiB;
+// TAGDIG_PAR_INFLATE=0/1 forces the choice; TAGDIG_ZLIB=1: zlib's gzread instead).  BGZF files (bgzip: a series of <= 64 KiB gzip members, each announcing its
 // compressed size in a 'BC' extra field and ending with its uncompressed size) are inflated
 // member-parallel: the members of one request are located first, then worker threads inflate
 // them straight into the destination at their prefix offsets, each checking size and CRC-32.
@@ -93,10 +95,11 @@ struct GzSource {
         if (over == MAP_FAILED) { munmap(base, total); return false; }
         (void)madvise(base, n, MADV_SEQUENTIAL);
         map = (uint8_t *)base; map_len = total;
+        // chunk-parallel above 8 MiB of compressed data (TAGDIG_PAR_INFLATE=1: always, =0: never)
         const char *par = getenv("TAGDIG_PAR_INFLATE");
-        if (par && atoi(par) > 0 && want_threads > 1) {
+        if (want_threads > 1 && (par ? atoi(par) > 0 : n >= ((size_t)8 << 20))) {
             const char *cb = getenv("TAGDIG_INFLATE_CHUNK");
-            pi.open(map, n, want_threads, cb ? (size_t)atol(cb) : (size_t)2 << 20);
+            pi.open(map, n, want_threads, cb ? (size_t)atol(cb) : (size_t)1 << 20);
             use_pi = true;
         } else {
             fi.open(map, n);

@@ -27,7 +27,9 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -39,18 +41,25 @@ namespace tdhost {
 class ParInflate {
   public:
     static constexpr size_t PAD = FastInflate::PAD;          // readable bytes the caller guarantees behind the input
-    struct Stats { uint64_t batches = 0, chunks = 0, dropped = 0, rejected = 0; double t_decode = 0, t_chain = 0, t_resolve = 0, t_find = 0, t_busy = 0; } stats;
+    // batches run, chunks on the chains, chunks decoded for nothing, block-start guesses rejected; seconds of
+    // the producer in steps 1-2 / 3 / 4 and waiting for a free output buffer, of all threads searching / decoding
+    struct Stats {
+        uint64_t batches = 0, chunks = 0, dropped = 0, rejected = 0, out_bytes = 0;
+        double t_search = 0, t_decode = 0, t_chain = 0, t_resolve = 0, t_wait = 0, t_find = 0, t_busy = 0;
+    } stats;
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
     ~ParInflate() { close(); }
     void open(const uint8_t *data, size_t n, int threads, size_t chunk_bytes) {
         close();
         data_ = data; n_ = n;
-        threads_ = std::max(1, std::min(threads, 64));
+        threads_ = std::max(1, std::min(threads, MAX_CHUNKS / 4));
+        const char *ov = getenv("TAGDIG_INFLATE_OVERSUB");          // (more chunks than threads: they take unequal time)
+        max_chunks_ = std::min(MAX_CHUNKS, std::max(1, ov ? atoi(ov) : 2) * threads_);
         chunk_ = std::max<size_t>(chunk_bytes, 1024);
         cap_ = std::max<size_t>(chunk_ * 48, (size_t)1 << 22);
-        cur_ = threads_;
-        chunks_.reset(new Chunk[threads_]);
+        cur_ = max_chunks_;
+        chunks_.reset(new Chunk[max_chunks_]);
         failed_ = false; end_ = false; err_ = "";
         member_out_ = 0; crc_ = 0;
         stats = Stats();
@@ -64,6 +73,12 @@ class ParInflate {
             { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
             cv_.notify_all();
             producer_.join();
+            if (getenv("TAGDIG_INFLATE_STATS"))
+                fprintf(stderr, "par_inflate: %d threads, %zu KiB chunks: %lu batches, %lu chunks (+%lu dropped), %lu guesses rejected, %.1f MB out; "
+                        "producer: search %.3f s, decode %.3f s, chain %.3f s, resolve %.3f s, waiting for the reader %.3f s; threads: search %.3f s, decode %.3f s\n",
+                        threads_, chunk_ >> 10, (unsigned long)stats.batches, (unsigned long)stats.chunks, (unsigned long)stats.dropped,
+                        (unsigned long)stats.rejected, stats.out_bytes / 1e6, stats.t_search, stats.t_decode, stats.t_chain, stats.t_resolve, stats.t_wait,
+                        stats.t_find, stats.t_busy);
         }
     }
     const char *error() const { return err_; }
@@ -99,7 +114,7 @@ class ParInflate {
   private:
     using FI = FastInflate;
     static constexpr uint32_t WIN = 32768;
-    static constexpr uint64_t PENDING = ~0ull, NONE = ~0ull - 1;
+    static constexpr uint64_t NONE = ~0ull;
 
     template <typename T>
     struct Buf {                                              // (uninitialised storage that can grow)
@@ -132,11 +147,11 @@ class ParInflate {
 
     struct Chunk {
         uint64_t search_from = 0, search_to = 0;     // its territory in bits (first chunk: search_from is its exact start)
-        std::atomic<uint64_t> start{PENDING};        // the first block it decodes (bit position), or NONE
+        uint64_t start = NONE;                       // its first block (bit position), or NONE
+        uint64_t resume = 0, target = 0;             // where step 2 goes on (behind the block step 1 decoded) and up to where
         uint64_t stop = 0;                           // the block boundary it stopped on
         bool member_done = false, failed = false;
         const char *err = "";
-        int next = 0;                                // the chunk whose start it is heading for
         Buf<uint16_t> wide; Buf<uint8_t> narrow;     // [WIN elements before the chunk | its output]
         size_t out_len = 0;
         size_t valid_back = 0;                       // how far before the chunk a copy may reach (elements)
@@ -150,7 +165,8 @@ class ParInflate {
     };
 
     const uint8_t *data_ = nullptr; size_t n_ = 0;
-    int threads_ = 1, cur_ = 1, nch_ = 0;
+    static constexpr int MAX_CHUNKS = 128;
+    int threads_ = 1, max_chunks_ = 2, cur_ = 1, nch_ = 0;
     size_t chunk_ = 0, cap_ = 0;
     std::unique_ptr<Chunk[]> chunks_;
     uint64_t pos_ = 0;                               // bit position of the next block of the current member
@@ -172,8 +188,10 @@ class ParInflate {
         for (int w = 0;; w ^= 1) {
             Slot &o = slot_[w];
             {
+                const double t0 = now();
                 std::unique_lock<std::mutex> g(mu_);
                 cv_.wait(g, [&]() { return !o.ready || stop_; });
+                stats.t_wait += now() - t0;
                 if (stop_) return;
             }
             o.len = o.pos = 0;
@@ -381,50 +399,59 @@ class ParInflate {
         }
     }
 
-    // has chunk k, at block boundary `here` with `produced` elements out, reached where it should stop?
-    bool should_stop(int k, uint64_t here, size_t produced) {
+    // ---- step 1 for chunk k >= 1: the first position in its territory that passes as a block start.  The
+    // block decoded for the check stays in the chunk's buffer; step 2 goes on behind it
+    void find_start(int k) {
         Chunk &c = chunks_[k];
-        if (produced > cap_) return true;
-        if (here < c.search_to) return false;
-        while (c.next < nch_) {
-            std::atomic<uint64_t> &a = chunks_[c.next].start;
-            uint64_t s = a.load(std::memory_order_acquire);
-            while (s == PENDING) { std::this_thread::yield(); s = a.load(std::memory_order_acquire); }
-            if (s == NONE) { c.next++; continue; }
-            return here >= s;
+        if (!c.tables) c.tables.reset(new Tables);
+        Tables &t = *c.tables;
+        Buf<uint16_t> &buf = c.wide;
+        buf.reserve(WIN + chunk_ * 8 + 4096);
+        for (uint32_t i = 0; i < WIN; i++) buf.p[i] = (uint16_t)(0x8000u | i);
+        c.valid_back = WIN;
+        uint64_t rejected = 0;
+        const double t0 = now();
+        const char *err = "";
+        for (uint64_t p = c.search_from; (p = next_plausible(p, c.search_to)) < c.search_to; p++, rejected++) {
+            Bits b;
+            b.seek(data_, p);
+            bool final = false; uint32_t slen = 0;
+            if (block_header(b, t, true, final, slen, err) != H_DYNAMIC || final) continue;
+            uint16_t *out = buf.p + WIN;
+            if (huff_block<uint16_t>(b, t, buf, out, WIN, WIN + ((size_t)1 << 22), err) != 0) continue;
+            Bits b2 = b;                                           // a second header must follow the block
+            if (block_header(b2, t, true, final, slen, err) == H_BAD) continue;
+            c.start = p; c.resume = b.bitpos(data_); c.out_len = (size_t)(out - buf.p) - WIN;
+            break;
         }
-        return here >= batch_end_;
+        std::lock_guard<std::mutex> g(mu_);
+        stats.rejected += rejected; stats.t_find += now() - t0;
     }
 
-    // decodes chunk k from bit p.  verify: p is a guess -- 1 when it turns out not to be a block start
-    // (nothing has been published then); otherwise 0 with the chunk's results filled in
+    // ---- step 2: chunk k from c.resume up to the first block boundary at or past c.target
     template <typename T>
-    int decode_from(int k, uint64_t p, bool verify) {
+    void decode_chunk(int k) {
         Chunk &c = chunks_[k];
-        Buf<T> &buf = buffer<T>(c);
+        if (c.start == NONE) return;
+        const double t0 = now();
+        if (!c.tables) c.tables.reset(new Tables);
         Tables &t = *c.tables;
+        Buf<T> &buf = buffer<T>(c);
+        if (k == 0) {
+            buf.reserve(WIN + chunk_ * 8 + 4096);
+            memcpy(buf.p, window_, WIN);
+            c.valid_back = (size_t)std::min<uint64_t>(WIN, member_out_);
+        }
         Bits b;
-        b.seek(data_, p);
-        T *out = buf.p + WIN;
-        size_t nblocks = 0;
-        bool published = !verify;
+        b.seek(data_, c.resume);
+        T *out = buf.p + WIN + c.out_len;
         const char *err = "";
-        for (;;) {
+        for (bool first = k == 0;; first = false) {
             const uint64_t here = b.bitpos(data_);
-            if (verify && nblocks == 1) {                          // a second header must follow the first block
-                Bits b2 = b;
-                bool f2; uint32_t s2 = 0;
-                if (block_header(b2, t, true, f2, s2, err) == H_BAD) return 1;
-                c.start.store(p, std::memory_order_release);
-                published = true;
-            }
-            if (nblocks > 0 && should_stop(k, here, (size_t)(out - buf.p) - WIN)) { c.stop = here; break; }
+            if (!first && (here >= c.target || (size_t)(out - buf.p) - WIN > cap_)) { c.stop = here; break; }
             bool final = false; uint32_t slen = 0;
-            const int h = block_header(b, t, verify && nblocks == 0, final, slen, err);
-            if (h == H_BAD || (!published && (h != H_DYNAMIC || final))) {
-                if (!published) return 1;
-                c.failed = true; c.err = err; c.stop = here; break;
-            }
+            const int h = block_header(b, t, false, final, slen, err);
+            if (h == H_BAD) { c.failed = true; c.err = err; c.stop = here; break; }
             if (h == H_STORED) {
                 const uint8_t *s = b.in - (b.cnt >> 3);
                 if (s + slen > data_ + n_) { c.failed = true; c.err = "truncated stored block"; c.stop = here; break; }
@@ -434,57 +461,25 @@ class ParInflate {
                 for (uint32_t i = 0; i < slen; i++) out[i] = (T)s[i];
                 out += slen;
                 b.in = s + slen; b.buf = 0; b.cnt = 0;
-            } else {
-                const size_t limit = published ? ~(size_t)0 : WIN + ((size_t)1 << 22);
-                if (huff_block<T>(b, t, buf, out, c.valid_back, limit, err) != 0) {
-                    if (!published) return 1;
-                    c.failed = true; c.err = err; c.stop = here; break;
-                }
+            } else if (huff_block<T>(b, t, buf, out, c.valid_back, ~(size_t)0, err) != 0) {
+                c.failed = true; c.err = err; c.stop = here; break;
             }
-            nblocks++;
             if (final) { c.member_done = true; c.stop = b.bitpos(data_); break; }
         }
         c.out_len = (size_t)(out - buf.p) - WIN;
-        return 0;
+        std::lock_guard<std::mutex> g(mu_);
+        stats.t_busy += now() - t0;
     }
 
-    void run_chunk(int k) {
-        Chunk &c = chunks_[k];
-        if (!c.tables) c.tables.reset(new Tables);
-        if (k == 0) {
-            c.narrow.reserve(WIN + chunk_ * 6 + 4096);
-            memcpy(c.narrow.p, window_, WIN);
-            c.valid_back = (size_t)std::min<uint64_t>(WIN, member_out_);
-            c.start.store(c.search_from, std::memory_order_release);
-            decode_from<uint8_t>(0, c.search_from, false);
-            return;
-        }
-        c.wide.reserve(WIN + chunk_ * 6 + 4096);
-        for (uint32_t i = 0; i < WIN; i++) c.wide.p[i] = (uint16_t)(0x8000u | i);
-        c.valid_back = WIN;
-        uint64_t rejected = 0;
-        const double t0 = now();
-        for (uint64_t p = c.search_from; (p = next_plausible(p, c.search_to)) < c.search_to; p++) {
-            const double t1 = now();
-            if (decode_from<uint16_t>(k, p, true) == 0) {
-                rejected_.fetch_add(rejected);
-                std::lock_guard<std::mutex> g(mu_);
-                stats.t_find += t1 - t0; stats.t_busy += now() - t1;
-                return;
-            }
-            rejected++;
-        }
-        rejected_.fetch_add(rejected);
-        c.start.store(NONE, std::memory_order_release);
-    }
-    std::atomic<uint64_t> rejected_{0};
-
+    // fn(0) .. fn(n - 1) on up to threads_ threads, in order, each taking the next when it is free
     template <typename F>
     void parallel(int n, F &&fn) {
         if (n <= 0) return;
+        std::atomic<int> next{0};
+        auto work = [&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); };
         std::vector<std::thread> pool;
-        for (int i = 1; i < n; i++) pool.emplace_back([&fn, i]() { fn(i); });
-        fn(0);
+        for (int i = 1; i < std::min(n, threads_); i++) pool.emplace_back(work);
+        work();
         for (auto &t : pool) t.join();
     }
 
@@ -524,23 +519,25 @@ class ParInflate {
             Chunk &c = chunks_[k];
             c.search_from = k == 0 ? pos_ : (uint64_t)lo * 8;
             c.search_to = (uint64_t)std::min(lo + chunk_, n_) * 8;
-            c.start.store(PENDING, std::memory_order_relaxed);
+            c.start = k == 0 ? pos_ : NONE; c.resume = pos_;
             c.stop = 0; c.member_done = false; c.failed = false; c.err = ""; c.out_len = 0;
-            c.next = k + 1; c.bad_marker = false;
+            c.bad_marker = false;
             nch_++;
         }
         batch_end_ = chunks_[nch_ - 1].search_to;
         // ---- steps 1 and 2
         const double t0 = now();
-        double tend[64] = {0};
-        parallel(nch_, [this, &tend](int k) { run_chunk(k); tend[k] = now(); });
+        parallel(nch_ - 1, [this](int k) { find_start(k + 1); });
+        for (int k = nch_ - 1; k >= 0; k--)                       // every chunk heads for the next start found
+            chunks_[k].target = k == nch_ - 1 ? batch_end_ : (chunks_[k + 1].start != NONE ? chunks_[k + 1].start : chunks_[k + 1].target);
+        const double tf = now();
+        parallel(nch_, [this](int k) { if (k == 0) decode_chunk<uint8_t>(0); else decode_chunk<uint16_t>(k); });
         const double t1 = now();
-        if (getenv("PI_DEBUG")) { fprintf(stderr, "batch:"); for (int k = 0; k < nch_; k++) fprintf(stderr, " %.1f(%zu)", (tend[k] - t0) * 1e3, chunks_[k].out_len >> 10); fprintf(stderr, " | %.1f\n", (t1 - t0) * 1e3); }
-        stats.t_decode += t1 - t0;
+        stats.t_search += tf - t0;
+        stats.t_decode += t1 - tf;
         stats.batches++;
-        stats.rejected += rejected_.exchange(0);
         // ---- step 3: the chain, windows, destinations
-        int chain[64], nchain = 0;
+        int chain[MAX_CHUNKS], nchain = 0;
         size_t total = 0;
         const uint8_t *win = window_;
         uint8_t next_win[WIN];
@@ -564,8 +561,8 @@ class ParInflate {
             pos_ = c.stop;
             if (c.member_done) break;
             int j = k + 1;
-            while (j < nch_ && chunks_[j].start.load(std::memory_order_acquire) == NONE) j++;
-            if (j >= nch_ || chunks_[j].start.load(std::memory_order_acquire) != c.stop) break;
+            while (j < nch_ && chunks_[j].start == NONE) j++;
+            if (j >= nch_ || chunks_[j].start != c.stop) break;
             k = j;
         }
         stats.chunks += (uint64_t)nchain;
@@ -576,7 +573,7 @@ class ParInflate {
         // inside the batch): try fewer next time, more again when all were used
         const bool whole = nchain > 0 && (pos_ >= batch_end_ || last == nch_ - 1);
         if (!whole) stats.dropped += (uint64_t)(nch_ - 1 - last);
-        cur_ = whole ? std::min(threads_, cur_ * 2) : std::max(1, last + 1);
+        cur_ = whole ? std::min(max_chunks_, cur_ * 2) : std::max(1, last + 1);
         o.b.reserve(total + 1);
         o.len = total;
         size_t off = 0;
@@ -602,6 +599,7 @@ class ParInflate {
             crc_ = (uint32_t)crc32_combine(crc_, c.crc, (z_off_t)c.out_len);
         }
         member_out_ += total;
+        stats.out_bytes += total;
         if (!failed_ && nchain && chunks_[last].member_done) finish_member();
     }
 

@@ -19,6 +19,20 @@ def gunzip(path, capacity, chunk=0):
     return rc, bytes(buf[:n.value])
 
 
+@pytest.fixture(autouse=True, params=["sequential", "parallel-3000", "parallel-65536"])
+def decoder(request, monkeypatch):
+    """Every test runs with the one-thread decoder (fast_inflate.hpp) and with the chunk-parallel one
+    (par_inflate.hpp) forced on with chunks so small that these files span many batches, chunks without a
+    block start, members that end inside a batch and dropped chunks."""
+    if request.param == "sequential":
+        monkeypatch.setenv("TAGDIG_PAR_INFLATE", "0")
+    else:
+        monkeypatch.setenv("TAGDIG_PAR_INFLATE", "1")
+        monkeypatch.setenv("TAGDIG_INFLATE_CHUNK", request.param.split("-")[1])
+        monkeypatch.setenv("TAGDIG_INFLATE_THREADS", "4")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def fastq():
     rng = random.Random(7)
@@ -175,3 +189,51 @@ def test_zlib_fallback_env(tmp_path, monkeypatch):
     monkeypatch.setenv("TAGDIG_ZLIB", "1")
     rc, got = gunzip(p, len(data))
     assert rc == 0 and got == data
+
+
+def _stats_line(capfd):
+    err = capfd.readouterr().err
+    lines = [ln for ln in err.splitlines() if ln.startswith("par_inflate:")]
+    return lines[-1] if lines else None
+
+
+def test_parallel_decoder_chains_chunks(tmp_path, monkeypatch, capfd, decoder):
+    """With 64 KiB chunks the chains are longer than one chunk (block starts are found and confirmed by the
+    predecessor); with 3000-byte chunks a batch is shorter than a block, holds no block start, and the first
+    chunk decodes alone.  The output is byte-identical either way."""
+    import re
+    if decoder == "sequential":
+        pytest.skip("parallel decoder only")
+    monkeypatch.setenv("TAGDIG_INFLATE_STATS", "1")
+    data = _payloads()["fastq"]
+    p = tmp_path / "x.gz"
+    p.write_bytes(_gz(data, 6))
+    rc, got = gunzip(p, len(data))
+    assert rc == 0 and got == data
+    line = _stats_line(capfd)
+    assert line, "the chunk-parallel decoder did not run"
+    batches, chunks = map(int, re.search(r"(\d+) batches, (\d+) chunks", line).groups())
+    assert (chunks > batches if decoder == "parallel-65536" else chunks == batches) and batches >= 1, line
+
+
+def test_parallel_decoder_is_the_default_for_large_files(tmp_path, monkeypatch, capfd, decoder):
+    """No TAGDIG_PAR_INFLATE: files from 8 MiB of compressed data go through the chunk-parallel decoder,
+    smaller ones through the one-thread decoder."""
+    if decoder != "sequential":
+        pytest.skip("once is enough")
+    monkeypatch.delenv("TAGDIG_PAR_INFLATE", raising=False)
+    monkeypatch.setenv("TAGDIG_INFLATE_STATS", "1")
+    monkeypatch.setenv("TAGDIG_INFLATE_THREADS", "4")
+    rng = random.Random(5)
+    big = rng.randbytes(6 << 20) + _payloads()["fastq"] * 2 + rng.randbytes(3 << 20)     # > 8 MiB even compressed
+    p = tmp_path / "big.gz"
+    p.write_bytes(_gz(big, 1))
+    assert os.path.getsize(p) >= 8 << 20
+    rc, got = gunzip(p, len(big))
+    assert rc == 0 and got == big
+    assert _stats_line(capfd)
+    small = _payloads()["fastq"]
+    p.write_bytes(_gz(small, 6))
+    rc, got = gunzip(p, len(small))
+    assert rc == 0 and got == small
+    assert _stats_line(capfd) is None

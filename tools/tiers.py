@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput tiers T2/T3 of SURVEY section 8d (never the bench `value`, which is T1 = HBM-resident):
 T2 host buffer -> pinned staging -> hipMemcpyAsync overlapped with counting (td_count_host);
-T3 end to end from a file, plain, gzip (fast_inflate.hpp on one host thread) and BGZF (member-parallel)."""
+T3 end to end from a file, plain, gzip (par_inflate.hpp chunk-parallel, fast_inflate.hpp on one host thread, zlib)
+and BGZF (member-parallel)."""
 import gzip, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -41,8 +42,15 @@ with gzip.open(gzp, "wb", compresslevel=1) as fh:
     fh.write(host)
 tz = time.perf_counter() - t0
 eng.reset(); t0 = time.perf_counter(); eng.count_file(gzp); eng.sync(); dt = time.perf_counter() - t0; check()
-print("T3 gzip file     : %6.2f Mreads/s  %6.2f GB/s uncompressed (one thread: the library's own DEFLATE decoder, CRC-32 checked; %.2f GB gz, made in %.1f s)" % (
-    reads / dt / 1e6, nb / dt / 1e9, os.path.getsize(gzp) / 1e9, tz))
+print("T3 gzip file     : %6.2f Mreads/s  %6.2f GB/s uncompressed (chunk-parallel DEFLATE decoder, %s threads, CRC-32 checked; %.2f GB gz, made in %.1f s)" % (
+    reads / dt / 1e6, nb / dt / 1e9, os.environ.get("TAGDIG_INFLATE_THREADS", "default"), os.path.getsize(gzp) / 1e9, tz))
+os.environ["TAGDIG_PAR_INFLATE"] = "0"
+eng.reset(); t0 = time.perf_counter(); eng.count_file(gzp); eng.sync(); dt = time.perf_counter() - t0; check()
+print("T3 gzip, 1 thread: %6.2f Mreads/s  %6.2f GB/s uncompressed (TAGDIG_PAR_INFLATE=0: the sequential decoder)" % (reads / dt / 1e6, nb / dt / 1e9))
+os.environ["TAGDIG_ZLIB"] = "1"
+eng.reset(); t0 = time.perf_counter(); eng.count_file(gzp); eng.sync(); dt = time.perf_counter() - t0; check()
+print("T3 gzip, zlib    : %6.2f Mreads/s  %6.2f GB/s uncompressed (TAGDIG_ZLIB=1)" % (reads / dt / 1e6, nb / dt / 1e9))
+del os.environ["TAGDIG_PAR_INFLATE"], os.environ["TAGDIG_ZLIB"]
 def bgzf_bytes(data, block=0xFF00, level=6):
     import struct, zlib
     out = []
