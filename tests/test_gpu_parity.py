@@ -2,6 +2,7 @@
 the committed golden fixtures and against the CPU oracle on identical bytes.
 Bit-exact: the path is integer/byte work, no tolerance anywhere.
 Run on an MI355X with `pytest -m gpu`."""
+import os
 import random
 
 import numpy as np
@@ -284,6 +285,44 @@ def test_bgzf_file_counts_like_plain(tmp_path):
         eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
         eng.count_file(str(p))
         want, _ = synth_expected(cfg, 0, cfg.nreads)
+        assert (eng.counts_numpy() == want).all()
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("decoder", ["default", "sequential", "zlib"])
+def test_gzip_file_counts_like_plain(tmp_path, monkeypatch, capfd, decoder):
+    """An ordinary one-member gzip file above 8 MiB goes through the chunk-parallel decoder by default
+    (csrc/par_inflate.hpp; TAGDIG_PAR_INFLATE=0: one thread, TAGDIG_ZLIB=1: zlib): same matrix as the
+    plain bytes, also with a read limit that ends the stream early."""
+    import gzip
+    import tagdigger_amd
+    from tagdigger_amd.synth import SynthConfig
+    from helpers import synth_host_bytes, synth_expected
+    for k in ("TAGDIG_PAR_INFLATE", "TAGDIG_ZLIB", "TAGDIG_INFLATE_CHUNK", "TAGDIG_INFLATE_THREADS"):
+        monkeypatch.delenv(k, raising=False)
+    if decoder == "sequential":
+        monkeypatch.setenv("TAGDIG_PAR_INFLATE", "0")
+    if decoder == "zlib":
+        monkeypatch.setenv("TAGDIG_ZLIB", "1")
+    monkeypatch.setenv("TAGDIG_INFLATE_STATS", "1")
+    cfg = SynthConfig(nreads=300_000, nbar=8, nmarkers=50, seed=4321)      # 66 MB, about 13 MB compressed
+    data = bytes(synth_host_bytes(cfg, 0, cfg.nreads))
+    p = tmp_path / "lib.fq.gz"
+    p.write_bytes(gzip.compress(data, 1))
+    assert os.path.getsize(p) > 8 << 20
+    eng = tagdigger_amd.Engine(0)
+    try:
+        eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        eng.count_file(str(p))
+        want, _ = synth_expected(cfg, 0, cfg.nreads)
+        assert (eng.counts_numpy() == want).all()
+        ran_parallel = "par_inflate:" in capfd.readouterr().err
+        assert ran_parallel == (decoder == "default")
+        eng.reset()
+        eng.count_file(str(p), maxreads=100_000)                           # (the reader stops asking early)
+        want, _ = synth_expected(cfg, 0, 100_000)
         assert (eng.counts_numpy() == want).all()
     finally:
         eng.close()
