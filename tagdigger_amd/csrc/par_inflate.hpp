@@ -18,7 +18,9 @@
 //   4. all threads turn markers into bytes and take the CRC-32 of their part; the parts' CRCs are
 //      combined, and CRC and length of every member are checked.
 // Batches are decoded ahead of the reader by a producer thread (two output buffers), so read() is a
-// copy that overlaps the next batch.
+// copy that overlaps the next batch; and step 4 of one batch shares the threads with step 2 of the
+// next (two sets of chunk buffers): its pieces are taken up as threads run out of chunks to decode,
+// which fills the idle tail that chunks of unequal duration leave.
 // Files without findable block starts (stored or fixed-Huffman blocks only) are decoded by the first
 // thread alone.  After: Kerbiriou & Chikhi, "Parallel decompression of gzip-compressed files and random
 // access to DNA sequences" (2019), without its text heuristics -- step 3 makes the search exact.
@@ -42,7 +44,7 @@ class ParInflate {
   public:
     static constexpr size_t PAD = FastInflate::PAD;          // readable bytes the caller guarantees behind the input
     // batches run, chunks on the chains, chunks decoded for nothing, block-start guesses rejected; seconds of
-    // the producer in steps 1-2 / 3 / 4 and waiting for a free output buffer, of all threads searching / decoding
+    // the producer in step 1 / steps 2 + 4 / step 3 and waiting for a free output buffer, of all threads in steps 1 / 2 / 4
     struct Stats {
         uint64_t batches = 0, chunks = 0, dropped = 0, rejected = 0, out_bytes = 0;
         double t_search = 0, t_decode = 0, t_chain = 0, t_resolve = 0, t_wait = 0, t_find = 0, t_busy = 0;
@@ -59,9 +61,11 @@ class ParInflate {
         chunk_ = std::max<size_t>(chunk_bytes, 1024);
         cap_ = std::max<size_t>(chunk_ * 48, (size_t)1 << 22);
         cur_ = max_chunks_;
-        chunks_.reset(new Chunk[max_chunks_]);
+        for (auto &set : sets_) set.reset(new Chunk[max_chunks_]);
+        chunks_ = sets_[0].get();
+        pend_.valid = false; crc_run_ = 0;
         failed_ = false; end_ = false; err_ = "";
-        member_out_ = 0; crc_ = 0;
+        member_out_ = 0;
         stats = Stats();
         for (Slot &o : slot_) { o.len = o.pos = 0; o.ready = false; o.last = false; o.failed = false; }
         rd_ = 0; stop_ = false; drained_ = false; read_failed_ = false;
@@ -75,10 +79,10 @@ class ParInflate {
             producer_.join();
             if (getenv("TAGDIG_INFLATE_STATS"))
                 fprintf(stderr, "par_inflate: %d threads, %zu KiB chunks: %lu batches, %lu chunks (+%lu dropped), %lu guesses rejected, %.1f MB out; "
-                        "producer: search %.3f s, decode %.3f s, chain %.3f s, resolve %.3f s, waiting for the reader %.3f s; threads: search %.3f s, decode %.3f s\n",
+                        "producer: search %.3f s, decode + markers %.3f s, chain %.3f s, waiting for the reader %.3f s; threads: search %.3f s, decode %.3f s, markers + CRC %.3f s\n",
                         threads_, chunk_ >> 10, (unsigned long)stats.batches, (unsigned long)stats.chunks, (unsigned long)stats.dropped,
-                        (unsigned long)stats.rejected, stats.out_bytes / 1e6, stats.t_search, stats.t_decode, stats.t_chain, stats.t_resolve, stats.t_wait,
-                        stats.t_find, stats.t_busy);
+                        (unsigned long)stats.rejected, stats.out_bytes / 1e6, stats.t_search, stats.t_decode, stats.t_chain, stats.t_wait,
+                        stats.t_find, stats.t_busy, stats.t_resolve);
         }
     }
     const char *error() const { return err_; }
@@ -159,19 +163,21 @@ class ParInflate {
         // after chaining
         uint8_t window[WIN];                         // the 32 KiB of output before it
         uint64_t member_before = 0;                  // bytes of the current member before it
-        uint8_t *dest = nullptr;
-        uint32_t crc = 0;
-        bool bad_marker = false;
+        size_t dest_off = 0;                         // where its bytes go in the batch's output
+        bool is_narrow = false;
+        double t_begin = 0, t_end = 0;               // (step 2, for TAGDIG_INFLATE_STATS=2)
     };
 
     const uint8_t *data_ = nullptr; size_t n_ = 0;
     static constexpr int MAX_CHUNKS = 128;
     int threads_ = 1, max_chunks_ = 2, cur_ = 1, nch_ = 0;
     size_t chunk_ = 0, cap_ = 0;
-    std::unique_ptr<Chunk[]> chunks_;
+    std::unique_ptr<Chunk[]> sets_[2];               // the chunks of even and of odd batches
+    Chunk *chunks_ = nullptr;                        // ... of the batch being decoded
     uint64_t pos_ = 0;                               // bit position of the next block of the current member
     uint64_t batch_end_ = 0;
-    uint64_t member_out_ = 0; uint32_t crc_ = 0;
+    uint64_t member_out_ = 0;                        // bytes of the current member up to the batch being decoded
+    uint32_t crc_run_ = 0;                           // CRC-32 of the current member up to the batch last resolved
     uint8_t window_[WIN];
     bool failed_ = false, end_ = false;              // (producer side)
     const char *err_ = "";
@@ -184,24 +190,112 @@ class ParInflate {
     int rd_ = 0;
     bool drained_ = false, read_failed_ = false;     // (reader side)
 
+    // a batch that has been decoded and chained and waits for step 4
+    struct Piece { Chunk *c; size_t off, len; uint32_t crc; bool bad; };
+    struct Pending {
+        bool valid = false;
+        std::vector<Piece> pieces;
+        Slot *slot = nullptr;
+        size_t total = 0;
+        bool member_done = false; uint32_t want_crc = 0;   // the batch ends its member: the CRC-32 its trailer states
+        bool failed = false, last = false;                 // the stream is bad / ends behind this batch
+    } pend_;
+
     void produce() {
-        for (int w = 0;; w ^= 1) {
-            Slot &o = slot_[w];
-            {
-                const double t0 = now();
-                std::unique_lock<std::mutex> g(mu_);
-                cv_.wait(g, [&]() { return !o.ready || stop_; });
-                stats.t_wait += now() - t0;
-                if (stop_) return;
+        for (int b = 0;; b++) {
+            const bool more = !failed_ && !end_;
+            double t0 = now(), tf = t0;
+            if (more) {
+                chunks_ = sets_[b & 1].get();
+                territories();
+                parallel(nch_ - 1, [this](int k) { find_start(k + 1); });
+                for (int k = nch_ - 1; k >= 0; k--)               // every chunk heads for the next start found
+                    chunks_[k].target = k == nch_ - 1 ? batch_end_ : (chunks_[k + 1].start != NONE ? chunks_[k + 1].start : chunks_[k + 1].target);
+                tf = now();
+                stats.t_search += tf - t0;
+            } else {
+                nch_ = 0;
             }
-            o.len = o.pos = 0;
-            if (!failed_ && !end_) batch(o);
-            o.failed = failed_; o.last = failed_ || end_;
-            const bool fin = o.last;
-            { std::lock_guard<std::mutex> g(mu_); o.ready = true; }
-            cv_.notify_all();
-            if (fin) return;
+            if (pend_.valid) {                                    // its output buffer must have been read out
+                Slot &o = *pend_.slot;
+                const double tw = now();
+                {
+                    std::unique_lock<std::mutex> g(mu_);
+                    cv_.wait(g, [&]() { return !o.ready || stop_; });
+                    if (stop_) return;
+                }
+                stats.t_wait += now() - tw;
+                o.b.reserve(pend_.total + 1);
+                o.len = pend_.total; o.pos = 0;
+            } else if (!more) {                                   // (nothing at all: an empty or bad stream)
+                publish(slot_[b & 1], 0);
+                return;
+            }
+            // ---- step 2 of this batch, then step 4 of the one before as threads become free
+            const double td = now();
+            const int ndec = nch_, npieces = pend_.valid ? (int)pend_.pieces.size() : 0;
+            parallel(ndec + npieces, [this, ndec](int i) {
+                if (i >= ndec) resolve_piece(pend_.pieces[(size_t)(i - ndec)]);
+                else if (i == 0) decode_chunk<uint8_t>(0);
+                else decode_chunk<uint16_t>(i);
+            });
+            const double t1 = now();
+            stats.t_decode += t1 - td;
+            if (more) {
+                stats.batches++;
+                if (const char *e = getenv("TAGDIG_INFLATE_STATS")) if (atoi(e) >= 2) {
+                    fprintf(stderr, "par_inflate batch: search %.1f ms; decode per chunk [begin-end ms, KiB out]:", (tf - t0) * 1e3);
+                    for (int k = 0; k < nch_; k++) fprintf(stderr, " %.1f-%.1f/%zu", (chunks_[k].t_begin - td) * 1e3, (chunks_[k].t_end - td) * 1e3, chunks_[k].out_len >> 10);
+                    fprintf(stderr, " | with %d pieces of the batch before: %.1f ms\n", npieces, (t1 - td) * 1e3);
+                }
+            }
+            if (pend_.valid) {
+                const bool fin = finish_pending();
+                if (fin) return;
+            }
+            if (more) chain(slot_[b & 1]);
+            stats.t_chain += now() - t1;
         }
+    }
+    void publish(Slot &o, size_t len) {
+        o.len = len; o.pos = 0;
+        o.failed = failed_; o.last = failed_ || end_;
+        { std::lock_guard<std::mutex> g(mu_); o.ready = true; }
+        cv_.notify_all();
+    }
+    // CRCs of the resolved batch; true when it was the last one (end of the stream, or an error)
+    bool finish_pending() {
+        for (const Piece &pc : pend_.pieces) {
+            if (pc.bad && !pend_.failed) { pend_.failed = true; err_ = "distance reaches before the start of the output"; }
+            crc_run_ = FI::crc32_join(crc_run_, pc.crc, pc.len);
+        }
+        if (pend_.member_done) {
+            if (!pend_.failed && crc_run_ != pend_.want_crc) { pend_.failed = true; err_ = "gzip member fails its CRC-32 check"; }
+            crc_run_ = 0;
+        }
+        stats.out_bytes += pend_.total;
+        Slot &o = *pend_.slot;
+        const bool fin = pend_.failed || pend_.last;
+        if (pend_.failed) failed_ = true;
+        o.failed = pend_.failed; o.last = fin;
+        { std::lock_guard<std::mutex> g(mu_); o.ready = true; }
+        cv_.notify_all();
+        pend_.valid = false;
+        return fin;
+    }
+    void resolve_piece(Piece &pc) {
+        const double t0 = now();
+        Chunk &c = *pc.c;
+        uint8_t *dst = pend_.slot->b.p + c.dest_off + pc.off;
+        if (c.is_narrow) memcpy(dst, c.narrow.p + WIN + pc.off, pc.len);
+        else {
+            const uint64_t before = c.member_before + pc.off;
+            pc.bad = !resolve(c.wide.p + WIN + pc.off, pc.len, c.window, dst, WIN - (uint32_t)std::min<uint64_t>(WIN, before));
+        }
+        pc.crc = FI::crc32_update(0, dst, pc.len);
+        const double dt = now() - t0;
+        std::lock_guard<std::mutex> g(mu_);
+        stats.t_resolve += dt;
     }
 
     void begin_member(size_t at_byte) {
@@ -210,7 +304,7 @@ class ParInflate {
         if (r < 0) { failed_ = true; return; }
         if (r == 0) { end_ = true; return; }
         pos_ = (uint64_t)(body - data_) * 8;
-        member_out_ = 0; crc_ = 0;
+        member_out_ = 0;
     }
 
     // ---- block headers.  strict: accept only what a compressor writes (complete codes)
@@ -467,8 +561,9 @@ class ParInflate {
             if (final) { c.member_done = true; c.stop = b.bitpos(data_); break; }
         }
         c.out_len = (size_t)(out - buf.p) - WIN;
+        c.t_begin = t0; c.t_end = now();
         std::lock_guard<std::mutex> g(mu_);
-        stats.t_busy += now() - t0;
+        stats.t_busy += c.t_end - t0;
     }
 
     // fn(0) .. fn(n - 1) on up to threads_ threads, in order, each taking the next when it is free
@@ -508,9 +603,8 @@ class ParInflate {
         return ok;
     }
 
-    // one batch into an output buffer
-    void batch(Slot &o) {
-        // ---- territories
+    // ---- the territories of the next batch
+    void territories() {
         const size_t first = (size_t)(pos_ >> 3);
         nch_ = 0;
         for (int k = 0; k < cur_; k++) {
@@ -521,42 +615,34 @@ class ParInflate {
             c.search_to = (uint64_t)std::min(lo + chunk_, n_) * 8;
             c.start = k == 0 ? pos_ : NONE; c.resume = pos_;
             c.stop = 0; c.member_done = false; c.failed = false; c.err = ""; c.out_len = 0;
-            c.bad_marker = false;
+            c.is_narrow = k == 0;
             nch_++;
         }
         batch_end_ = chunks_[nch_ - 1].search_to;
-        // ---- steps 1 and 2
-        const double t0 = now();
-        parallel(nch_ - 1, [this](int k) { find_start(k + 1); });
-        for (int k = nch_ - 1; k >= 0; k--)                       // every chunk heads for the next start found
-            chunks_[k].target = k == nch_ - 1 ? batch_end_ : (chunks_[k + 1].start != NONE ? chunks_[k + 1].start : chunks_[k + 1].target);
-        const double tf = now();
-        parallel(nch_, [this](int k) { if (k == 0) decode_chunk<uint8_t>(0); else decode_chunk<uint16_t>(k); });
-        const double t1 = now();
-        stats.t_search += tf - t0;
-        stats.t_decode += t1 - tf;
-        stats.batches++;
-        // ---- step 3: the chain, windows, destinations
-        int chain[MAX_CHUNKS], nchain = 0;
+    }
+
+    // ---- step 3: the chain, windows, destinations in `o`, the pieces of step 4; moves on to where the
+    // chain ended (over the member's trailer and the next header if it ended the member)
+    void chain(Slot &o) {
+        Chunk *chain[MAX_CHUNKS];
+        int nchain = 0, last = 0;
         size_t total = 0;
-        const uint8_t *win = window_;
-        uint8_t next_win[WIN];
+        pend_.failed = false;
         for (int k = 0;;) {
             Chunk &c = chunks_[k];
             if (c.failed) {                                         // (a chunk on the chain decoded true blocks: the stream is bad)
-                failed_ = true; err_ = c.err;
+                pend_.failed = true; failed_ = true; err_ = c.err;
                 break;
             }
-            chain[nchain++] = k;
+            chain[nchain++] = &c;
+            last = k;
             c.member_before = member_out_ + total;
             if (k > 0) {
-                memcpy(c.window, win, WIN);
-                for (uint32_t i = 0; i < WIN; i++) { const uint32_t v = c.wide.p[c.out_len + i]; next_win[i] = v & 0x8000u ? c.window[v & 0x7FFFu] : (uint8_t)v; }
+                memcpy(c.window, window_, WIN);
+                for (uint32_t i = 0; i < WIN; i++) { const uint32_t v = c.wide.p[c.out_len + i]; window_[i] = v & 0x8000u ? c.window[v & 0x7FFFu] : (uint8_t)v; }
             } else {
-                memcpy(next_win, c.narrow.p + c.out_len, WIN);
+                memcpy(window_, c.narrow.p + c.out_len, WIN);
             }
-            memcpy(window_, next_win, WIN);
-            win = window_;
             total += c.out_len;
             pos_ = c.stop;
             if (c.member_done) break;
@@ -566,52 +652,39 @@ class ParInflate {
             k = j;
         }
         stats.chunks += (uint64_t)nchain;
-        const double t2 = now();
-        stats.t_chain += t2 - t1;
-        const int last = nchain ? chain[nchain - 1] : 0;
         // chunks behind the end of the chain were decoded for nothing (a false start, or a member ended
         // inside the batch): try fewer next time, more again when all were used
         const bool whole = nchain > 0 && (pos_ >= batch_end_ || last == nch_ - 1);
         if (!whole) stats.dropped += (uint64_t)(nch_ - 1 - last);
         cur_ = whole ? std::min(max_chunks_, cur_ * 2) : std::max(1, last + 1);
-        o.b.reserve(total + 1);
-        o.len = total;
+        member_out_ += total;
+        pend_.valid = true;
+        pend_.slot = &o;
+        pend_.total = total;
+        pend_.pieces.clear();
         size_t off = 0;
         for (int i = 0; i < nchain; i++) {
-            Chunk &c = chunks_[chain[i]];
-            c.dest = o.b.p + off;
+            Chunk &c = *chain[i];
+            c.dest_off = off;
+            for (size_t at = 0; at < c.out_len; at += PIECE) pend_.pieces.push_back({&c, at, std::min(PIECE, c.out_len - at), 0, false});
             off += c.out_len;
         }
-        // ---- step 4
-        parallel(nchain, [this, &chain](int i) {
-            Chunk &c = chunks_[chain[i]];
-            if (chain[i] == 0) memcpy(c.dest, c.narrow.p + WIN, c.out_len);
+        pend_.member_done = !pend_.failed && nchain && chunks_[last].member_done;
+        if (pend_.member_done) {
+            const size_t at = (size_t)((pos_ + 7) >> 3);
+            uint32_t want_len = 0;
+            if (at + 8 > n_) { pend_.failed = true; err_ = "truncated gzip member (no CRC / length)"; }
             else {
-                const uint32_t min_idx = WIN - (uint32_t)std::min<uint64_t>(WIN, c.member_before);
-                c.bad_marker = !resolve(c.wide.p + WIN, c.out_len, c.window, c.dest, min_idx);
+                memcpy(&pend_.want_crc, data_ + at, 4); memcpy(&want_len, data_ + at + 4, 4);
+                if (want_len != (uint32_t)member_out_) { pend_.failed = true; err_ = "gzip member fails its length check"; }
+                else begin_member(at + 8);
             }
-            c.crc = FI::crc32_update(0, c.dest, c.out_len);
-        });
-        stats.t_resolve += now() - t2;
-        for (int i = 0; i < nchain; i++) {
-            Chunk &c = chunks_[chain[i]];
-            if (c.bad_marker && !failed_) { failed_ = true; err_ = "distance reaches before the start of the output"; }
-            crc_ = (uint32_t)crc32_combine(crc_, c.crc, (z_off_t)c.out_len);
+            if (pend_.failed) failed_ = true;
         }
-        member_out_ += total;
-        stats.out_bytes += total;
-        if (!failed_ && nchain && chunks_[last].member_done) finish_member();
+        pend_.failed |= failed_;
+        pend_.last = end_;
     }
-
-    void finish_member() {
-        const size_t at = (size_t)((pos_ + 7) >> 3);
-        if (at + 8 > n_) { failed_ = true; err_ = "truncated gzip member (no CRC / length)"; return; }
-        uint32_t want_crc, want_len;
-        memcpy(&want_crc, data_ + at, 4); memcpy(&want_len, data_ + at + 4, 4);
-        if (want_crc != crc_) { failed_ = true; err_ = "gzip member fails its CRC-32 check"; return; }
-        if (want_len != (uint32_t)member_out_) { failed_ = true; err_ = "gzip member fails its length check"; return; }
-        begin_member(at + 8);
-    }
+    static constexpr size_t PIECE = (size_t)1 << 19;          // symbols per task of step 4
 };
 
 template <> inline ParInflate::Buf<uint8_t> &ParInflate::buffer<uint8_t>(Chunk &c) { return c.narrow; }
