@@ -26,6 +26,7 @@
 // access to DNA sequences" (2019), without its text heuristics -- step 3 makes the search exact.
 #pragma once
 #include <emmintrin.h>
+#include <sys/mman.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -121,14 +122,18 @@ class ParInflate {
     static constexpr uint64_t NONE = ~0ull;
 
     template <typename T>
-    struct Buf {                                              // (uninitialised storage that can grow)
-        T *p = nullptr; size_t cap = 0;
-        ~Buf() { free(p); }
+    struct Buf {                                              // uninitialised storage that can grow: its own mapping,
+        T *p = nullptr; size_t cap = 0;                       // on huge pages where the system hands them out on request
+        ~Buf() { if (p) munmap(p, bytes(cap)); }              // (a page fault per 4 KiB of these buffers is most of a short run)
+        static size_t bytes(size_t n) { return (n * sizeof(T) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); }
         void reserve(size_t n) {
             if (n <= cap) return;
-            T *q = (T *)realloc(p, n * sizeof(T));
-            if (!q) abort();
-            p = q; cap = n;
+            const size_t want = bytes(n);
+            void *q = p ? mremap(p, bytes(cap), want, MREMAP_MAYMOVE)
+                        : mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q == MAP_FAILED) abort();
+            (void)madvise(q, want, MADV_HUGEPAGE);
+            p = (T *)q; cap = want / sizeof(T);
         }
     };
     struct Tables { uint32_t lit[FI::LIT_ENTRIES]; uint32_t dist[FI::DIST_ENTRIES]; };
