@@ -58,10 +58,18 @@ __device__ __forceinline__ void set_prio(uint32_t level) {
 
 // FIX = false: the main pass over all tiles (phase predicted, nothing to subtract, no limit);
 // FIX = true: the fix-up pass over the queue k_resolve left.
+// threads per workgroup of k_fast (a power of two; the tile is CPT * FBLOCK chunks)
+#ifndef TD_FAST_BLOCK
+#define TD_FAST_BLOCK 256
+#endif
+#ifndef TD_FAST_WAVES_PER_SIMD
+#define TD_FAST_WAVES_PER_SIMD TD_WAVES_PER_SIMD
+#endif
+constexpr int FBLOCK = TD_FAST_BLOCK;
 template <int CPT, int W, bool FIX>
-__global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams fp) {
+__global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const FParams fp) {
     const KParams &p = fp.k;
-    constexpr int TILE_CH = CPT * BLOCK;
+    constexpr int TILE_CH = CPT * FBLOCK;
     constexpr uint32_t TILE = TILE_CH * 16;
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir)};
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t i = tid; i < p.bblob_bytes / 4; i += BLOCK)
+    for (uint32_t i = tid; i < p.bblob_bytes / 4; i += FBLOCK)
         reinterpret_cast<uint32_t *>(L_bidx)[i] = p.bblob[i];
     if (tid == 0) L_misc[1] = 0;
 
@@ -151,13 +159,13 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
         if (p.nt_loads) {
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
-                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * (BLOCK * 16), 2 /* nt */);
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * (FBLOCK * 16), 2 /* nt */);
                 v[j] = make_uint4(q.x, q.y, q.z, q.w);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
-                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * (BLOCK * 16), 0);
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * (FBLOCK * 16), 0);
                 v[j] = make_uint4(q.x, q.y, q.z, q.w);
             }
         }
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                 if (!general) {
 #pragma unroll
                     for (int j = 0; j < CPT; j++) {
-                        const uint32_t c = j * BLOCK + tid;
+                        const uint32_t c = j * FBLOCK + tid;
                         const uint2 pk = convert_chunk_ascii(v[j]);
                         L_mask[c] = (uint16_t)term[j];
                         L_inv[c] = (uint16_t)pk.y;
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
             if (__builtin_expect(general, 0)) {
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
-                    const uint32_t c = j * BLOCK + tid;
+                    const uint32_t c = j * FBLOCK + tid;
                     const uint64_t g = tbase + (uint64_t)c * 16u;
                     uint32_t nl = eq_mask16(v[j], 0x0A0A0A0Au);
                     uint32_t cr = eq_mask16(v[j], 0x0D0D0D0Du);
@@ -294,14 +302,14 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
 #pragma unroll
             for (int c = 0; c < 4; c++)
                 packed |= (uint32_t)__builtin_popcountll(__ballot(vote_good && lclass == (uint32_t)c)) << (8 * c);
-            if (lane == 63) { L_misc[4 + wave] = incl; L_misc[8 + wave] = packed; }
+            if (lane == 63) { L_misc[4 + wave] = incl; L_misc[4 + FBLOCK / 64 + wave] = packed; }
         }
         lds_barrier();
         uint32_t wbase = 0, total = 0;
         uint32_t v02 = 0, v13 = 0;                       // 16-bit fields: votes of in-tile classes 0,2 and 1,3
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) {
-            const uint32_t x = L_misc[4 + w], pk = L_misc[8 + w];
+        for (int w = 0; w < FBLOCK / 64; w++) {
+            const uint32_t x = L_misc[4 + w], pk = L_misc[4 + FBLOCK / 64 + w];
             // wave w's local class c is in-tile class (c + total-so-far) & 3: rotate its four byte fields
             const uint32_t rot = 8u * (total & 3u);
             const uint32_t r = rot ? ((pk << rot) | (pk >> (32u - rot))) : pk;
@@ -442,14 +450,14 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_fast(const FParams
                 // ~60 bytes), matched from the packed chunks.  A thread's LAST line is left pending
                 // in the pipelined form: no other memory access follows it here, the bucket loads
                 // stay in flight.
-                const uint32_t j0 = ((uint32_t)tid + 64u * (t & 3u)) & (uint32_t)(BLOCK - 1);
+                const uint32_t j0 = ((uint32_t)tid + 64u * (t & (uint32_t)(FBLOCK / 64 - 1))) & (uint32_t)(FBLOCK - 1);
 #pragma nounroll
-                for (uint32_t j = j0; j < nwant; j += BLOCK) {
+                for (uint32_t j = j0; j < nwant; j += FBLOCK) {
                     const uint32_t srel = L_list[j];
                     // (a 32-bit status: 1 pending, 0 no barcode, 2 barcode only, 6 raw bytes needed)
                     const uint32_t k = (uint32_t)(match_prepare<W, ML_FAST>(p, cx, tbase + srel, srel, false, pd) >> 61);
                     if (k == 1u) {
-                        if (PIPE && j + BLOCK >= nwant) pd_valid = true;
+                        if (PIPE && j + FBLOCK >= nwant) pd_valid = true;
                         else { commit(match_finish<W>(p, pd)); vm_settled(); }
                     } else if (__builtin_expect(k == 6u, 0)) {
                         // cold: needs its raw bytes (leading blanks to strip, a first byte that is not a

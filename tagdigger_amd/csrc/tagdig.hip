@@ -211,8 +211,9 @@ template <int CPT, bool FIX> FFn pick_fast_w(int W) {
     }
 }
 FFn pick_fast(int tile_kb, int W, bool fix) {
-    if (fix) return tile_kb == 32 ? pick_fast_w<8, true>(W) : pick_fast_w<4, true>(W);
-    return tile_kb == 32 ? pick_fast_w<8, false>(W) : pick_fast_w<4, false>(W);
+    constexpr int C32 = 32 * 1024 / (tdk::FBLOCK * 16), C16 = 16 * 1024 / (tdk::FBLOCK * 16);      // chunks per thread
+    if (fix) return tile_kb == 32 ? pick_fast_w<C32, true>(W) : pick_fast_w<C16, true>(W);
+    return tile_kb == 32 ? pick_fast_w<C32, false>(W) : pick_fast_w<C16, false>(W);
 }
 
 size_t lds_bytes_fast(const td_handle *h, int tile_kb) {
@@ -335,7 +336,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
         if (bpc <= 0) {
             if (h->occ_fn != (const void *)ffn || h->occ_lds != flds) {
                 int occ = 0;
-                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)ffn, tdk::BLOCK, flds));
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)ffn, tdk::FBLOCK, flds));
                 h->occ_fn = (const void *)ffn; h->occ_lds = flds; h->occ_val = std::max(1, occ);
             }
             bpc = h->occ_val;
@@ -351,14 +352,14 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
             e0 = h->ev_pool[h->ev_used].first; e1 = h->ev_pool[h->ev_used].second; h->ev_used++;
             HIPCHK(hipEventRecord(e0, stream));
         }
-        hipLaunchKernelGGL(ffn, dim3(grid), dim3(tdk::BLOCK), flds, stream, fp);
+        hipLaunchKernelGGL(ffn, dim3(grid), dim3(tdk::FBLOCK), flds, stream, fp);
         {   // exact line phase of every tile (d_state is free on this path: it holds the block sums)
             const uint32_t rblocks = (ntiles + tdk::RESOLVE_SPAN - 1) / tdk::RESOLVE_SPAN;
             unsigned long long *super = reinterpret_cast<unsigned long long *>(h->d_state.p);
             hipLaunchKernelGGL(tdk::k_resolve_sums, dim3(rblocks), dim3(256), 0, stream, fp, super);
             hipLaunchKernelGGL(tdk::k_resolve, dim3(rblocks), dim3(1024), 0, stream, fp, super);
         }
-        hipLaunchKernelGGL(fixfn, dim3(std::min<uint32_t>(grid, (uint32_t)h->num_cu * 2)), dim3(tdk::BLOCK), flds, stream, fp);
+        hipLaunchKernelGGL(fixfn, dim3(std::min<uint32_t>(grid, (uint32_t)h->num_cu * 2)), dim3(tdk::FBLOCK), flds, stream, fp);
         HIPCHK(hipGetLastError());
         if (h->timing) HIPCHK(hipEventRecord(e1, stream));
         return TD_OK;
