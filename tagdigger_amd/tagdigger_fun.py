@@ -30,6 +30,52 @@ def find_tags_fastq(fqfile, barcodes, tags, cutsite="TGCAG", maxreads=5e9, tasse
     return eng.counts(signed=bool(tassel_tagcount))
 
 
+def find_tags_fastq_many(files, barcodes, tags, cutsite="TGCAG", maxreads=5e9, tassel_tagcount=False,
+                         devices=(0,)):
+    """`find_tags_fastq` over several files, the files dealt out to the GPUs in `devices` and counted
+    concurrently (one host thread and one engine per GPU; the library calls release the GIL).
+
+    `barcodes` is either one list used for every file or a list of lists, one per file -- the way
+    the reference's callers loop `find_tags_fastq(f, bckeys[f][0], tags[1], cutsite=...)` over the
+    files of a key file (tagdigger_script.py:124-126).  Returns the matrices in the order of `files`;
+    each equals the single-file call's.  An exception in any file is raised after the others finish.
+    (Several processes instead of threads, with an all-reduce into sample rows: tagdigger_amd.multi.)
+    """
+    import threading
+    files = list(files)
+    per_file = bool(barcodes) and isinstance(barcodes[0], (list, tuple))
+    if per_file and len(barcodes) != len(files):
+        raise ValueError("one barcode list per file expected")
+    devs = list(dict.fromkeys(int(d) for d in devices))
+    if not devs:
+        raise ValueError("no device given")
+    results, errors = [None] * len(files), [None] * len(files)
+    todo = list(range(len(files)))
+    lock = threading.Lock()
+
+    def work(dev):
+        while True:
+            with lock:
+                if not todo:
+                    return
+                k = todo.pop(0)
+            try:
+                results[k] = find_tags_fastq(files[k], barcodes[k] if per_file else barcodes, tags, cutsite=cutsite,
+                                             maxreads=maxreads, tassel_tagcount=tassel_tagcount, device=dev)
+            except BaseException as exc:      # noqa: BLE001 -- reported to the caller below
+                errors[k] = exc
+    threads = [threading.Thread(target=work, args=(d,)) for d in devs[1:]]
+    for t in threads:
+        t.start()
+    work(devs[0])
+    for t in threads:
+        t.join()
+    for exc in errors:
+        if exc is not None:
+            raise exc
+    return results
+
+
 # =============================================================================
 # Periphery of the counting path (SURVEY.md section 2, rows 6-13): plain host
 # Python, no acceleration -- kept so that the reference's command line stays a

@@ -329,6 +329,35 @@ def test_gzip_file_counts_like_plain(tmp_path, monkeypatch, capfd, decoder):
 
 
 @pytest.mark.gpu
+def test_find_tags_fastq_many(tmp_path):
+    """The batched call returns, in file order, what the single-file call returns (the first
+    file's is a reference output); one barcode list for all files or one per file; an error in one file
+    surfaces after the others are done."""
+    import gzip
+    from tagdigger_amd import tagdigger_fun as tf
+    case = next(c for c in load_golden("hotpath_random.json") if c["name"] == "random000")
+    first = write_case_file(case, tmp_path)
+    data = case_payload(case)
+    lines = data.split(b"\n")
+    second = str(tmp_path / "half.fq")
+    open(second, "wb").write(b"\n".join(lines[:len(lines) // 8 * 4]) + b"\n")
+    third = str(tmp_path / "again.fq.gz")
+    open(third, "wb").write(gzip.compress(data))
+    files = [first, second, third]
+    bars, tags, cut = case["barcodes"], case["tags"], case["kwargs"]["cutsite"]
+    got = tf.find_tags_fastq_many(files, bars, tags, cutsite=cut, devices=[0])
+    assert got[0] == case["counts"] and got[2] == case["counts"]
+    assert got == [tf.find_tags_fastq(f, bars, tags, cutsite=cut) for f in files]
+    per_file = [bars, bars[:3], bars[1:]]
+    got = tf.find_tags_fastq_many(files, per_file, tags, cutsite=cut, devices=[0, 0])
+    assert got == [tf.find_tags_fastq(f, b, tags, cutsite=cut) for f, b in zip(files, per_file)]
+    with pytest.raises(FileNotFoundError):
+        tf.find_tags_fastq_many([first, str(tmp_path / "missing.fq")], bars, tags, cutsite=cut)
+    with pytest.raises(ValueError):
+        tf.find_tags_fastq_many(files, [bars] * 4, tags, cutsite=cut)
+
+
+@pytest.mark.gpu
 def test_byte_sharded_file_on_the_gpu(tmp_path):
     """One file cut into byte shards at line starts (tagdigger_amd.multi): counted shard by shard
     with each shard's own first line index, the GPU gives the whole file's matrix; and the
