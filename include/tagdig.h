@@ -164,7 +164,7 @@ int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
  * TAGDIG_INFLATE_CHUNK    compressed bytes per chunk of the chunk-parallel decoder (default 1 MiB; two chunks per thread and batch)
  * TAGDIG_INFLATE_STATS    set: the chunk-parallel decoder reports batches, chunks and where its time went, on stderr
  * TAGDIG_ZLIB             set: ordinary gzip through zlib's gzread, BGZF members through zlib's inflate
- * TAGDIG_SPLIT_THREADS    writer threads of td_split_file (default 8, at most the number of barcodes)
+ * TAGDIG_SPLIT_THREADS    writer threads of td_split_file (default 16, at most the host's cores and the number of barcodes)
  * TAGDIG_SPLIT_TIMING     set: td_split_file reports where its wall time went, on stderr */
 
 /* ---- tuning / introspection ------------------------------------------------ */

@@ -1113,8 +1113,51 @@ struct SplitFiles {
     ~SplitFiles() { for (FILE *f : out) if (f) fclose(f); }
 };
 
-// One writer thread: walks EVERY line of a piece (so that all threads agree on line numbers and on
-// where maxreads stops) but copies, clips and writes only the records of its own barcodes.
+// The lines of a piece, found once by all writer threads together (each scans 1/n of the bytes):
+// line k is p[starts[k], starts[k + 1] - 1).  Pieces holding a '\r' are walked byte by byte instead.
+struct PieceIndex {
+    std::vector<std::vector<uint32_t>> part;     // per thread: starts of the lines that begin in its range
+    std::vector<uint32_t> starts;
+    size_t nlines = 0;
+    bool has_cr = false, nonascii = false;
+    std::vector<uint8_t> flags;                  // per thread: 1 = saw '\r', 2 = saw a byte >= 0x80
+    // a barrier for the threads of one piece
+    std::mutex mu; std::condition_variable cv; uint32_t arrived = 0, generation = 0, nthreads = 1;
+    void barrier() {
+        std::unique_lock<std::mutex> g(mu);
+        const uint32_t gen = generation;
+        if (++arrived == nthreads) { arrived = 0; generation++; cv.notify_all(); }
+        else cv.wait(g, [&]() { return generation != gen; });
+    }
+    void scan(uint32_t tid, const uint8_t *p, size_t n) {
+        const size_t a = n * tid / nthreads, b = n * (tid + 1) / nthreads;
+        std::vector<uint32_t> &v = part[tid];
+        v.clear();
+        uint8_t any = 0;
+        for (size_t i = a; i < b; i++) any |= p[i];                         // (vectorises)
+        flags[tid] = (uint8_t)((memchr(p + a, '\r', b - a) ? 1 : 0) | (any & 0x80 ? 2 : 0));
+        for (size_t i = a; i < b;) {
+            const uint8_t *nl = (const uint8_t *)memchr(p + i, '\n', b - i);
+            if (!nl) break;
+            i = (size_t)(nl - p) + 1;
+            v.push_back((uint32_t)i);
+        }
+    }
+    void merge(size_t n) {                        // (one thread, between two barriers)
+        has_cr = false; nonascii = false;
+        for (uint8_t f : flags) { has_cr |= (f & 1) != 0; nonascii |= (f & 2) != 0; }
+        starts.clear();
+        if (n == 0) { nlines = 0; return; }
+        starts.push_back(0);
+        for (const auto &v : part) starts.insert(starts.end(), v.begin(), v.end());
+        if (starts.back() == n) nlines = starts.size() - 1;               // the piece ends with a terminator
+        else { nlines = starts.size(); starts.push_back((uint32_t)n + 1); }   // ... or with an unterminated last line
+    }
+};
+
+// One writer thread.  All threads agree on line numbers and on where maxreads stops (each steps
+// through every record of a piece), but a thread copies, clips and writes only the records of its
+// own barcodes.
 struct SplitWriter {
     SplitFiles &files;
     const std::vector<std::string> &barcodes;
@@ -1178,21 +1221,46 @@ struct SplitWriter {
         } }
         lineindex++;
     }
-    // all lines of a piece that ends at a line end (or at the end of the file)
-    void piece(const uint8_t *p, size_t n, const int2 *res) {
-        if (tid == 0) {
-            uint8_t any = 0;
-            for (size_t i = 0; i < n; i++) any |= p[i];                  // (vectorises)
-            if (any & 0x80) nonascii = true;
+    // one whole record whose four lines are lines k .. k + 3 of the piece
+    void record(const uint8_t *p, const uint32_t *st, const int2 &d) {
+        cur_bar = d.x; cur_slice = d.y;
+        reads++;
+        if (mine()) {
+            stripped(p + st[0], st[1] - 1 - st[0], comment1, false);
+            stripped(p + st[1], st[2] - 1 - st[1], sequence, true);
+            stripped(p + st[2], st[3] - 1 - st[2], comment2, false);
+            stripped(p + st[3], st[4] - 1 - st[3], quality, false);
+            barcut++;
+            const std::string &bc = barcodes[(size_t)cur_bar];
+            const long slice1 = (long)bc.size();
+            long slice2 = cur_slice;
+            if (slice2 == 999) slice2 = (long)sequence.size(); else clipped++;
+            std::string &o = pend[(size_t)cur_bar];
+            o.append(comment1); o.append(bc); o.push_back('\n');
+            put_slice(o, sequence, slice1, slice2);
+            if (comment2 == "+") o.append("+\n");
+            else { o.append(comment1); o.append(bc); o.push_back('\n'); }
+            put_slice(o, quality, slice1, slice2);
+            if (o.size() >= FLUSH_AT && !flush((size_t)cur_bar)) io_error = true;
         }
-        if (!memchr(p, '\r', n)) {                                       // the usual file: '\n' only
-            size_t start = 0;
-            while (start < n && !stop) {
-                const uint8_t *nl = (const uint8_t *)memchr(p + start, '\n', n - start);
-                const size_t end = nl ? (size_t)(nl - p) : n;
-                line(p + start, end - start, res);
-                start = end + 1;
-            }
+        if (reads >= max_reads) stop = true;
+        lineindex += 4;
+    }
+    // all lines of a piece that ends at a line end (or at the end of the file)
+    void piece(const uint8_t *p, size_t n, const int2 *res, PieceIndex &ix) {
+        ix.scan(tid, p, n);
+        ix.barrier();
+        if (tid == 0) ix.merge(n);
+        ix.barrier();
+        if (tid == 0 && ix.nonascii) nonascii = true;
+        if (!ix.has_cr) {                                                // the usual file: '\n' only
+            const uint32_t *st = ix.starts.data();
+            size_t k = 0;
+            // the lines of a record begun in the piece before, whole records, the lines of a record cut by the piece's end
+            while (k < ix.nlines && (lineindex & 3) != 0 && !stop) { line(p + st[k], st[k + 1] - 1 - st[k], res); k++; }
+            while (k + 4 <= ix.nlines && !stop) { record(p, st + k, *res++); k += 4; }
+            // (a trailing partial comment line is kept by every thread: its record's barcode is not known yet)
+            while (k < ix.nlines && !stop) { line(p + st[k], st[k + 1] - 1 - st[k], res); k++; }
             return;
         }
         size_t start = 0, i = 0;
@@ -1325,15 +1393,17 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
     };
     SplitFiles files(h->sp_barcodes);
     const char *tenv = getenv("TAGDIG_SPLIT_THREADS");
-    const uint32_t nthr = (uint32_t)std::max<long>(1, std::min<long>({tenv ? atol(tenv) : 8L, (long)h->sp_barcodes.size(),
+    const uint32_t nthr = (uint32_t)std::max<long>(1, std::min<long>({tenv ? atol(tenv) : 16L, (long)h->sp_barcodes.size(),
                                                                       (long)std::max<unsigned>(1, std::thread::hardware_concurrency())}));
     std::vector<SplitWriter> writers;
     for (uint32_t t = 0; t < nthr; t++) { writers.emplace_back(files, t, nthr); writers.back().max_reads = std::max<uint64_t>(1, max_reads); }
     SplitWriter &w = writers[0];                 // (every writer sees the same lines: thread 0 speaks for the line numbers)
+    PieceIndex pindex;
+    pindex.nthreads = nthr; pindex.part.resize(nthr); pindex.flags.assign(nthr, 0);
     auto write_piece = [&](const uint8_t *p, size_t n, const int2 *res) {
         std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < nthr; t++) pool.emplace_back([&, t]() { writers[t].piece(p, n, res); });
-        writers[0].piece(p, n, res);
+        for (uint32_t t = 1; t < nthr; t++) pool.emplace_back([&, t]() { writers[t].piece(p, n, res, pindex); });
+        writers[0].piece(p, n, res, pindex);
         for (auto &th : pool) th.join();
     };
     int rc = TD_OK;
@@ -1391,44 +1461,57 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
         t_wait += t1 - t0; t_write += now() - t1;
         return TD_OK;
     };
-    // Per piece: read it, start its copy and its line prefix on the GPU, write the PREVIOUS piece's
-    // records meanwhile (that also tells the exact line index this piece starts at), then have the
-    // GPU decide this piece's reads (a millisecond) and fetch the decisions.
+    // Per piece: read it and start its copy and its line prefix on the GPU while the writer threads
+    // write the PREVIOUS piece's records (that also tells the exact line index this piece starts at),
+    // then have the GPU decide this piece's reads (a millisecond) and fetch the decisions.
     int cur = 0;
     Slot *prev = nullptr;
     while (!eof && !w.stop && !rc) {
         Slot &sl = slot[cur];
+        int wrc = TD_OK;
+        std::thread wt;
+        if (prev) {
+            Slot *pv = prev;
+            wt = std::thread([&, pv]() { (void)hipSetDevice(h->device); wrc = write_out(*pv); });
+        }
+        prev = nullptr;
         const double tr0 = now();
         size_t have = carry.size();
         if (have) memcpy(sl.pin, carry.data(), have);
         carry.clear();
         while (have < cap) {
             long got = reader(sl.pin + have, cap - have);
-            if (got < 0) { rc = fail(TD_E_IO, "read error while streaming FASTQ"); break; }
+            if (got < 0) { rc = TD_E_IO; break; }
             if (got == 0) { eof = true; break; }
             have += (size_t)got;
         }
-        if (rc) break;
         size_t cut = have;
-        if (!eof) {
+        if (!rc && !eof) {
             cut = cut_at_line_end(sl.pin, have);
-            if (cut == 0) { rc = fail(TD_E_LIMIT, "a single line exceeds the staging buffer"); break; }
-            carry.assign(sl.pin + cut, sl.pin + have);
+            if (cut == 0) rc = TD_E_LIMIT;
+            else carry.assign(sl.pin + cut, sl.pin + have);
         }
         sl.n = cut;
         t_read += now() - tr0;
-        if (cut) {
-            hipError_t e = hipMemcpyAsync(sl.dev, sl.pin, cut, hipMemcpyHostToDevice, h->work_stream);
-            if (e != hipSuccess) { rc = hipfail("hipMemcpyAsync", e); break; }
-            rc = launch_split_prefix(h, sl.dev, cut, h->work_stream); if (rc) break;
-            e = hipMemcpyAsync(terms_pin, h->d_cursor.p, 8, hipMemcpyDeviceToHost, h->work_stream);
-            if (e != hipSuccess) { rc = hipfail("hipMemcpyAsync", e); break; }
+        hipError_t e = hipSuccess;
+        const char *what = "";
+        if (!rc && cut) {
+            e = hipMemcpyAsync(sl.dev, sl.pin, cut, hipMemcpyHostToDevice, h->work_stream); what = "hipMemcpyAsync";
+            if (e == hipSuccess) {
+                const int prc = launch_split_prefix(h, sl.dev, cut, h->work_stream);
+                if (prc) rc = prc;
+                else e = hipMemcpyAsync(terms_pin, h->d_cursor.p, 8, hipMemcpyDeviceToHost, h->work_stream);
+            }
         }
-        if (prev) { rc = write_out(*prev); if (rc) break; }
-        prev = nullptr;
+        if (wt.joinable()) wt.join();
+        if (rc == TD_E_IO) { rc = fail(TD_E_IO, "read error while streaming FASTQ"); break; }
+        if (rc == TD_E_LIMIT) { rc = fail(TD_E_LIMIT, "a single line exceeds the staging buffer"); break; }
+        if (rc) break;
+        if (e != hipSuccess) { rc = hipfail(what, e); break; }
+        if (wrc) { rc = wrc; break; }
         if (cut && !w.stop) {
             const double t0 = now();
-            hipError_t e = hipStreamSynchronize(h->work_stream);          // (copy + prefix ran under the writing)
+            e = hipStreamSynchronize(h->work_stream);                     // (copy + prefix ran under the writing)
             if (e != hipSuccess) { rc = hipfail("hipStreamSynchronize", e); break; }
             t_wait += now() - t0;
             const uint64_t lines = *terms_pin + 1;                        // (+1: an unterminated last line, at most)
