@@ -208,16 +208,15 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
             uint32_t cr_absent = 0x80808080u;
             bool general = !inside || __any((hiacc & 0x80808080u) != 0);
             if (!general) {
-                uint32_t term[CPT];
 #pragma unroll
-                for (int j = 0; j < CPT; j++) term[j] = nl_mask16_ascii(v[j], cr_absent);
+                for (int j = 0; j < CPT; j++) cr_absent_ascii(v[j], cr_absent);
                 general = __any((cr_absent & 0x80808080u) != 0x80808080u);
                 if (!general) {
 #pragma unroll
                     for (int j = 0; j < CPT; j++) {
                         const uint32_t c = j * FBLOCK + tid;
                         const uint2 pk = convert_chunk_ascii(v[j]);
-                        L_mask[c] = (uint16_t)term[j];
+                        L_mask[c] = (uint16_t)nl_mask16_ascii(v[j]);
                         L_inv[c] = (uint16_t)pk.y;
                         L_conv[c] = pk;
                     }

@@ -250,22 +250,34 @@ __device__ __forceinline__ uint2 convert_chunk_ascii(const uint4 &v) {
     }
     return make_uint2(cw, ((ihi >> 7) << 8) | (ilo >> 7));   // each accumulator is 128 * (8 flag bits)
 }
-// 16-bit mask of bytes equal to '\n' in an all-ASCII chunk, and whether it holds any '\r'
-__device__ __forceinline__ uint32_t nl_mask16_ascii(const uint4 &v, uint32_t &cr_absent_acc) {
+// (a ^ b) + c in one instruction.  v_xad_u32 takes no literal operands, and at most one of its
+// sources may be an SGPR: b is kept in an SGPR and c in a VGPR across the loop (written out because
+// the compiler, given two literals, emits v_xor + v_add instead).
+__device__ __forceinline__ uint32_t xor_add(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+// AND-accumulates "no '\r' here" over an all-ASCII chunk: bit 7 of a byte of acc is cleared iff some chunk had '\r' there
+__device__ __forceinline__ void cr_absent_ascii(const uint4 &v, uint32_t &acc) {
+    acc &= xor_add(v.x, 0x0D0D0D0Du, 0x7F7F7F7Fu) & xor_add(v.y, 0x0D0D0D0Du, 0x7F7F7F7Fu);
+    acc &= xor_add(v.z, 0x0D0D0D0Du, 0x7F7F7F7Fu) & xor_add(v.w, 0x0D0D0D0Du, 0x7F7F7F7Fu);
+}
+// 16-bit mask of bytes equal to '\n' in an all-ASCII chunk
+__device__ __forceinline__ uint32_t nl_mask16_ascii(const uint4 &v) {
     const uint32_t x[4] = {v.x, v.y, v.z, v.w};
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        const uint32_t y = x[d] ^ 0x0A0A0A0Au;
-        const uint32_t u = (y + 0x7F7F7F7Fu) | 0x7F7F7F7Fu;       // 0x7F where the byte is '\n', else 0xFF
-        cr_absent_acc &= (x[d] ^ 0x0D0D0D0Du) + 0x7F7F7F7Fu;      // bit 7 of a byte cleared iff it is '\r'
+        // bit 7 of a byte of (x ^ c) + 0x7F..7F is clear iff the byte equals c (bytes < 0x80: no carries)
+        const uint32_t u = xor_add(x[d], 0x0A0A0A0Au, 0x7F7F7F7Fu) & 0x80808080u;       // 0x80 where the byte is NOT '\n'
         if (d == 0) lo = udot4(u, 0x08040201u, 0u);
         else if (d == 1) lo = udot4(u, 0x80402010u, lo);
         else if (d == 2) hi = udot4(u, 0x08040201u, 0u);
         else hi = udot4(u, 0x80402010u, hi);
     }
-    // dot = 255 * 255 - 128 * mask8
-    return ((65025u - lo) >> 7) | (((65025u - hi) >> 7) << 8);
+    // each dot is 128 * (the complement of eight mask bits)
+    return ((lo >> 7) | (hi << 1)) ^ 0xFFFFu;
 }
 
 // CPT: 16-byte chunks per thread per tile (tile = CPT*4 KiB); W: 64-bit words per packed tag
