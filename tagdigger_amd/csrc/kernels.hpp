@@ -168,13 +168,18 @@ __device__ __forceinline__ void wave_lds_fence() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// wave-level inclusive scan (64 lanes)
+// wave-level inclusive scan (64 lanes) in six DPP additions: a scan inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8, lanes without a source add 0), then lane 15 of rows 0 and 2 added to rows
+// 1 and 3 (row_bcast:15), then lane 31 to rows 2 and 3 (row_bcast:31).  No LDS traffic, no index
+// arithmetic (__shfl_up goes through ds_bpermute with four address instructions per step).
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+    (void)lane;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
     return v;
 }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
