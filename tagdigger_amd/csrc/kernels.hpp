@@ -477,15 +477,19 @@ __device__ __forceinline__ uint64_t match_finish(const KParams &p, const Pending
     constexpr int SPB = (BUCKET_U4 * 4 - 1) / SLOT_DW;  // slots per bucket
     const uint64_t *R = pd.R;
     const uint32_t nrem = pd.nr & 0x7FFFu;
+    // do the first `len` (<= 32 W) bases of the read equal the stored tag's?  Counted rather than masked:
+    // the bases before the first differing bit, word by word (no per-slot 64-bit masks to build)
     auto prefix_eq = [&](const uint64_t *T, uint32_t len) -> bool {
-        bool ok = true;
+        uint32_t same = 0;                      // equal leading bases
+        bool open = true;                       // no difference seen yet
 #pragma unroll
         for (int w = 0; w < W; w++) {
-            int nb = (int)len - 32 * w;
-            uint64_t mask = nb <= 0 ? 0ull : nb >= 32 ? ~0ull : (~0ull << (64 - 2 * nb));
-            ok = ok && (((R[w] ^ T[w]) & mask) == 0);
+            const uint64_t d = R[w] ^ T[w];
+            const uint32_t z = d ? (uint32_t)__builtin_clzll(d) : 64u;
+            if (open) same += z >> 1;
+            open = open && z == 64u;
         }
-        return ok;
+        return len <= same;
     };
     bool thit = false;
     uint32_t col = 0;
