@@ -246,14 +246,14 @@ __device__ __forceinline__ uint2 convert_chunk_ascii(const uint4 &v) {
         uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, code);
         uint32_t diff = (x[d] & 0xDFDFDFDFu) ^ expect;            // 0 where the byte is a base, < 0x80 otherwise
         uint32_t nz = (diff + 0x7F7F7F7Fu) & 0x80808080u;
-        cw = (cw << 8) | udot4(code, 0x01041040u, 0u);
+        cw = udot4(code, 0x01041040u, cw << 8);                   // (the dot's addend carries the words before)
         // 0x80 * (first byte -> weight 1 ... ), two dwords per accumulator
         if (d == 0) ilo = udot4(nz, 0x08040201u, 0u);
         else if (d == 1) ilo = udot4(nz, 0x80402010u, ilo);
         else if (d == 2) ihi = udot4(nz, 0x08040201u, 0u);
         else ihi = udot4(nz, 0x80402010u, ihi);
     }
-    return make_uint2(cw, ((ihi >> 7) << 8) | (ilo >> 7));   // each accumulator is 128 * (8 flag bits)
+    return make_uint2(cw, (ihi << 1) | (ilo >> 7));             // each accumulator is 128 * (8 flag bits)
 }
 // (a ^ b) + c in one instruction.  v_xad_u32 takes no literal operands, and at most one of its
 // sources may be an SGPR: b is kept in an SGPR and c in a VGPR across the loop (written out because
