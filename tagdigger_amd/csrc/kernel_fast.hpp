@@ -297,10 +297,10 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
             const uint64_t win = (((uint64_t)hi << 32) | lo) >> ((fpos & 31u) + 1u);
             const bool vote_good = found && (win & 0xFFu) == 0 && span0 + fpos + 9u <= tile_rem;
             const uint32_t lclass = (incl - cnt) & 3u;
-            uint32_t packed = 0;                         // 4 x 8-bit counts (<= 64 each)
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                packed |= (uint32_t)__builtin_popcountll(__ballot(vote_good && lclass == (uint32_t)c)) << (8 * c);
+            // 4 x 8-bit counts (<= 64 each) of the good votes per class: three ballots, the rest scalar
+            const uint64_t bg = __ballot(vote_good), b0 = __ballot((lclass & 1u) != 0), b1 = __ballot((lclass & 2u) != 0);
+            const uint32_t packed = (uint32_t)__builtin_popcountll(bg & ~b0 & ~b1) | ((uint32_t)__builtin_popcountll(bg & b0 & ~b1) << 8) |
+                                    ((uint32_t)__builtin_popcountll(bg & ~b0 & b1) << 16) | ((uint32_t)__builtin_popcountll(bg & b0 & b1) << 24);
             if (lane == 63) { L_misc[4 + wave] = incl; L_misc[4 + FBLOCK / 64 + wave] = packed; }
         }
         lds_barrier();
