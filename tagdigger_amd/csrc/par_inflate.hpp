@@ -60,7 +60,9 @@ class ParInflate {
         const char *ov = getenv("TAGDIG_INFLATE_OVERSUB");          // (more chunks than threads: they take unequal time)
         max_chunks_ = std::min(MAX_CHUNKS, std::max(1, ov ? atoi(ov) : 2) * threads_);
         chunk_ = std::max<size_t>(chunk_bytes, 1024);
-        cap_ = std::max<size_t>(chunk_ * 48, (size_t)1 << 22);
+        // a chunk stops at the first block boundary past this much output (bounds the buffers on highly
+        // compressible input: the chain then ends there and the next batch tries fewer chunks)
+        cap_ = std::max<size_t>(chunk_ * 12, (size_t)1 << 22);
         cur_ = max_chunks_;
         for (auto &set : sets_) set.reset(new Chunk[max_chunks_]);
         chunks_ = sets_[0].get();
