@@ -1,39 +1,41 @@
 #!/usr/bin/env python3
-"""Command-line mirror of the reference's barcode_splitter_script.py: split every FASTQ file named
-in a key file ('Input File', 'Barcode', 'Output File' columns) into one clipped FASTQ per barcode.
-Same arguments; the per-read decisions are made on the GPU (tagdigger_fun.barcodeSplitter)."""
+"""Splitting from the command line: every FASTQ file of a key file ('Input File', 'Barcode',
+'Output File' columns) into one clipped FASTQ per barcode, the per-read decisions made on the GPU
+(tagdigger_fun.barcodeSplitter).  Takes the two options of the reference's barcode_splitter_script.py.
+
+    python -m tagdigger_amd.barcode_splitter_script -b splitkey.csv -a PstI-MspI-Hall
+"""
 import argparse
 import sys
 
-from . import tagdigger_fun
+from . import tagdigger_fun as tf
 
 
 def build_parser():
-    ap = argparse.ArgumentParser(description="TagDigger v. 1.1 barcode splitter command line script by Lindsay V. Clark "
-                                             "(MI355X engine)")
-    ap.add_argument('-b', '--barcodefile', help='Name of barcode key file', required=True)
-    ap.add_argument('-a', '--adapter', help='Name of the adapter set', required=True,
-                    choices=sorted(tagdigger_fun.adapters.keys()))
-    ap.add_argument('--td-device', type=int, default=0, help='GPU to use (this build only)')
+    ap = argparse.ArgumentParser(description="Split FASTQ files by barcode and trim adapter read-through on an MI355X")
+    ap.add_argument("-b", "--barcodefile", required=True, metavar="FILE", help="key file: input file, barcode, output file")
+    ap.add_argument("-a", "--adapter", required=True, choices=sorted(tf.adapters),
+                    help="enzyme pair and adapter design (its first word names the enzyme at the barcode end)")
+    ap.add_argument("--td-device", type=int, default=0, help="GPU to use (this build only)")
     return ap
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    bckeys = tagdigger_fun.readBarcodeKeyfile(args.barcodefile, forSplitter=True)
-    if bckeys == None:
+    keys = tf.readBarcodeKeyfile(args.barcodefile, forSplitter=True)
+    if keys is None:
         raise Exception("Problem reading barcode file.")
-    adapter = tagdigger_fun.adapters[args.adapter]
-    cutsite = tagdigger_fun.enzymes[args.adapter[:args.adapter.find("-")]]     # the set's name starts with the enzyme
-    fqfiles = sorted(bckeys.keys())
-    fqok = [tagdigger_fun.isFastq(f) for f in fqfiles]
-    if not all(fqok):
+    enzyme = args.adapter.split("-", 1)[0]
+    inputs = sorted(keys)
+    unreadable = [f for f in inputs if not tf.isFastq(f)]
+    if unreadable:
         print("Cannot read the following as FASTQ files:")
-        print([fqfiles[i] for i in range(len(fqfiles)) if not fqok[i]])
+        print(unreadable)
         raise Exception("Cannot read all FASTQ files.")
-    for f in fqfiles:
-        tagdigger_fun.barcodeSplitter(f, bckeys[f][0], bckeys[f][1], cutsite=cutsite, adapter=adapter,
-                                      device=args.td_device)
+    for f in inputs:
+        barcodes, outputs = keys[f][0], keys[f][1]
+        tf.barcodeSplitter(f, barcodes, outputs, cutsite=tf.enzymes[enzyme], adapter=tf.adapters[args.adapter],
+                           device=args.td_device)
     return 0
 
 
