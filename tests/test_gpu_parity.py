@@ -123,6 +123,45 @@ def test_fuzz_vs_oracle(eng, cutsite, nl, seed):
     eng.set_option("tile_kb", 16)
 
 
+def test_fuzz_campaign(eng):
+    """Randomised cases against the C oracle for TD_FUZZ_SECONDS seconds (default 3; a soak run on the
+    GPU box uses minutes): random index shapes (barcode and tag counts and lengths, cut sites with IUPAC
+    codes, tags longer than 32 and 64 bases), every terminator style, long lines and phase shifts, both
+    tile sizes, both kernels."""
+    import time
+    budget = float(os.environ.get("TD_FUZZ_SECONDS", "3"))
+    seed0 = int(os.environ.get("TD_FUZZ_SEED", "12345"))
+    t_end = time.time() + budget
+    ncase = 0
+    cuts = ["TGCAG", "CWGC", "", "RCATGY", "TGCAT", "CATGG", "GWC"]
+    try:
+        while time.time() < t_end:
+            rnd = random.Random(seed0 + ncase)
+            cutsite = rnd.choice(cuts)
+            nl = rnd.choice([("\n",), ("\r\n",), ("\r",), ("\n", "\r\n", "\r")])
+            taglens = rnd.choice([(8, 30), (20, 70), (60, 130), (30, 64)])
+            barcodes, tags, cutsites = small_index(rnd, cutsite, nbar=rnd.randint(1, 24), ntag=rnd.randint(1, 120), taglens=taglens)
+            data = dirty_fastq(rnd, barcodes, tags, cutsites, nrec=rnd.randint(1, 3000), nl_choices=nl,
+                               long_lines=rnd.random() < 0.3, permanent_shifts=rnd.random() < 0.3)
+            ost = {}
+            want = c_oracle.COracle(barcodes, tags, cutsite).count_bytes(data, stats=ost)
+            eng.set_index(barcodes, tags, cutsite)
+            for tile_kb, fast in ((32, 1), (16, 1), (32, 0)):
+                eng.set_option("tile_kb", tile_kb)
+                eng.set_option("fastpath", fast)
+                eng.reset()
+                eng.count_bytes(data)
+                st = eng.stats()
+                assert (eng.counts_numpy() == want).all(), ("seed", seed0 + ncase, cutsite, nl, tile_kb, fast)
+                assert (st["reads"], st["barcut"], st["tag"]) == (ost["reads"], ost["barcut"], ost["tag"]), ("seed", seed0 + ncase)
+            ncase += 1
+    finally:
+        eng.set_option("tile_kb", 16)
+        eng.set_option("fastpath", 1)
+    print(" [fuzz campaign: %d cases] " % ncase, end="")
+    assert ncase > 0
+
+
 def test_tile_boundary_sweep(eng):
     """Slide a record across a tile boundary byte by byte (16 KiB tiles), with \\r\\n split across it."""
     barcodes, tags = ["AACG", "TTGACC"], ["TGCAGAAAC", "TGCAGGGGT"]
