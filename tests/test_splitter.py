@@ -194,15 +194,20 @@ def test_gpu_split_device_decisions(seed, adapter):
 
 
 @pytest.mark.gpu
-def test_gpu_split_file_large(tmp_path):
-    """More than one 32 MiB piece through td_split_file, CRLF line ends: files equal the oracle's."""
+@pytest.mark.parametrize("newline,threads", [(b"\r\n", None), (b"\n", None), (b"\n", "3"), (b"\n", "1")])
+def test_gpu_split_file_large(tmp_path, monkeypatch, newline, threads):
+    """More than one 32 MiB piece through td_split_file (records straddle the pieces): files equal the
+    oracle's.  CRLF files take the writers' byte-by-byte walk, LF files the shared line index; any number
+    of writer threads gives the same files."""
+    if threads:
+        monkeypatch.setenv("TAGDIG_SPLIT_THREADS", threads)
     import tagdigger_amd
     from tagdigger_amd import tagdigger_fun as tf
     rng = random.Random(11)
     barcodes = ["AACG", "TTGACC", "CGT", "GATTACAG"]
     ad = adapter_of("PstI-MspI-Hall")
-    block = synth_reads(rng, barcodes, "TGCAG", ad, 3000).replace(b"\n", b"\r\n")
-    data = block * (((40 << 20) // len(block)) + 1)
+    block = synth_reads(rng, barcodes, "TGCAG", ad, 3001).replace(b"\n", newline)
+    data = block * (((70 << 20) // len(block)) + 1)
     src = tmp_path / "big.fq"
     src.write_bytes(data)
     outs = [str(tmp_path / ("o%d.fq" % i)) for i in range(len(barcodes))]
