@@ -585,8 +585,9 @@ class ParInflate {
         for (auto &t : pool) t.join();
     }
 
-    // markers -> bytes through a 64 Ki-entry table (a literal is its own entry, marker 0x8000 | i is the
-    // window's byte i), sixteen marker-free symbols at a time by a pack.  min_idx: window positions below
+    // markers -> bytes: sixteen marker-free symbols at a time by a pack, sixteen consecutive markers by a
+    // copy, the rest through a 64 Ki-entry table (a literal is its own entry, marker 0x8000 | i is the
+    // window's byte i).  min_idx: window positions below
     // it lie before the member's start, and a marker pointing there makes the stream invalid
     static bool resolve(const uint16_t *src, size_t n, const uint8_t *win, uint8_t *dst, uint32_t min_idx) {
         std::unique_ptr<uint8_t[]> lut(new uint8_t[65536]);
@@ -602,9 +603,21 @@ class ParInflate {
             const __m128i a = _mm_loadu_si128((const __m128i *)(src + i)), b = _mm_loadu_si128((const __m128i *)(src + i + 8));
             if ((_mm_movemask_epi8(_mm_or_si128(a, b)) & 0xAAAA) == 0) {
                 _mm_storeu_si128((__m128i *)(dst + i), _mm_packus_epi16(a, b));
-            } else {
-                for (size_t k = i; k < i + 16; k++) dst[k] = t[src[k]];
+                continue;
             }
+            // sixteen markers in a row pointing at sixteen window bytes in a row (a copied string: most
+            // marker blocks of FASTQ are): one 16-byte copy from the window
+            const uint32_t first = src[i];
+            if (first >= 0x8000u && first <= 0xFFF0u) {
+                const __m128i base = _mm_set1_epi16((short)first);
+                const __m128i ea = _mm_add_epi16(base, _mm_setr_epi16(0, 1, 2, 3, 4, 5, 6, 7));
+                const __m128i eb = _mm_add_epi16(base, _mm_setr_epi16(8, 9, 10, 11, 12, 13, 14, 15));
+                if (_mm_movemask_epi8(_mm_and_si128(_mm_cmpeq_epi16(a, ea), _mm_cmpeq_epi16(b, eb))) == 0xFFFF) {
+                    _mm_storeu_si128((__m128i *)(dst + i), _mm_loadu_si128((const __m128i *)(win + (first & 0x7FFFu))));
+                    continue;
+                }
+            }
+            for (size_t k = i; k < i + 16; k++) dst[k] = t[src[k]];
         }
         for (; i < n; i++) dst[i] = t[src[i]];
         return ok;
