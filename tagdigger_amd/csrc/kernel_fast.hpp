@@ -93,7 +93,11 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
     // Main pass, 64-byte buckets: a thread's (single) wanted line is matched up to the tag-bucket loads
     // in its own tile and finished -- compares, count -- in the NEXT tile's phase D, so the probe's
     // latency runs under that tile's phases A-C instead of stalling the wave.
+#ifdef TD_NO_PIPE
+    constexpr bool PIPE = false;                      // (experiment: trades the pipelined probe for registers)
+#else
     constexpr bool PIPE = !FIX && W <= 3;
+#endif
     Pending<W> pd;
     bool pd_valid = false;
     // compares of the pending line; returns its count cell, or ~0 (the caller commits: the atomic is
