@@ -194,6 +194,53 @@ def test_gpu_split_device_decisions(seed, adapter):
 
 
 @pytest.mark.gpu
+def test_gpu_split_fuzz_campaign():
+    """Random barcode sets, adapter sets, read mixes, line ends and first-line offsets for
+    TD_FUZZ_SECONDS seconds (default 3): every decision of k_split equals the oracle's."""
+    import time
+    import tagdigger_amd
+    from tagdigger_amd import tagdigger_fun as tf
+    budget = float(os.environ.get("TD_FUZZ_SECONDS", "3"))
+    seed0 = int(os.environ.get("TD_FUZZ_SEED", "4242"))
+    t_end = time.time() + budget
+    names = sorted(G["adapters"].keys())
+    eng = tagdigger_amd.Engine(0)
+    ncase = 0
+    try:
+        while time.time() < t_end:
+            rng = random.Random(seed0 + ncase)
+            name = rng.choice(names)
+            ad = adapter_of(name)
+            cutsite = "TGCAT" if name.startswith("Nsi") else "TGCAG"
+            barcodes = []
+            while len(barcodes) < rng.randint(1, 12):
+                b = "".join(rng.choice("ACGT") for _ in range(rng.randint(3, 9)))
+                if not any((b + cutsite).startswith(o + cutsite) or (o + cutsite).startswith(b + cutsite) for o in barcodes):
+                    barcodes.append(b)
+            data = synth_reads(rng, barcodes, cutsite, ad, rng.randint(1, 1500))
+            nl = rng.choice([b"\n", b"\n", b"\r\n", b"\r"])
+            data = data.replace(b"\n", nl)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ends = tf._adapter_ends(ad, barcodes)
+            eng.set_splitter(barcodes, cutsite, ad[0][0].replace("^", ""), ad[1][0].replace("^", ""), ends)
+            d = eng.dev_alloc(len(data))
+            try:
+                eng.h2d(d, data)
+                res, _ = eng.split_device(d, len(data), first_line=4 * rng.randint(0, 3))
+                want = []
+                po.barcode_splitter_bytes(data, barcodes, cutsite, ad, decisions=want)
+                got = [(int(a), int(b)) for a, b in res[:len(want)]]
+                assert got == [(b, 999 if b < 0 else c) for b, c in want], ("seed", seed0 + ncase, name, nl)
+            finally:
+                eng.dev_free(d)
+            ncase += 1
+    finally:
+        eng.close()
+    print(" [splitter fuzz campaign: %d cases] " % ncase, end="")
+    assert ncase > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("newline,threads", [(b"\r\n", None), (b"\n", None), (b"\n", "3"), (b"\n", "1")])
 def test_gpu_split_file_large(tmp_path, monkeypatch, newline, threads):
     """More than one 32 MiB piece through td_split_file (records straddle the pieces): files equal the
