@@ -580,7 +580,9 @@ class ParInflate {
         std::atomic<int> next{0};
         auto work = [&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); };
         std::vector<std::thread> pool;
-        for (int i = 1; i < std::min(n, threads_); i++) pool.emplace_back(work);
+        for (int i = 1; i < std::min(n, threads_); i++) {
+            try { pool.emplace_back(work); } catch (...) { break; }      // (no more threads to be had: fewer workers, same work)
+        }
         work();
         for (auto &t : pool) t.join();
     }
