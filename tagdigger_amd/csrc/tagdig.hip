@@ -1109,6 +1109,7 @@ struct SplitFiles {
     const std::vector<std::string> &barcodes;
     std::vector<FILE *> out;
     std::vector<std::string> pend;            // per output file: bytes not yet handed to stdio
+    std::vector<uint8_t> owner;               // per barcode: the writer thread its file belongs to
     explicit SplitFiles(const std::vector<std::string> &b) : barcodes(b) {}
     ~SplitFiles() { for (FILE *f : out) if (f) fclose(f); }
 };
@@ -1171,7 +1172,7 @@ struct SplitWriter {
     bool stop = false, nonascii = false, io_error = false;
 
     SplitWriter(SplitFiles &f, uint32_t t, uint32_t n) : files(f), barcodes(f.barcodes), out(f.out), pend(f.pend), tid(t), nthreads(n) {}
-    bool mine() const { return cur_bar > -1 && (uint32_t)cur_bar % nthreads == tid; }
+    bool mine() const { return cur_bar > -1 && files.owner[(size_t)cur_bar] == tid; }
 
     static void stripped(const uint8_t *p, size_t n, std::string &dst, bool upper) {
         size_t a = 0, b = n;
@@ -1222,25 +1223,42 @@ struct SplitWriter {
         lineindex++;
     }
     // one whole record whose four lines are lines k .. k + 3 of the piece
+    // (the same from the piece's bytes directly: no intermediate strings)
+    struct Span { const uint8_t *p; size_t n; };
+    static Span strip(const uint8_t *p, size_t n) {
+        size_t a = 0, b = n;
+        while (a < b && host_blank(p[a])) a++;
+        while (b > a && host_blank(p[b - 1])) b--;
+        return {p + a, b - a};
+    }
+    static void put_slice(std::string &o, Span s, long a, long b, bool upper) {
+        const long n = (long)s.n;
+        if (b < 0) { b += n; if (b < 0) b = 0; }
+        if (b > n) b = n;
+        if (a < b) {
+            const size_t at = o.size();
+            o.append((const char *)s.p + a, (size_t)(b - a));
+            if (upper) for (size_t i = at; i < o.size(); i++) { const char c = o[i]; o[i] = (char)(c - (((unsigned)(c - 'a') < 26u) << 5)); }
+        }
+        o.push_back('\n');
+    }
     void record(const uint8_t *p, const uint32_t *st, const int2 &d) {
         cur_bar = d.x; cur_slice = d.y;
         reads++;
         if (mine()) {
-            stripped(p + st[0], st[1] - 1 - st[0], comment1, false);
-            stripped(p + st[1], st[2] - 1 - st[1], sequence, true);
-            stripped(p + st[2], st[3] - 1 - st[2], comment2, false);
-            stripped(p + st[3], st[4] - 1 - st[3], quality, false);
+            const Span c1 = strip(p + st[0], st[1] - 1 - st[0]), sq = strip(p + st[1], st[2] - 1 - st[1]),
+                       c2 = strip(p + st[2], st[3] - 1 - st[2]), ql = strip(p + st[3], st[4] - 1 - st[3]);
             barcut++;
             const std::string &bc = barcodes[(size_t)cur_bar];
             const long slice1 = (long)bc.size();
             long slice2 = cur_slice;
-            if (slice2 == 999) slice2 = (long)sequence.size(); else clipped++;
+            if (slice2 == 999) slice2 = (long)sq.n; else clipped++;
             std::string &o = pend[(size_t)cur_bar];
-            o.append(comment1); o.append(bc); o.push_back('\n');
-            put_slice(o, sequence, slice1, slice2);
-            if (comment2 == "+") o.append("+\n");
-            else { o.append(comment1); o.append(bc); o.push_back('\n'); }
-            put_slice(o, quality, slice1, slice2);
+            o.append((const char *)c1.p, c1.n); o.append(bc); o.push_back('\n');
+            put_slice(o, sq, slice1, slice2, true);
+            if (c2.n == 1 && c2.p[0] == '+') o.append("+\n");
+            else { o.append((const char *)c1.p, c1.n); o.append(bc); o.push_back('\n'); }
+            put_slice(o, ql, slice1, slice2, false);
             if (o.size() >= FLUSH_AT && !flush((size_t)cur_bar)) io_error = true;
         }
         if (reads >= max_reads) stop = true;
@@ -1393,7 +1411,7 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
     };
     SplitFiles files(h->sp_barcodes);
     const char *tenv = getenv("TAGDIG_SPLIT_THREADS");
-    const uint32_t nthr = (uint32_t)std::max<long>(1, std::min<long>({tenv ? atol(tenv) : 16L, (long)h->sp_barcodes.size(),
+    const uint32_t nthr = (uint32_t)std::max<long>(1, std::min<long>({tenv ? atol(tenv) : 16L, 256L, (long)h->sp_barcodes.size(),
                                                                       (long)std::max<unsigned>(1, std::thread::hardware_concurrency())}));
     std::vector<SplitWriter> writers;
     for (uint32_t t = 0; t < nthr; t++) { writers.emplace_back(files, t, nthr); writers.back().max_reads = std::max<uint64_t>(1, max_reads); }
@@ -1437,6 +1455,8 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
         files.out.push_back(f);
     }
     files.pend.assign(files.out.size(), std::string());
+    files.owner.resize(files.out.size());
+    for (size_t b = 0; b < files.owner.size(); b++) files.owner[b] = (uint8_t)(b % nthr);
     std::vector<uint8_t> carry;
     bool eof = false;
     // TAGDIG_SPLIT_TIMING=1: where the wall time of this call went, on stderr
