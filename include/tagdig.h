@@ -165,7 +165,8 @@ int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
  * TAGDIG_INFLATE_STATS    set: the chunk-parallel decoder reports batches, chunks and where its time went, on stderr
  * TAGDIG_ZLIB             set: ordinary gzip through zlib's gzread, BGZF members through zlib's inflate
  * TAGDIG_SPLIT_THREADS    writer threads of td_split_file (default 16, at most the host's cores and the number of barcodes)
- * TAGDIG_SPLIT_TIMING     set: td_split_file reports where its wall time went, on stderr */
+ * TAGDIG_SPLIT_TIMING     set: td_split_file reports where its wall time went, on stderr
+ * TAGDIG_SPLIT_DISCARD    set: td_split_file assembles the records but writes nothing (timing only) */
 
 /* ---- tuning / introspection ------------------------------------------------ */
 /* Defaults are the measured best; every setting gives the same counts.  name:

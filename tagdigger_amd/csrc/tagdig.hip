@@ -1122,6 +1122,8 @@ struct PieceIndex {
     size_t nlines = 0;
     bool has_cr = false, nonascii = false;
     std::vector<uint8_t> flags;                  // per thread: 1 = saw '\r', 2 = saw a byte >= 0x80
+    // whole records dealt out: bucket[s * nthreads + o] = the records of scanner s's share that writer o owns
+    std::vector<std::vector<uint32_t>> bucket;
     // a barrier for the threads of one piece
     std::mutex mu; std::condition_variable cv; uint32_t arrived = 0, generation = 0, nthreads = 1;
     void barrier() {
@@ -1191,7 +1193,8 @@ struct SplitWriter {
     }
     bool flush(size_t k) {
         std::string &o = pend[k];
-        const bool ok = o.empty() || fwrite(o.data(), 1, o.size(), out[k]) == o.size();
+        static const bool discard = getenv("TAGDIG_SPLIT_DISCARD") != nullptr;      // (timing only: assemble the records, write nothing)
+        const bool ok = o.empty() || discard || fwrite(o.data(), 1, o.size(), out[k]) == o.size();
         o.clear();
         return ok;
     }
@@ -1242,10 +1245,9 @@ struct SplitWriter {
         }
         o.push_back('\n');
     }
-    void record(const uint8_t *p, const uint32_t *st, const int2 &d) {
+    void own_record(const uint8_t *p, const uint32_t *st, const int2 &d) {
         cur_bar = d.x; cur_slice = d.y;
-        reads++;
-        if (mine()) {
+        {
             const Span c1 = strip(p + st[0], st[1] - 1 - st[0]), sq = strip(p + st[1], st[2] - 1 - st[1]),
                        c2 = strip(p + st[2], st[3] - 1 - st[2]), ql = strip(p + st[3], st[4] - 1 - st[3]);
             barcut++;
@@ -1261,23 +1263,41 @@ struct SplitWriter {
             put_slice(o, ql, slice1, slice2, false);
             if (o.size() >= FLUSH_AT && !flush((size_t)cur_bar)) io_error = true;
         }
-        if (reads >= max_reads) stop = true;
-        lineindex += 4;
     }
     // all lines of a piece that ends at a line end (or at the end of the file)
+    double t_index = 0, t_records = 0;           // (thread 0's, for TAGDIG_SPLIT_TIMING)
     void piece(const uint8_t *p, size_t n, const int2 *res, PieceIndex &ix) {
+        const auto clk = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = clk();
         ix.scan(tid, p, n);
         ix.barrier();
         if (tid == 0) ix.merge(n);
         ix.barrier();
+        const double t1 = clk();
+        t_index += t1 - t0;
+        struct Done { double &acc; double from; decltype(clk) &c; ~Done() { acc += c() - from; } } done{t_records, t1, clk};
         if (tid == 0 && ix.nonascii) nonascii = true;
         if (!ix.has_cr) {                                                // the usual file: '\n' only
             const uint32_t *st = ix.starts.data();
             size_t k = 0;
-            // the lines of a record begun in the piece before, whole records, the lines of a record cut by the piece's end
+            // the lines of a record begun in the piece before (every thread walks them: all keep the same state)
             while (k < ix.nlines && (lineindex & 3) != 0 && !stop) { line(p + st[k], st[k + 1] - 1 - st[k], res); k++; }
-            while (k + 4 <= ix.nlines && !stop) { record(p, st + k, *res++); k += 4; }
-            // (a trailing partial comment line is kept by every thread: its record's barcode is not known yet)
+            // whole records: each thread sorts its share of them by owner, then every writer takes its own
+            size_t nrec = stop ? 0 : (ix.nlines - k) / 4;
+            if (max_reads - reads < nrec) nrec = (size_t)(max_reads - reads);          // (reads < max_reads while not stopped)
+            const size_t lo = nrec * tid / nthreads, hi = nrec * (tid + 1) / nthreads;
+            for (uint32_t o = 0; o < nthreads; o++) ix.bucket[(size_t)tid * nthreads + o].clear();
+            for (size_t j = lo; j < hi; j++) {
+                const int b = res[j].x;
+                if (b > -1) ix.bucket[(size_t)tid * nthreads + files.owner[(size_t)b]].push_back((uint32_t)j);
+            }
+            ix.barrier();
+            for (uint32_t sc = 0; sc < nthreads; sc++)
+                for (const uint32_t j : ix.bucket[(size_t)sc * nthreads + tid]) own_record(p, st + k + 4 * (size_t)j, res[j]);
+            reads += nrec; lineindex += 4 * nrec; res += nrec; k += 4 * nrec;
+            if (reads >= max_reads) stop = true;
+            ix.barrier();                                                // (the buckets are refilled by the next piece)
+            // the lines of a record cut by the piece's end (its barcode is not known yet: every thread keeps them)
             while (k < ix.nlines && !stop) { line(p + st[k], st[k + 1] - 1 - st[k], res); k++; }
             return;
         }
@@ -1417,12 +1437,39 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
     for (uint32_t t = 0; t < nthr; t++) { writers.emplace_back(files, t, nthr); writers.back().max_reads = std::max<uint64_t>(1, max_reads); }
     SplitWriter &w = writers[0];                 // (every writer sees the same lines: thread 0 speaks for the line numbers)
     PieceIndex pindex;
-    pindex.nthreads = nthr; pindex.part.resize(nthr); pindex.flags.assign(nthr, 0);
-    auto write_piece = [&](const uint8_t *p, size_t n, const int2 *res) {
-        std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < nthr; t++) pool.emplace_back([&, t]() { writers[t].piece(p, n, res, pindex); });
-        writers[0].piece(p, n, res, pindex);
+    pindex.nthreads = nthr; pindex.part.resize(nthr); pindex.flags.assign(nthr, 0); pindex.bucket.resize((size_t)nthr * nthr);
+    // the writer threads live as long as this call: a piece is announced to them, the caller works as
+    // writer 0, and all meet again at the end of the piece
+    struct Job { const uint8_t *p = nullptr; size_t n = 0; const int2 *res = nullptr; uint64_t seq = 0; bool quit = false;
+                 std::mutex mu; std::condition_variable cv; uint32_t finished = 0; } job;
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < nthr; t++)
+        pool.emplace_back([&, t]() {
+            uint64_t seen = 0;
+            for (;;) {
+                const uint8_t *p; size_t n; const int2 *res;
+                {
+                    std::unique_lock<std::mutex> g(job.mu);
+                    job.cv.wait(g, [&]() { return job.quit || job.seq != seen; });
+                    if (job.quit) return;
+                    seen = job.seq; p = job.p; n = job.n; res = job.res;
+                }
+                writers[t].piece(p, n, res, pindex);
+                { std::lock_guard<std::mutex> g(job.mu); job.finished++; }
+                job.cv.notify_all();
+            }
+        });
+    struct PoolEnd { Job &j; std::vector<std::thread> &pool; ~PoolEnd() {
+        { std::lock_guard<std::mutex> g(j.mu); j.quit = true; }
+        j.cv.notify_all();
         for (auto &th : pool) th.join();
+    } } pool_end{job, pool};
+    auto write_piece = [&](const uint8_t *p, size_t n, const int2 *res) {
+        { std::lock_guard<std::mutex> g(job.mu); job.p = p; job.n = n; job.res = res; job.finished = 0; job.seq++; }
+        job.cv.notify_all();
+        writers[0].piece(p, n, res, pindex);
+        std::unique_lock<std::mutex> g(job.mu);
+        job.cv.wait(g, [&]() { return job.finished == nthr - 1; });
     };
     int rc = TD_OK;
     const size_t cap = (size_t)32 << 20;
@@ -1559,7 +1606,8 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
     for (auto &wr : writers) { io_error |= wr.io_error; n_barcut += wr.barcut; n_clipped += wr.clipped; }
     if (io_error && !rc) rc = fail(TD_E_IO, "error writing an output file");
     if (stats) { stats[0] = w.reads; stats[1] = n_barcut; stats[2] = n_clipped; }
-    if (timing) fprintf(stderr, "td_split_file: read %.3f s, waiting for the GPU %.3f s, writing %.3f s\n", t_read, t_wait, t_write);
+    if (timing) fprintf(stderr, "td_split_file: read %.3f s, waiting for the GPU %.3f s, writing %.3f s (thread 0: line index %.3f s, records %.3f s)\n",
+                        t_read, t_wait, t_write, w.t_index, w.t_records);
     if (rc) return rc;
     if (w.nonascii) return fail(TD_E_NONASCII, "the splitter accepts ASCII FASTQ only (a byte >= 0x80 was found)");
     if (have_st) return check_device_errors(h, st);
