@@ -161,6 +161,9 @@ struct td_handle {
     // barcode splitter (td_set_splitter / td_split_*)
     bool have_splitter = false;
     std::vector<std::string> sp_barcodes;
+    // td_split_file's two staging slots, kept between calls (pinned allocations cost tens of milliseconds)
+    struct SplitSlot { uint8_t *pin = nullptr, *dev = nullptr; int2 *res_dev = nullptr, *res_pin = nullptr; size_t n = 0;
+                       hipEvent_t done = nullptr; bool pending = false; } sp_slot[2];
     uint32_t sp_bblob_bytes = 0, sp_off_bmeta = 0, sp_off_bdir = 0, sp_cutlen = 0;
     unsigned long long sp_site[2] = {0, 0};
     uint32_t sp_site_len[2] = {0, 0};
@@ -504,6 +507,13 @@ void td_destroy(td_handle *h) {
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
     h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release();
     for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto &sl : h->sp_slot) {
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.res_dev) (void)hipFree(sl.res_dev);
+        if (sl.res_pin) (void)hipHostFree(sl.res_pin);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->work_stream) (void)hipStreamDestroy(h->work_stream);
     delete h;
@@ -1474,26 +1484,21 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
     int rc = TD_OK;
     const size_t cap = (size_t)32 << 20;
     // two slots: the GPU decides piece k + 1 while the host writes piece k
-    struct Slot { uint8_t *pin = nullptr, *dev = nullptr; int2 *res_dev = nullptr, *res_pin = nullptr; size_t n = 0; hipEvent_t done = nullptr; bool pending = false; } slot[2];
+    using Slot = td_handle::SplitSlot;
+    Slot (&slot)[2] = h->sp_slot;                      // (allocated on first use, freed by td_destroy)
     auto cleanup = [&]() {
-        for (auto &sl : slot) {
-            if (sl.pin) (void)hipHostFree(sl.pin);
-            if (sl.dev) (void)hipFree(sl.dev);
-            if (sl.res_dev) (void)hipFree(sl.res_dev);
-            if (sl.res_pin) (void)hipHostFree(sl.res_pin);
-            if (sl.done) (void)hipEventDestroy(sl.done);
-        }
         zsrc.close();
         if (pf) fclose(pf);
         pf = nullptr;
     };
 #define SPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(TD_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
     for (auto &sl : slot) {
-        SPCHK(hipHostMalloc((void **)&sl.pin, cap, hipHostMallocDefault));
-        SPCHK(hipMalloc((void **)&sl.dev, cap));
-        SPCHK(hipMalloc((void **)&sl.res_dev, max_seq_lines(cap) * sizeof(int2)));          // (a line holds at least its terminator)
-        SPCHK(hipHostMalloc((void **)&sl.res_pin, max_seq_lines(cap) * sizeof(int2), hipHostMallocDefault));
-        SPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        sl.pending = false; sl.n = 0;
+        if (!sl.pin) SPCHK(hipHostMalloc((void **)&sl.pin, cap, hipHostMallocDefault));
+        if (!sl.dev) SPCHK(hipMalloc((void **)&sl.dev, cap));
+        if (!sl.res_dev) SPCHK(hipMalloc((void **)&sl.res_dev, max_seq_lines(cap) * sizeof(int2)));          // (a line holds at least its terminator)
+        if (!sl.res_pin) SPCHK(hipHostMalloc((void **)&sl.res_pin, max_seq_lines(cap) * sizeof(int2), hipHostMallocDefault));
+        if (!sl.done) SPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     for (uint32_t b = 0; b < h->sp_barcodes.size(); b++) {
         FILE *f = fopen(out_paths[b], "wb");
