@@ -85,7 +85,14 @@ class Engine:
 
     # ------------------------------------------------------------------ index
     def set_index(self, barcodes, tags, cutsite="TGCAG"):
-        """Set-up of find_tags_fastq, tagdigger_fun.py:197-233."""
+        """Set-up of find_tags_fastq, tagdigger_fun.py:197-233.  The index on the device is kept when the
+        same barcodes, tags and cut site come again (the libraries of one run usually share a barcode set):
+        only the counts are zeroed then, as a fresh index would have them."""
+        key = (tuple(barcodes), tuple(tags), cutsite)
+        if key == getattr(self, "_index_key", None):
+            self.reset()
+            return
+        self._index_key = None
         assert all([set(barcode.upper()) <= set('ACGT') for barcode in barcodes]), "Non-ACGT barcode."
         cutsite = cutsite.upper()
         assert set(cutsite) <= set('ACGTNRYKMSWBDHV'), "Invalid cut site."
@@ -107,6 +114,7 @@ class Engine:
         B.check(self._L.td_set_index(self._h, _c_strings(barcut), len(barcut), barnum, off,
                                      _c_strings(tags), len(tags)))
         self.barnum, self.ntags = barnum, len(tags)
+        self._index_key = key
 
     # ------------------------------------------------------------------ counting
     def reset(self):

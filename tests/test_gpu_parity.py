@@ -368,6 +368,25 @@ def test_gzip_file_counts_like_plain(tmp_path, monkeypatch, capfd, decoder):
 
 
 @pytest.mark.gpu
+def test_index_is_kept_between_identical_calls(tmp_path):
+    """The same barcodes / tags / cut site again: the device index is reused and the counts start from zero;
+    anything different rebuilds it."""
+    from tagdigger_amd import tagdigger_fun as tf
+    case = next(c for c in load_golden("hotpath_random.json") if c["name"] == "random000")
+    path = write_case_file(case, tmp_path)
+    bars, tags, cut = case["barcodes"], case["tags"], case["kwargs"]["cutsite"]
+    first = tf.find_tags_fastq(path, bars, tags, cutsite=cut)
+    again = tf.find_tags_fastq(path, list(bars), list(tags), cutsite=cut)          # equal lists, other objects
+    assert first == again == case["counts"]
+    fewer = tf.find_tags_fastq(path, bars, tags[:-1], cutsite=cut)
+    assert fewer == [row[:-1] for row in case["counts"]]
+    assert tf.find_tags_fastq(path, bars, tags, cutsite=cut) == case["counts"]
+    with pytest.raises(AssertionError, match="Non-ACGT tag"):
+        tf.find_tags_fastq(path, bars, tags[:-1] + ["ACGN"], cutsite=cut)
+    assert tf.find_tags_fastq(path, bars, tags, cutsite=cut) == case["counts"]      # (after a failed set-up too)
+
+
+@pytest.mark.gpu
 def test_find_tags_fastq_many(tmp_path):
     """The batched call returns, in file order, what the single-file call returns (the first
     file's is a reference output); one barcode list for all files or one per file; an error in one file
