@@ -63,7 +63,7 @@ class ParInflate {
         // a chunk stops at the first block boundary past this much output (bounds the buffers on highly
         // compressible input: the chain then ends there and the next batch tries fewer chunks)
         cap_ = std::max<size_t>(chunk_ * 12, (size_t)1 << 22);
-        cur_ = max_chunks_;
+        cur_ = std::max(1, threads_ / 2);                        // a short first batch (the reader waits for two), doubling from there
         for (auto &set : sets_) set.reset(new Chunk[max_chunks_]);
         chunks_ = sets_[0].get();
         pend_.valid = false; crc_run_ = 0;
