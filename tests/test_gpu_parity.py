@@ -132,6 +132,7 @@ def test_fuzz_campaign(eng):
     budget = float(os.environ.get("TD_FUZZ_SECONDS", "3"))
     seed0 = int(os.environ.get("TD_FUZZ_SEED", "12345"))
     t_end = time.time() + budget
+    next_note = time.time() + 30
     ncase = 0
     cuts = ["TGCAG", "CWGC", "", "RCATGY", "TGCAT", "CATGG", "GWC"]
     try:
@@ -155,6 +156,9 @@ def test_fuzz_campaign(eng):
                 assert (eng.counts_numpy() == want).all(), ("seed", seed0 + ncase, cutsite, nl, tile_kb, fast)
                 assert (st["reads"], st["barcut"], st["tag"]) == (ost["reads"], ost["barcut"], ost["tag"]), ("seed", seed0 + ncase)
             ncase += 1
+            if time.time() >= next_note:                      # (a long soak must not look hung)
+                print(" [%d cases so far] " % ncase, end="", flush=True)
+                next_note = time.time() + 30
     finally:
         eng.set_option("tile_kb", 16)
         eng.set_option("fastpath", 1)

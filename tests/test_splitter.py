@@ -203,6 +203,7 @@ def test_gpu_split_fuzz_campaign():
     budget = float(os.environ.get("TD_FUZZ_SECONDS", "3"))
     seed0 = int(os.environ.get("TD_FUZZ_SEED", "4242"))
     t_end = time.time() + budget
+    next_note = time.time() + 30
     names = sorted(G["adapters"].keys())
     eng = tagdigger_amd.Engine(0)
     ncase = 0
@@ -234,6 +235,9 @@ def test_gpu_split_fuzz_campaign():
             finally:
                 eng.dev_free(d)
             ncase += 1
+            if time.time() >= next_note:                      # (a long soak must not look hung)
+                print(" [%d cases so far] " % ncase, end="", flush=True)
+                next_note = time.time() + 30
     finally:
         eng.close()
     print(" [splitter fuzz campaign: %d cases] " % ncase, end="")
