@@ -1,16 +1,18 @@
 // Chunk-parallel decoder for ordinary (single-stream) gzip on the host side of libtagdig (no GPU code).
 //
 // A DEFLATE stream has no index, and a block may copy from the 32 KiB before it, so a stream is
-// normally decoded by one thread.  This decoder works through the compressed file in batches of one
-// chunk per thread:
-//   1. every thread but the first looks for a block start inside its chunk: it tries bit positions
+// normally decoded by one thread.  This decoder works through the compressed file in batches of two
+// chunks per thread (1 MiB of compressed data each by default; the first batches are shorter), the
+// chunks of a step taken up by the threads as they become free:
+//   1. for every chunk but the first a block start is searched inside it: bit positions are tried
 //      in turn for a non-final dynamic-Huffman header that only a compressor would write (all three
-//      codes complete), decodes that block, and requires a second valid header behind it;
-//   2. it then decodes from there into 16-bit symbols: literals as themselves, and a copy that reaches
+//      codes complete), that block is decoded, and a second valid header must follow it;
+//   2. the chunk is then decoded from there into 16-bit symbols: literals as themselves, and a copy that reaches
 //      into the unknown 32 KiB before the chunk as a marker 0x8000 | position-in-that-window (markers
-//      are copied around like literals).  The first thread starts at the known position with the
-//      known window and decodes bytes.  Every thread stops at the first block boundary at or past the
-//      start its successor found;
+//      are copied around like literals).  The first chunk starts at the known position with the
+//      known window and is decoded as bytes.  Every chunk stops at the first block boundary at or past
+//      the start its successor found (or past 12x its compressed size of output: that bounds the
+//      buffers on highly compressible input, and the next batch goes on from there);
 //   3. the chunks are chained on the calling thread: a chunk counts only if its predecessor stopped
 //      exactly on its start (so a false start from step 1 is dropped with everything behind it, and
 //      the next batch begins where the chain ended -- the result never depends on the search), and
