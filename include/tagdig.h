@@ -177,7 +177,7 @@ int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
  *   "prescan"        1: the exact kernel with a separate line-count pass instead of look-back
  *   "nt_loads"       1 (default): stream the FASTQ with non-temporal loads
  *   "prio"           wave priority per phase of the fast path, two bits each: phase A | B-C << 2 |
- *                    D << 4 | end of A << 6 (default 0xD4)
+ *                    D << 4 | end of A << 6 (default 0xE4)
  *   "table_load_pct" fill of the tag hash table, 10..95 (default 50); applies to the next td_set_index
  *   "stagger"        start-up stagger of co-resident workgroups, in 4096-cycle units (default 0)
  *   "timing"         1: record HIP events around every launch for td_kernel_time_ms

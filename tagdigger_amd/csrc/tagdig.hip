@@ -177,7 +177,7 @@ struct td_handle {
     uint32_t debug_ablate = 0;
     double table_load = 0.5;
     int stagger = 0;
-    int prio = 0xD4;            // wave priority per phase of the fast path: A 0, B-C 1, D 1, end of A 3 (kernel_fast.hpp set_prio)
+    int prio = 0xE4;            // wave priority per phase of the fast path: A 0, B-C 1, D 2, end of A 3 (kernel_fast.hpp set_prio)
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
