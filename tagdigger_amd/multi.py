@@ -127,12 +127,14 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
         first_line = int(sum(int(t[0]) for t in every[:rank]))
     else:
         first_line = 0
-    # the maxreads bound is global: reads that belong to earlier shards come off this shard's share
+    # The maxreads bound is global and so is the line index each shard is counted with: device and oracle
+    # both compare the bound with the GLOBAL read ordinal (first_line + lines seen), so it is passed on
+    # unchanged; a shard that starts at or past the bound is skipped.
     bound = max(1, int(math.ceil(min(maxreads, 2 ** 62))))
     reads_before = (first_line + 2) // 4               # sequence lines (index 1 mod 4) below first_line
     total = torch.zeros((len(barcodes), len(tags)), dtype=torch.int64, device=device if device is not None else "cpu")
     if len(data) and reads_before < bound:
-        m = counter(data, barcodes, tags, cutsite, first_line, bound - reads_before)
+        m = counter(data, barcodes, tags, cutsite, first_line, bound)
         total += torch.tensor(m, dtype=torch.int64).reshape(len(barcodes), len(tags)).to(total.device)
     if world > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM)

@@ -131,7 +131,7 @@ def _shard_worker(rank, world, port, path, barcodes, tags, maxreads, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("maxreads", [5e9, 150, 3])
+@pytest.mark.parametrize("maxreads", [5e9, 150, 3, 250, 300, 399])   # 250-399: the bound falls inside the second shard
 def test_two_ranks_shard_one_file(tmp_path, maxreads):
     from oracle import c_oracle
     path, data, barcodes, tags = _dirty_file(tmp_path, "mixed", seed=11)
