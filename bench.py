@@ -8,14 +8,19 @@ A "step" is one pass of the hot path (libtagdig's fused count kernel, through
 the C-ABI) over one synthetic FASTQ library already resident in HBM, plus --
 for N > 1 -- the one RCCL all-reduce of the integer count matrix.  Workload at
 N=1: the configuration BASELINE.json's metric is quoted on (200 M reads x 384
-barcodes x 100 k tags, 100 bp reads, 219 B/record = 43.8 GB), one such library
-per GPU (weak scaling, BASELINE config 4's file-per-GPU sharding).
+barcodes x 100 k tags, 100 bp reads, 219 B/record = 43.8 GB).
+  --scaling weak   (default) one such library per GPU: BASELINE config 4's file-per-GPU sharding
+  --scaling strong ONE library byte-sharded over the N GPUs (each shard counted with its true
+                   first line index), the same single all-reduce
+  --config 2|4|5   the other BASELINE index shapes (parity-test cases; not the headline line)
 
 Rank 0 prints ONE JSON line (see the driver contract in the task statement).
 The `roofline` object prices the count kernel against HBM bandwidth using
 ALGORITHMIC bytes = 219 B x reads per launch and the kernel's own duration
-from HIP events on the launch stream; `cpu_baseline` times the oracle's C
-restatement on a bounded prefix of the same stream on this box's host cores.
+from HIP events on the launch stream; `cpu_baseline` times the oracle (the
+reference-equivalent Python restatement, and its C port beside it) on a bounded
+prefix of the same stream on this box's host cores; `tiers` reports the
+PCIe- and file-inclusive rates (never `value`).
 """
 import argparse
 import json
@@ -35,22 +40,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=200_000_000, help="reads per GPU")
-    ap.add_argument("--barcodes", type=int, default=384)
-    ap.add_argument("--markers", type=int, default=50_000, help="tags = 2 x markers")
-    ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--cutsite", default="TGCAG", help="cut site, IUPAC codes allowed (BASELINE config 5: CWGC)")
-    ap.add_argument("--bclen-max", type=int, default=8, help="barcodes are 4..N bases long (config 5: 10)")
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5),
+                    help="BASELINE config whose index shape and seed to use (3 = the one the metric is quoted on)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (weak) / in the library (strong); 0 = 200 M, config 2: 50 M")
+    ap.add_argument("--barcodes", type=int, default=0)
+    ap.add_argument("--markers", type=int, default=0, help="tags = 2 x markers")
+    ap.add_argument("--seed", type=int, default=-1)
+    ap.add_argument("--cutsite", default="", help="cut site, IUPAC codes allowed (BASELINE config 5: CWGC)")
+    ap.add_argument("--bclen-max", type=int, default=0, help="barcodes are 4..N bases long (config 5: 10)")
+    ap.add_argument("--skew", type=float, default=0.0, help="Zipf exponent of the hit distribution over tags and barcodes (0 = uniform)")
     ap.add_argument("--tile-kb", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="reads in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="reads in the C port's cpu_baseline sample (0 = skip cpu_baseline)")
     ap.add_argument("--cpu-python-sample", type=int, default=400_000,
-                    help="reads for the pure-Python restatement's timing inside cpu_baseline (0 = skip)")
+                    help="reads for the pure-Python restatement's timing (cpu_baseline.value; 0 = skip)")
+    ap.add_argument("--oracle-sample", type=int, default=2_000_000,
+                    help="reads of the resident stream counted by the C oracle and compared with a GPU pass over the same bytes (0 = skip)")
+    ap.add_argument("--tier-reads", type=int, default=8_000_000, help="reads in the T2/T3 tier measurements (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--stagger", type=int, default=-1)
     ap.add_argument("--table-load", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
     ap.add_argument("--prio", type=int, default=-1)
+    ap.add_argument("--opt", action="append", default=[], help="name=value passed to td_set_option (repeatable)")
     ap.add_argument("--debug-ablate", type=int, default=0, help="timing-only kernel ablation bits (implies --no-check)")
     args = ap.parse_args()
 
@@ -81,10 +94,28 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     import tagdigger_amd
-    from tagdigger_amd.synth import SynthConfig
+    from tagdigger_amd.synth import CONFIGS, SynthConfig
 
-    cfg = SynthConfig(nreads=args.reads, nbar=args.barcodes, nmarkers=args.markers, seed=args.seed,
-                      cutsite=args.cutsite, bclen=(4, args.bclen_max))
+    base = dict(CONFIGS[args.config])
+    if args.config in (4, 5):
+        base["nreads"] = 200_000_000                    # (one library; config 5's 1 B reads are five of them)
+    if args.reads:
+        base["nreads"] = args.reads
+    if args.barcodes:
+        base["nbar"] = args.barcodes
+    if args.markers:
+        base["nmarkers"] = args.markers
+    if args.seed >= 0:
+        base["seed"] = args.seed
+    if args.cutsite:
+        base["cutsite"] = args.cutsite
+    if args.bclen_max:
+        base["bclen"] = (4, args.bclen_max)
+    if args.skew:
+        base["skew"] = args.skew
+    cfg = SynthConfig(**base)
+    default_workload = (args.config == 3 and not (args.reads or args.barcodes or args.markers or args.cutsite or args.bclen_max
+                                                   or args.skew or args.seed >= 0))
     eng = tagdigger_amd.Engine(local_rank)
     if args.tile_kb:
         eng.set_option("tile_kb", args.tile_kb)
@@ -98,13 +129,26 @@ def main():
         eng.set_option("nt_loads", args.nt)
     if args.prio >= 0:
         eng.set_option("prio", args.prio)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v, 0))
     if args.debug_ablate:
         eng.set_option("debug_ablate", args.debug_ablate)
         args.no_check = True
-    nbytes = cfg.nbytes()
+
+    # ---- this rank's share of the stream
+    if args.scaling == "weak":
+        my_reads, first_read = cfg.nreads, rank * cfg.nreads         # its own library = its own slice of the stream
+        first_line = 0                                               # ... a file of its own: line 0
+        job_reads = cfg.nreads * world
+    else:
+        lo, hi = cfg.nreads * rank // world, cfg.nreads * (rank + 1) // world
+        my_reads, first_read = hi - lo, lo                           # a byte range of ONE file, cut at line starts
+        first_line = 4 * lo                                          # ... counted with its true line index
+        job_reads = cfg.nreads
+    nbytes = my_reads * cfg.record_bytes
     fastq = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    first_read = rank * cfg.nreads                      # this GPU's library = its own slice of the stream
-    cfg.fill_device(eng, fastq.data_ptr(), first_read, cfg.nreads)
+    cfg.fill_device(eng, fastq.data_ptr(), first_read, my_reads)
     # The matrix lives in torch tensors so that RCCL can reduce it in place.  With several GPUs there are
     # two: the all-reduce of one pass (the path's one exchange: an integer sum over xGMI) runs on RCCL's
     # stream while the next pass counts into the other matrix.
@@ -125,7 +169,7 @@ def main():
             reducing[b] = None
         mats[b].zero_()
         eng.bind_counts(mats[b].data_ptr())
-        eng.count_device(fastq.data_ptr(), nbytes, stream=stream)
+        eng.count_device(fastq.data_ptr(), nbytes, first_line=first_line, stream=stream)
         if world > 1:
             reducing[b] = dist.all_reduce(mats[b], async_op=True)
         return mats[b]
@@ -147,23 +191,44 @@ def main():
     # ---- correctness of what is being timed (rank-local shard, before any all-reduce)
     check = None
     if not args.no_check:
-        # the whole matrix against the one the generator's own choices imply (built on the device from
+        # (1) the whole matrix against the one the generator's own choices imply (built on the device from
         # the shared spec include/td_synth_spec.h; nothing is parsed, nothing of oracle/ is involved)
         counts.zero_()
         eng.reset()
         eng.bind_counts(counts.data_ptr())
-        eng.count_device(fastq.data_ptr(), nbytes, stream=stream)
+        eng.count_device(fastq.data_ptr(), nbytes, first_line=first_line, stream=stream)
         torch.cuda.synchronize()
         want = torch.zeros_like(counts)
-        hits = cfg.expected_device(eng, want.data_ptr(), first_read, cfg.nreads)
+        hits = cfg.expected_device(eng, want.data_ptr(), first_read, my_reads)
         st = eng.stats()
-        ok = bool(torch.equal(counts, want)) and st["tag"] == hits and st["reads"] == cfg.nreads
+        ok = bool(torch.equal(counts, want)) and st["tag"] == hits and st["reads"] == my_reads
         check = {"bit_exact_vs_expected": ok, "reads": int(st["reads"]), "barcut": int(st["barcut"]), "tag": int(st["tag"])}
+        del want
         if not ok:
             print("bench.py: rank %d COUNT MISMATCH against the generator's expected matrix" % rank, file=sys.stderr)
             sys.exit(3)
+        # (2) an independent checker on a sample: the first reads of the RESIDENT bytes, copied back and
+        # counted by the C oracle, against a GPU pass over exactly that prefix
+        if rank == 0 and args.oracle_sample > 0:
+            n = min(args.oracle_sample, my_reads)
+            counts.zero_()
+            eng.reset()
+            eng.count_device(fastq.data_ptr(), n * cfg.record_bytes, first_line=first_line, stream=stream)
+            torch.cuda.synchronize()
+            gst = eng.stats()
+            sample = fastq[:n * cfg.record_bytes].cpu().numpy()
+            okc, ost = oracle_check(cfg, sample, first_line, counts.cpu().numpy().view(np.uint32))
+            okc = okc and (gst["reads"], gst["barcut"], gst["tag"]) == (ost["reads"], ost["barcut"], ost["tag"])
+            check["oracle_sample"] = {"reads": n, "bit_exact_vs_c_oracle": bool(okc), "tag": int(ost["tag"])}
+            del sample
+            if not okc:
+                print("bench.py: GPU counts differ from the C oracle on the first %d reads" % n, file=sys.stderr)
+                sys.exit(3)
+        counts.zero_()
+        eng.reset()
 
     eng.set_option("timing", 1)
+    eng.kernel_times_ms()                 # (drop what the check launched)
     fence()
     t0 = time.perf_counter()
     last = counts
@@ -171,7 +236,8 @@ def main():
         last = step()
     fence()
     elapsed = time.perf_counter() - t0
-    kms, klaunches = eng.kernel_time_ms()
+    ktimes = eng.kernel_times_ms()
+    kms = sum(ktimes) / len(ktimes) if ktimes else 0.0
     fixups = eng.debug_counters()[11]
     eng.set_option("timing", 0)
 
@@ -189,41 +255,56 @@ def main():
             sys.exit(3)
 
     if rank == 0:
-        total_reads = cfg.nreads * world * args.steps
-        value = total_reads / elapsed
-        algo_bytes = cfg.record_bytes * cfg.nreads
+        value = job_reads * args.steps / elapsed
+        algo_bytes = cfg.record_bytes * my_reads
         achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        # HBM traffic from the PMC passes (profiles/pmc_traffic.json, tools/profile_round.sh): a property of the
+        # DEFAULT workload -- any other shape or option set reports null rather than a number it did not measure
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if default_workload and world == 1 and not (args.tile_kb or args.blocks_per_cu or args.opt) and os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        metric = "FASTQ reads/sec (whole node), 200M-read \u00d7 100k-tag synthetic, 1/2/4/8 MI355X"
+        metric = "FASTQ reads/sec (whole node), 200M-read × 100k-tag synthetic, 1/2/4/8 MI355X"
         try:                                              # (verbatim from BASELINE.json when it is there)
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
             pass
+        if world == 1:
+            sharding = "single GPU"
+        elif args.scaling == "weak":
+            sharding = "library-per-GPU + RCCL all-reduce(int32 count matrix) per pass, overlapped with the next pass"
+        else:
+            sharding = "one library byte-sharded over the GPUs (true first line index per shard) + RCCL all-reduce(int32 count matrix) per pass"
         out = {
             "metric": metric,
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2] shape, device-resident (tier T1): %d reads x %d barcodes x %d tags "
-                                   "per GPU, 100 bp reads, %d B/record, one library per GPU"
-                                   % (cfg.nreads, len(cfg.barcodes), len(cfg.tags), cfg.record_bytes),
-                       "reads_per_gpu": cfg.nreads, "barcodes": len(cfg.barcodes), "tags": len(cfg.tags),
-                       "fastq_bytes_per_gpu": nbytes, "sharding": "library-per-GPU + RCCL all-reduce(int32 count matrix) per pass, overlapped with the next pass"
-                       if world > 1 else "single GPU"},
+            "config": {"workload": "BASELINE configs[%d] shape, device-resident (tier T1): %d reads x %d barcodes x %d tags "
+                                   "per GPU, 100 bp reads, %d B/record, cut site %s%s, %s"
+                                   % (args.config - 1, my_reads, len(cfg.barcodes), len(cfg.tags), cfg.record_bytes, cfg.cutsite,
+                                      ", Zipf %.2f hits" % args.skew if args.skew else "",
+                                      "one library per GPU" if args.scaling == "weak" else "one library over all GPUs"),
+                       "reads_per_gpu": my_reads, "barcodes": len(cfg.barcodes), "tags": len(cfg.tags),
+                       "fastq_bytes_per_gpu": nbytes, "sharding": sharding},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "tdk::k_fast (+k_resolve, fix-up pass)", "kernel_ms": kms, "fixup_queue": fixups, "kernel_launches": klaunches,
+                         "kernel": "tdk::k_fast (+k_resolve, fix-up pass)", "kernel_ms": kms,
+                         "kernel_ms_min": min(ktimes) if ktimes else None, "kernel_ms_max": max(ktimes) if ktimes else None,
+                         "fixup_queue": fixups, "kernel_launches": len(ktimes),
                          "algorithmic_bytes_per_launch": algo_bytes},
             "check": check,
         }
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample, cfg.nreads), min(args.cpu_python_sample, cfg.nreads))
+            out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample, my_reads), min(args.cpu_python_sample, my_reads))
+        if world == 1 and args.tier_reads > 0 and not args.debug_ablate:
+            del fastq
+            torch.cuda.empty_cache()
+            eng.bind_counts(0)
+            out["tiers"] = tiers(eng, cfg, min(args.tier_reads, my_reads))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -231,12 +312,33 @@ def main():
     eng.close()
 
 
+def oracle_check(cfg, sample, first_line, got_flat):
+    """The checker: oracle/oracle.c over `sample` (numpy uint8, whole records) against the GPU's matrix."""
+    import numpy as np
+    from oracle import c_oracle
+    ost = {}
+    want = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(sample, first_line=first_line, stats=ost)
+    return bool((want.reshape(-1) == got_flat.astype(np.uint64)).all()), ost
+
+
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, sample_reads, python_reads=0):
-    """The oracle's C restatement (oracle/oracle.c, scalar, one thread) on the first
-    `sample_reads` reads of the same stream, produced by the host reference generator.
-    `python_restatement`: the pure-Python restatement (oracle/tagdigger_oracle.py: the reference's own
-    nested-list trie and per-line loop, the closest thing to the reference that can travel; BASELINE.md
-    has its calibration against the real reference: 41.6 k vs 28.2 k reads/s on the build host)."""
+    """The reference CPU path, timed on this box's host cores on a bounded prefix of the same stream
+    (host reference generator).  `value` is the pure-Python restatement (oracle/tagdigger_oracle.py: the
+    reference's own nested-list trie and per-line loop, one interpreter thread -- the closest thing to
+    the reference that can travel; BASELINE.md section 3 has its calibration against the real reference:
+    it is 1.47x FASTER than the real thing on the build host).  `c_port` / `c_port_all_cores`: the
+    scalar C restatement (oracle/oracle.c) on one core and on every core this process may use -- a fairer
+    CPU line, labelled as not-the-reference."""
     from helpers import synth_host_bytes
     from oracle import c_oracle
     data = synth_host_bytes(cfg, 0, sample_reads)
@@ -246,13 +348,14 @@ def cpu_baseline(cfg, sample_reads, python_reads=0):
     t0 = time.perf_counter()
     ora.count_bytes(data)
     loop_s = time.perf_counter() - t0
-    out = {"value": sample_reads / loop_s, "unit": "reads/s", "cores": 1, "kind": "port",
-           "sample": "first %d reads of the same synthetic stream (%.2f GB), record loop only; "
-                     "trie build %.2f s timed separately; scalar C restatement oracle/oracle.c"
-                     % (sample_reads, data.nbytes / 1e9, build_s),
-           "index_build_s": build_s, "loop_s": loop_s}
+    c_port = {"value": sample_reads / loop_s, "unit": "reads/s", "cores": 1,
+              "sample": "first %d reads of the same synthetic stream (%.2f GB), record loop only; "
+                        "trie build %.2f s timed separately; scalar C restatement oracle/oracle.c"
+                        % (sample_reads, data.nbytes / 1e9, build_s),
+              "index_build_s": build_s, "loop_s": loop_s}
+    out = {"value": None, "unit": "reads/s", "cores": 1, "kind": "port", "cpu": host_cpu_model(), "c_port": c_port}
     # the same C restatement on every core this process may use (at most 16: the GPU box's share per GPU),
-    # one shard of whole records per thread, matrices summed -- the "own CPU path at all cores" line of SURVEY 8d
+    # one shard of whole records per thread, matrices summed
     try:
         ncore = max(1, min(16, len(os.sched_getaffinity(0))))
     except AttributeError:
@@ -274,8 +377,9 @@ def cpu_baseline(cfg, sample_reads, python_reads=0):
         with ThreadPoolExecutor(len(shards)) as ex:
             parts = list(ex.map(run, range(len(shards))))
         par_s = time.perf_counter() - t0
-        out["all_cores"] = {"value": sample_reads / par_s, "unit": "reads/s", "cores": len(shards), "loop_s": par_s,
-                            "matrix_total": int(sum(int(m.sum()) for m in parts))}
+        out["c_port_all_cores"] = {"value": sample_reads / par_s, "unit": "reads/s", "cores": len(shards), "loop_s": par_s,
+                                   "matrix_total": int(sum(int(m.sum()) for m in parts))}
+        del oracles, mats, parts
     if python_reads > 0:
         from oracle import tagdigger_oracle as po
         pdata = bytes(data[:python_reads * cfg.record_bytes])
@@ -285,9 +389,80 @@ def cpu_baseline(cfg, sample_reads, python_reads=0):
         t0 = time.perf_counter()
         po.count_bytes(pdata, cfg.barcodes, cfg.tags, cfg.cutsite, index=index)
         ploop = time.perf_counter() - t0
-        out["python_restatement"] = {"value": python_reads / ploop, "unit": "reads/s", "cores": 1,
-                                     "sample": "first %d reads, record loop only" % python_reads,
-                                     "index_build_s": pbuild, "loop_s": ploop}
+        out["value"] = python_reads / ploop
+        out["sample"] = ("first %d reads of the same synthetic stream, record loop only (the nested-list trie build, %.1f s, "
+                         "is timed separately); pure-Python restatement oracle/tagdigger_oracle.py, one interpreter thread"
+                         % (python_reads, pbuild))
+        out["index_build_s"] = pbuild
+        out["loop_s"] = ploop
+    else:                                 # (no Python sample asked for: the C port is the only line there is)
+        out["value"] = c_port["value"]
+        out["sample"] = c_port["sample"]
+    return out
+
+
+def tiers(eng, cfg, reads):
+    """Tiers T2/T3 of SURVEY 8d on `reads` reads of the same stream and index -- inputs NOT resident in HBM:
+    T2 host buffer -> pinned staging -> hipMemcpyAsync overlapped with counting; T3 from a file: plain,
+    ordinary gzip (host chunk-parallel inflate), BGZF (member-parallel inflate).  Each result is checked
+    against the generator's expected matrix.  Never the bench `value`."""
+    import gzip
+    import tempfile
+    import numpy as np
+    from helpers import bgzf_bytes
+    rb = cfg.record_bytes
+    nb = reads * rb
+    d = eng.dev_alloc(nb)
+    cfg.fill_device(eng, d, 0, reads)
+    host = np.frombuffer(eng.d2h(d, nb), dtype=np.uint8)
+    eng.dev_free(d)
+    cells = len(cfg.barcodes) * len(cfg.tags)
+
+    def expected(n):
+        dw = eng.dev_alloc(cells * 4)
+        eng.h2d(dw, bytes(cells * 4))
+        cfg.expected_device(eng, dw, 0, n)
+        w = np.frombuffer(eng.d2h(dw, cells * 4), dtype=np.uint32).reshape(len(cfg.barcodes), len(cfg.tags))
+        eng.dev_free(dw)
+        return w
+    want = expected(reads)
+    out = {"reads": reads, "stage_threads": int(os.environ.get("TAGDIG_STAGE_THREADS", "8")),
+           "inflate_threads": os.environ.get("TAGDIG_INFLATE_THREADS", "default (host cores, at most %s)" % os.environ.get("TAGDIG_INFLATE_MAX", "16"))}
+
+    def timed(fn, n, w):
+        eng.reset()
+        t0 = time.perf_counter()
+        fn()
+        eng.sync()
+        dt = time.perf_counter() - t0
+        ok = bool((eng.counts_numpy() == w).all())
+        return {"reads_per_s": n / dt, "GB_per_s": n * rb / dt / 1e9, "bit_exact": ok}
+    eng.count_bytes(host)                                           # (warm: pinned buffers, page faults)
+    out["T2_host_buffer_pinned_h2d_overlap"] = timed(lambda: eng.count_bytes(host), reads, want)
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR")) as tmp:
+        plain = os.path.join(tmp, "tiers_lib.fq")
+        with open(plain, "wb") as fh:
+            fh.write(host)
+        out["T3_plain_file_page_cache"] = timed(lambda: eng.count_file(plain), reads, want)
+        os.unlink(plain)
+        nz = max(1, reads // 2)                                     # (python-side compression is the slow part: half the sample)
+        wz = expected(nz)
+        part = host[:nz * rb].tobytes()
+        gzp = os.path.join(tmp, "tiers_lib.fq.gz")
+        with open(gzp, "wb") as fh:
+            fh.write(gzip.compress(part, compresslevel=1))
+        r = timed(lambda: eng.count_file(gzp), nz, wz)
+        r["reads"] = nz
+        r["gz_bytes"] = os.path.getsize(gzp)
+        out["T3_gzip_file_host_inflate"] = r
+        os.unlink(gzp)
+        bz = os.path.join(tmp, "tiers_lib.bgzf.fq.gz")
+        with open(bz, "wb") as fh:
+            fh.write(bgzf_bytes(part, level=1))
+        r = timed(lambda: eng.count_file(bz), nz, wz)
+        r["reads"] = nz
+        r["gz_bytes"] = os.path.getsize(bz)
+        out["T3_bgzf_file_host_inflate"] = r
     return out
 
 

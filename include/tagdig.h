@@ -94,7 +94,11 @@ int td_reset(td_handle *h);
  *   weights      0 for the plain +1 count (:267); 1 for tassel_tagcount
  *                (:251-253,:264-265): header lines carry count=N
  *   stream       hipStream_t to launch on (NULL = default stream)
- * Asynchronous: returns once the work is enqueued. */
+ * Asynchronous: returns once the work is enqueued.  ONE stream in flight per handle: the launch's
+ * scratch (per-tile words, fix-up queue, tail copy, block sums) belongs to the handle, so work
+ * enqueued through the same handle on a second stream must be ordered behind the first (an event,
+ * or a synchronise) -- two unordered launches of one handle would race on it.  Use one handle per
+ * concurrent stream. */
 int td_count_device(td_handle *h, const void *d_fastq, uint64_t nbytes,
                     uint64_t first_line, uint64_t max_reads, int weights, void *stream);
 
@@ -181,12 +185,16 @@ int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
  *   "table_load_pct" fill of the tag hash table, 10..95 (default 50); applies to the next td_set_index
  *   "stagger"        start-up stagger of co-resident workgroups, in 4096-cycle units (default 0)
  *   "timing"         1: record HIP events around every launch for td_kernel_time_ms
+ *   "fast_max_matrix_bytes"  count matrices of this many bytes and more go to the exact kernel (the
+ *                    free-running one addresses cells as base + 32-bit offset); 0 = the built-in 4 GiB
  *   "debug_ablate"   timing-only ablation bits -- the counts are WRONG when non-zero
  * Returns TD_E_ARG for unknown names. */
 int td_set_option(td_handle *h, const char *name, int64_t value);
 /* Average device time (ms) of the count kernel over the launches since the
  * last call (HIP events on the launch stream); launches_out optional. */
 int td_kernel_time_ms(td_handle *h, double *ms_per_launch, uint32_t *launches_out);
+/* The same per launch: out[0 .. min(launches, capacity)) in launch order; *launches_out = how many were written. */
+int td_kernel_times_ms(td_handle *h, double *out, uint32_t capacity, uint32_t *launches_out);
 
 /* Diagnostic counters (24 x uint64).  All zero in the shipped build; the phase-stamp
  * build (make prof -> libtagdig_prof.so) fills [0..7] with shader-clock cycles per phase. */

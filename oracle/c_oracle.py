@@ -26,7 +26,8 @@ def build(force=False):
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("nbar", C.c_uint32), ("ntags", C.c_uint32),
                 ("ncut", C.c_uint32), ("read_len", C.c_uint32), ("cut_len", C.c_uint32),
-                ("tag_stride", C.c_uint32)]
+                ("tag_stride", C.c_uint32), ("adapter_pct", C.c_uint32), ("adapter_len", C.c_uint32),
+                ("tag_cdf", C.c_void_p), ("bar_cdf", C.c_void_p), ("adapter", C.c_char * 64)]
 
 
 def lib():

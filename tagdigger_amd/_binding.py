@@ -39,7 +39,8 @@ class NonAsciiSequence(ValueError):
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("nbar", C.c_uint32), ("ntags", C.c_uint32),
                 ("ncut", C.c_uint32), ("read_len", C.c_uint32), ("cut_len", C.c_uint32),
-                ("tag_stride", C.c_uint32)]
+                ("tag_stride", C.c_uint32), ("adapter_pct", C.c_uint32), ("adapter_len", C.c_uint32),
+                ("tag_cdf", C.c_void_p), ("bar_cdf", C.c_void_p), ("adapter", C.c_char * 64)]
 
 
 def _hip_runtime_candidates():
@@ -110,6 +111,7 @@ def load():
     sig("td_get_stats", i32, vp, C.POINTER(u64))
     sig("td_set_option", i32, vp, C.c_char_p, C.c_int64)
     sig("td_kernel_time_ms", i32, vp, C.POINTER(C.c_double), C.POINTER(u32))
+    sig("td_kernel_times_ms", i32, vp, C.POINTER(C.c_double), u32, C.POINTER(u32))
     sig("td_debug_counters", i32, vp, C.POINTER(u64))
     sig("td_dev_alloc", i32, vp, u64, C.POINTER(vp))
     sig("td_dev_free", i32, vp, vp)
@@ -130,7 +132,7 @@ EXPORTS = [
     "td_last_error", "td_last_bad_index", "td_create", "td_destroy", "td_set_index",
     "td_bind_counts", "td_reset", "td_count_device", "td_count_host", "td_count_file",
     "td_count_lines_device", "td_gunzip_file", "td_set_splitter", "td_split_device", "td_split_file", "td_get_counts", "td_get_stats", "td_set_option",
-    "td_kernel_time_ms", "td_debug_counters", "td_dev_alloc", "td_dev_free", "td_memcpy_h2d", "td_memcpy_d2h",
+    "td_kernel_time_ms", "td_kernel_times_ms", "td_debug_counters", "td_dev_alloc", "td_dev_free", "td_memcpy_h2d", "td_memcpy_d2h",
     "td_device_sync", "td_synth_fill_device", "td_synth_expected_device",
 ]
 

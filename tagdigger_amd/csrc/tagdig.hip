@@ -174,6 +174,7 @@ struct td_handle {
     uint32_t max_need = 0;                    // bases from a read's start that the matcher may look at
     // options
     int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1, nt_loads = 1;
+    uint64_t fast_max_matrix = 1ull << 32;    // the free-running kernel addresses cells as base + 32-bit byte offset
     uint32_t debug_ablate = 0;
     double table_load = 0.5;
     int stagger = 0;
@@ -308,7 +309,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     const uint64_t fl_ub = std::max(first_line, first_line_ub);
     const bool limit_far = p.limit_line >= ~0ull - 16 || p.limit_line - std::min(p.limit_line, fl_ub) >= nbytes / 16;
     // (it addresses count cells as base + 32-bit byte offset)
-    const bool counts32 = (uint64_t)h->barnum * h->ntags * 4 < (1ull << 32);
+    const bool counts32 = (uint64_t)h->barnum * h->ntags * 4 < h->fast_max_matrix;
     if (h->fastpath && !tassel && !h->prescan && limit_far && counts32) {
         int rc = h->d_tileinfo.ensure(ntiles); if (rc) return rc;
         const uint32_t fix_cap = 3u * ntiles + 8u;
@@ -942,6 +943,8 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     else if (n == "prio") h->prio = (int)value & 255;
     else if (n == "table_load_pct") h->table_load = std::max<int64_t>(10, std::min<int64_t>(value, 95)) / 100.0;
     else if (n == "nt_loads") h->nt_loads = value ? 1 : 0;
+    else if (n == "fast_max_matrix_bytes")      // (tests: force the switch to the exact kernel; 0 = the built-in 4 GiB)
+        h->fast_max_matrix = value > 0 ? std::min<uint64_t>((uint64_t)value, 1ull << 32) : 1ull << 32;
     else if (n == "debug_ablate") h->debug_ablate = (uint32_t)value;   // timing-only ablations, wrong results
     else return fail(TD_E_ARG, "unknown option " + n);
     return TD_OK;
@@ -959,6 +962,21 @@ int td_kernel_time_ms(td_handle *h, double *ms, uint32_t *launches) {
     }
     *ms = h->ev_used ? tot / (double)h->ev_used : 0.0;
     if (launches) *launches = (uint32_t)h->ev_used;
+    h->ev_used = 0;
+    return TD_OK;
+}
+
+int td_kernel_times_ms(td_handle *h, double *out, uint32_t capacity, uint32_t *launches) {
+    if (!h || !out || !launches) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    uint32_t n = 0;
+    for (size_t i = 0; i < h->ev_used && n < capacity; i++, n++) {
+        HIPCHK(hipEventSynchronize(h->ev_pool[i].second));
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, h->ev_pool[i].first, h->ev_pool[i].second));
+        out[n] = t;
+    }
+    *launches = n;
     h->ev_used = 0;
     return TD_OK;
 }
@@ -1019,14 +1037,33 @@ __global__ void k_synth_expected(td_synth_params P, uint64_t first_read, uint64_
 
 extern "C" {
 
+// the generator's optional draw tables (td_synth_spec.h "skew"): host thresholds -> device copies, pointers swapped in P
+static int synth_upload_cdfs(td_synth_params &P, uint64_t *&d_tag_cdf, uint64_t *&d_bar_cdf) {
+    d_tag_cdf = d_bar_cdf = nullptr;
+    if (P.tag_cdf) {
+        HIPCHK(hipMalloc((void **)&d_tag_cdf, (size_t)P.ntags * 8));
+        HIPCHK(hipMemcpy(d_tag_cdf, P.tag_cdf, (size_t)P.ntags * 8, hipMemcpyHostToDevice));
+        P.tag_cdf = d_tag_cdf;
+    }
+    if (P.bar_cdf) {
+        HIPCHK(hipMalloc((void **)&d_bar_cdf, (size_t)P.nbar * 8));
+        HIPCHK(hipMemcpy(d_bar_cdf, P.bar_cdf, (size_t)P.nbar * 8, hipMemcpyHostToDevice));
+        P.bar_cdf = d_bar_cdf;
+    }
+    return TD_OK;
+}
+
 int td_synth_fill_device(td_handle *h, const void *params, uint64_t first_read, uint64_t nreads,
                          const char *bar_tab, const uint8_t *bar_len, const char *cut_tab,
                          const char *tag_tab, const uint16_t *tag_len, void *d_out, void *stream) {
     if (!h || !params || !d_out) return fail(TD_E_ARG, "NULL argument");
     HIPCHK(hipSetDevice(h->device));
     td_synth_params P = *(const td_synth_params *)params;
+    if (P.adapter_len > TD_SYNTH_ADAPTER_MAX) return fail(TD_E_ARG, "adapter_len beyond TD_SYNTH_ADAPTER_MAX");
     hipStream_t s = (hipStream_t)stream;
     char *d_bar = nullptr, *d_cut = nullptr, *d_tag = nullptr; uint8_t *d_bl = nullptr; uint16_t *d_tl = nullptr;
+    uint64_t *d_tc = nullptr, *d_bc = nullptr;
+    { int rc = synth_upload_cdfs(P, d_tc, d_bc); if (rc) return rc; }
     HIPCHK(hipMalloc((void **)&d_bar, (size_t)P.nbar * TD_SYNTH_BAR_STRIDE));
     HIPCHK(hipMalloc((void **)&d_bl, P.nbar));
     HIPCHK(hipMalloc((void **)&d_cut, (size_t)P.ncut * TD_SYNTH_CUT_STRIDE));
@@ -1042,6 +1079,8 @@ int td_synth_fill_device(td_handle *h, const void *params, uint64_t first_read, 
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     (void)hipFree(d_bar); (void)hipFree(d_bl); (void)hipFree(d_cut); (void)hipFree(d_tag); (void)hipFree(d_tl);
+    if (d_tc) (void)hipFree(d_tc);
+    if (d_bc) (void)hipFree(d_bc);
     return TD_OK;
 }
 
@@ -1049,8 +1088,10 @@ int td_synth_expected_device(td_handle *h, const void *params, uint64_t first_re
                              uint32_t *d_counts, uint64_t *hits_out, void *stream) {
     if (!h || !params || !d_counts) return fail(TD_E_ARG, "NULL argument");
     HIPCHK(hipSetDevice(h->device));
-    const td_synth_params P = *(const td_synth_params *)params;
+    td_synth_params P = *(const td_synth_params *)params;
     hipStream_t s = (hipStream_t)stream;
+    uint64_t *d_tc = nullptr, *d_bc = nullptr;
+    { int rc = synth_upload_cdfs(P, d_tc, d_bc); if (rc) return rc; }
     unsigned long long *d_hits = nullptr;
     HIPCHK(hipMalloc((void **)&d_hits, 8));
     HIPCHK(hipMemsetAsync(d_hits, 0, 8, s));
@@ -1061,6 +1102,8 @@ int td_synth_expected_device(td_handle *h, const void *params, uint64_t first_re
     HIPCHK(hipMemcpyAsync(&v, d_hits, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     (void)hipFree(d_hits);
+    if (d_tc) (void)hipFree(d_tc);
+    if (d_bc) (void)hipFree(d_bc);
     if (hits_out) *hits_out = v;
     return TD_OK;
 }

@@ -243,6 +243,13 @@ class Engine:
         B.check(self._L.td_kernel_time_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernel_times_ms(self, capacity=4096):
+        """Device time of every launch since the last call, in launch order (needs option "timing")."""
+        out = (C.c_double * capacity)()
+        n = C.c_uint32(0)
+        B.check(self._L.td_kernel_times_ms(self._h, out, capacity, C.byref(n)))
+        return list(out[:n.value])
+
     # ------------------------------------------------------------------ device memory helpers
     def dev_alloc(self, nbytes):
         p = C.c_void_p()

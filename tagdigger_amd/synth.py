@@ -22,8 +22,17 @@ CONFIGS = {
     2: dict(nreads=50_000_000, nbar=96, nmarkers=5_000, seed=2, cutsite="TGCAG", bclen=(4, 8)),
     3: dict(nreads=200_000_000, nbar=384, nmarkers=50_000, seed=3, cutsite="TGCAG", bclen=(4, 8)),
     4: dict(nreads=200_000_000, nbar=384, nmarkers=250_000, seed=40, cutsite="TGCAG", bclen=(4, 8)),
-    5: dict(nreads=1_000_000_000, nbar=384, nmarkers=50_000, seed=5, cutsite="CWGC", bclen=(4, 10)),
+    # config 5 as SURVEY App. B writes it: degenerate cut site (two concrete sites, tags carry theirs: the
+    # multi-cut-site branch of reference tagdigger_fun.py:227-231), barcodes of 4-10 bp, 5 % of the markers
+    # tri-allelic -- written as Merged-format rows and expanded by readTags_Merged (:592-598) -- and the
+    # common cutter's adapter read through in 20 % of the tag-bearing reads (:27-28) for the splitter branch
+    5: dict(nreads=1_000_000_000, nbar=384, nmarkers=50_000, seed=5, cutsite="CWGC", bclen=(4, 10),
+            triallelic_pct=5, adapter_pct=20),
 }
+
+# what a read runs into behind a short fragment: the rest of the common cutter's site + its adapter
+# (adapters['PstI-MspI-Hall'][0] of the reference, tagdigger_fun.py:27-28: 'CCG^G' + top strand)
+READ_THROUGH = "CCG" + "CTCAGGCATCACTCGATTCCTCCGTCGTATGCCGTCTTCTGCTTG"
 
 
 def _rand_seq(rng, n):
@@ -76,13 +85,64 @@ def make_tags(rng, nmarkers, cutsites, body=59):
     return tags
 
 
+def merged_rows(tags, nmarkers, rng, triallelic_pct):
+    """The biallelic tag pairs as Merged-format rows (marker name, sequence with the variable site as
+    [A/C]); `triallelic_pct` % of the markers get a third allele at the same site ([A/C/T])."""
+    rows = []
+    third = rng.integers(0, 100, nmarkers) < triallelic_pct
+    pick = rng.integers(0, 2, nmarkers)
+    for m in range(nmarkers):
+        a, b = tags[2 * m], tags[2 * m + 1]
+        pos = next(i for i in range(len(a)) if a[i] != b[i])
+        alleles = [a[pos], b[pos]]
+        if third[m]:
+            alleles.append([x for x in "ACGT" if x not in alleles][int(pick[m])])
+        rows.append(("M%d" % m, a[:pos] + "[" + "/".join(alleles) + "]" + a[pos + 1:]))
+    return rows
+
+
+def zipf_cdf(n, s, rng):
+    """n ascending 64-bit thresholds (the last one 2^64-1) of a Zipf(s) law whose ranks are dealt to the
+    indices by a seeded permutation (hot tags are scattered over the columns, as in real data)."""
+    w = 1.0 / np.arange(1, n + 1, dtype=np.float64) ** s
+    w = w[rng.permutation(n)]
+    c = np.cumsum(w / w.sum())
+    t = np.minimum(np.floor(c * 2.0 ** 64), 2.0 ** 64 - 2049).astype(np.uint64)   # (float64 cannot reach 2^64-1)
+    t = np.maximum.accumulate(t)
+    t[-1] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    return np.ascontiguousarray(t)
+
+
 class SynthConfig:
-    def __init__(self, nreads, nbar, nmarkers, seed, cutsite="TGCAG", bclen=(4, 8), read_len=100, body=59):
+    def __init__(self, nreads, nbar, nmarkers, seed, cutsite="TGCAG", bclen=(4, 8), read_len=100, body=59,
+                 skew=0.0, triallelic_pct=0, adapter_pct=0):
         self.nreads, self.seed, self.cutsite, self.read_len = nreads, seed, cutsite, read_len
         self.cutsites = enumerate_cut_sites(cutsite)
         rng = np.random.default_rng(seed)
         self.barcodes = make_barcodes(rng, nbar, bclen[0], bclen[1], self.cutsites)
         self.tags = make_tags(rng, nmarkers, self.cutsites, body)
+        self.tag_names = None
+        if triallelic_pct:
+            # through the reader the reference's CLI would use: a Merged-format file, expanded on the host
+            import csv
+            import os
+            import tempfile
+            from . import tagdigger_fun as tf
+            rows = merged_rows(self.tags, nmarkers, rng, triallelic_pct)
+            fd, path = tempfile.mkstemp(suffix=".csv")
+            try:
+                with os.fdopen(fd, "w", newline="") as fh:
+                    w = csv.writer(fh)
+                    w.writerow(["Marker name", "Tag sequence"])
+                    w.writerows(rows)
+                self.tag_names, self.tags = tf.readTags_Merged(path)
+            finally:
+                os.unlink(path)
+        self.skew = float(skew)
+        self.adapter_pct = int(adapter_pct)
+        # draw tables of the skewed variant (Zipf(s) over the tags, Zipf(s/2) over the barcodes); kept alive here
+        self.tag_cdf = zipf_cdf(len(self.tags), self.skew, rng) if self.skew else None
+        self.bar_cdf = zipf_cdf(len(self.barcodes), self.skew / 2, rng) if self.skew else None
         assert max(len(b) for b in self.barcodes) + max(len(t) for t in self.tags) <= read_len
         self.tag_stride = max(len(t) for t in self.tags)
         self.record_bytes = 2 * read_len + 19
@@ -100,9 +160,14 @@ class SynthConfig:
             c["nreads"] = nreads
         return cls(**c)
 
-    def params(self):
-        return B.SynthParams(self.seed, len(self.barcodes), len(self.tags), len(self.cutsites),
-                             self.read_len, len(self.cutsites[0]), self.tag_stride)
+    def params(self, cls=None):
+        """td_synth_params (include/td_synth_spec.h); `cls`: the ctypes mirror to fill (the binding's by default)."""
+        ad = READ_THROUGH[:64].encode() if self.adapter_pct else b""
+        return (cls or B.SynthParams)(
+            self.seed, len(self.barcodes), len(self.tags), len(self.cutsites), self.read_len, len(self.cutsites[0]),
+            self.tag_stride, self.adapter_pct, len(ad),
+            self.tag_cdf.ctypes.data if self.tag_cdf is not None else None,
+            self.bar_cdf.ctypes.data if self.bar_cdf is not None else None, ad)
 
     def nbytes(self, nreads=None):
         return (self.nreads if nreads is None else nreads) * self.record_bytes

@@ -9,8 +9,7 @@ from oracle import c_oracle
 
 
 def synth_params(cfg):
-    return c_oracle.SynthParams(cfg.seed, len(cfg.barcodes), len(cfg.tags), len(cfg.cutsites),
-                                cfg.read_len, len(cfg.cutsites[0]), cfg.tag_stride)
+    return cfg.params(c_oracle.SynthParams)
 
 
 def synth_host_bytes(cfg, first_read, nreads):

@@ -1,0 +1,158 @@
+"""Every BASELINE.json config's INDEX SHAPE under `pytest -m gpu`, against the C oracle on identical bytes.
+
+The goldens stop at 12 barcodes x 30 tags; the regimes that define configs 2-5 -- 96 x 10 k,
+384 x 100 k (8 MB tag table > one XCD's L2, overflow buckets, 154 MB matrix), 384 x 500 k (34 MB
+table, 768 MB matrix), `CWGC` x 384 x 100 k with barcodes of 4-10 bp -- are exercised here with
+1-2 M reads of the canonical stream each: the whole matrix and the three counters
+of reference tagdigger_fun.py:246-248 must equal the oracle's, for the free-running kernel at both
+tile sizes and for the exact look-back kernel.  Config 3's shape also goes through the file path
+(plain, gzip, BGZF: several staged pieces), and one case forces the matrix-size fallback.
+"""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from helpers import bgzf_bytes, synth_host_bytes
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+# name -> (config id of tagdigger_amd.synth.CONFIGS, reads in the sample, kernel modes (tile_kb, fastpath))
+SHAPES = {
+    "C2_96x10k": (2, 1_000_000, ((32, 1), (16, 1), (32, 0))),
+    "C3_384x100k": (3, 2_000_000, ((32, 1), (16, 1), (32, 0))),
+    "C4_384x500k": (4, 1_000_000, ((32, 1), (32, 0))),
+    "C5_CWGC_384x100k": (5, 1_000_000, ((32, 1), (16, 1), (32, 0))),
+}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import tagdigger_amd
+    e = tagdigger_amd.Engine(0)
+    yield e
+    e.close()
+
+
+_cache = {}
+
+
+def shape(name):
+    """(config, host bytes, oracle matrix, oracle stats) of a shape, built once per session."""
+    if name not in _cache:
+        from tagdigger_amd.synth import SynthConfig
+        cid, nreads, _ = SHAPES[name]
+        cfg = SynthConfig.from_id(cid, nreads=nreads)
+        host = synth_host_bytes(cfg, 0, nreads)
+        ost = {}
+        want = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(host, stats=ost)
+        _cache.clear()                                      # (one shape resident at a time: C4's matrix is 1.5 GB as uint64)
+        _cache[name] = (cfg, host, want, ost)
+    return _cache[name]
+
+
+def check(eng, want, ost, what):
+    got = eng.counts_numpy()
+    st = eng.stats()
+    assert (got == want).all(), what
+    assert (st["reads"], st["barcut"], st["tag"]) == (ost["reads"], ost["barcut"], ost["tag"]), what
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_config_shape_device_resident(eng, name):
+    """The generator's bytes written straight into HBM (== the host reference bytes), counted in place."""
+    cfg, host, want, ost = shape(name)
+    assert want.sum() > 0.6 * cfg.nreads                    # ~70 % of the stream are hits
+    nb = cfg.nbytes()
+    d = eng.dev_alloc(nb)
+    try:
+        cfg.fill_device(eng, d, 0, cfg.nreads)
+        assert eng.d2h(d, 1 << 20) == bytes(host[:1 << 20]) and eng.d2h(d + nb - 4096, 4096) == bytes(host[-4096:])
+        eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        try:
+            for tile_kb, fast in SHAPES[name][2]:
+                eng.set_option("tile_kb", tile_kb)
+                eng.set_option("fastpath", fast)
+                eng.reset()
+                eng.count_device(d, nb)
+                check(eng, want, ost, (name, tile_kb, fast))
+                if fast:
+                    assert eng.debug_counters()[11] == 0, "well-formed FASTQ must leave the fix-up queue empty"
+        finally:
+            eng.set_option("tile_kb", 32)
+            eng.set_option("fastpath", 1)
+    finally:
+        eng.dev_free(d)
+
+
+@pytest.mark.parametrize("s", [1.0, 1.5])
+def test_skewed_hits(eng, s):
+    """The Zipf variant of the stream (hot cells: many atomics on few addresses): device bytes == host
+    reference bytes, counts == oracle == the generator's own expected matrix."""
+    from helpers import synth_expected
+    from tagdigger_amd.synth import SynthConfig
+    cfg = SynthConfig(nreads=600_000, nbar=96, nmarkers=5_000, seed=21, skew=s)
+    nb = cfg.nbytes()
+    host = synth_host_bytes(cfg, 0, cfg.nreads)
+    ost = {}
+    want = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(host, stats=ost)
+    exp, hits = synth_expected(cfg, 0, cfg.nreads)
+    assert (want == exp).all() and want.max() > 50 * want.mean()
+    d = eng.dev_alloc(nb)
+    try:
+        cfg.fill_device(eng, d, 0, cfg.nreads)
+        assert eng.d2h(d, nb) == host.tobytes()
+        eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        eng.count_device(d, nb)
+        check(eng, want, ost, ("skew", s))
+        # and the device-side expected matrix the bench checks against
+        dw = eng.dev_alloc(want.size * 4)
+        try:
+            eng.h2d(dw, bytes(want.size * 4))
+            assert cfg.expected_device(eng, dw, 0, cfg.nreads) == hits
+            assert (np.frombuffer(eng.d2h(dw, want.size * 4), dtype=np.uint32).reshape(want.shape) == want).all()
+        finally:
+            eng.dev_free(dw)
+    finally:
+        eng.dev_free(d)
+
+
+def test_matrix_size_fallback(eng):
+    """The free-running kernel addresses count cells as base + 32-bit offset, so matrices of 4 GiB and
+    more go to the exact kernel (tagdig.hip launch_count).  The threshold is lowered to force that switch
+    on config 2's shape; the fix-up queue counter shows which kernel ran."""
+    cfg, host, want, ost = shape("C2_96x10k")
+    eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+    try:
+        eng.set_option("fast_max_matrix_bytes", 1 << 20)      # 96 x 10 k x 4 B = 3.84 MB is above it
+        eng.count_bytes(host)
+        check(eng, want, ost, "fallback")
+        eng.set_option("fast_max_matrix_bytes", 0)            # back to the built-in 4 GiB
+        eng.reset()
+        eng.count_bytes(host)
+        check(eng, want, ost, "fast again")
+    finally:
+        eng.set_option("fast_max_matrix_bytes", 0)
+
+
+@pytest.mark.parametrize("kind", ["plain", "gz", "bgzf"])
+def test_config3_shape_through_the_file_path(eng, tmp_path, kind):
+    """td_count_file at config 3's index shape: 438 MB of FASTQ = 14 staged pieces of 32 MiB, read
+    plain, inflated from ordinary gzip (chunk-parallel decoder) and from BGZF (member-parallel)."""
+    cfg, host, want, ost = shape("C3_384x100k")
+    raw = host.tobytes()
+    if kind == "plain":
+        path, blob = str(tmp_path / "c3.fq"), raw
+    elif kind == "gz":
+        path, blob = str(tmp_path / "c3.fq.gz"), gzip.compress(raw, compresslevel=1)
+    else:
+        path, blob = str(tmp_path / "c3.bgzf.fq.gz"), bgzf_bytes(raw, level=1)
+    with open(path, "wb") as fh:
+        fh.write(blob)
+    del blob, raw
+    eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+    eng.count_file(path)
+    check(eng, want, ost, kind)
+    os.unlink(path)
