@@ -40,7 +40,8 @@ _cache = {}
 
 
 def shape(name):
-    """(config, host bytes, oracle matrix, oracle stats) of a shape, built once per session."""
+    """(config, host bytes, oracle matrix, oracle stats) of a shape, built once per session (3.3 GB of host
+    memory in all, config 4's uint64 matrix being half of it)."""
     if name not in _cache:
         from tagdigger_amd.synth import SynthConfig
         cid, nreads, _ = SHAPES[name]
@@ -48,7 +49,6 @@ def shape(name):
         host = synth_host_bytes(cfg, 0, nreads)
         ost = {}
         want = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(host, stats=ost)
-        _cache.clear()                                      # (one shape resident at a time: C4's matrix is 1.5 GB as uint64)
         _cache[name] = (cfg, host, want, ost)
     return _cache[name]
 
