@@ -31,6 +31,7 @@ namespace tdk {
 constexpr uint32_t TI_COUNT_MASK = 0xFFFFFFu;   // tile_info: terminators in the tile
 constexpr uint32_t TI_R0_SHIFT = 24;            //            phase (r0) the tile was counted under
 constexpr uint32_t TI_HI = 1u << 26;            //            tile holds a byte >= 0x80
+constexpr uint32_t TI_SKIP = 1u << 27;          //            the main pass (k_fast2) only counted the tile's terminators
 // fix-up queue entry: {tile, code, P lo, P hi}; code = r0 | flags
 constexpr uint32_t FX_NEG = 4;                  // subtract instead of add
 constexpr uint32_t FX_LIMIT = 8;                // apply the maxreads limit (needs P)
@@ -573,11 +574,14 @@ __global__ __launch_bounds__(1024) void k_resolve(const FParams fp, const unsign
         // lines of this tile: first_line+P (only tile 0's own first line) .. first_line+P+v
         const bool beyond_all = finite && first_line + P + (i == 0 ? 0 : 1) > p.limit_line;
         const bool beyond_some = finite && first_line + P + v > p.limit_line;
+        const bool skipped = (info & TI_SKIP) != 0;      // nothing was counted: nothing to take back
         if (beyond_all) {
-            push(i, pred | FX_NEG, P);
+            if (!skipped) push(i, pred | FX_NEG, P);
         } else if (beyond_some) {
-            push(i, pred | FX_NEG, P);
+            if (!skipped) push(i, pred | FX_NEG, P);
             push(i, truth | FX_LIMIT, P);
+        } else if (skipped) {
+            push(i, truth, P);
         } else if (pred != truth) {
             push(i, pred | FX_NEG, P);
             push(i, truth, P);

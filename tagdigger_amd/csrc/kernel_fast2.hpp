@@ -1,0 +1,522 @@
+// k_fast2: the main pass of the free-running path, second generation ("lazy packing").
+//
+// k_fast (kernel_fast.hpp) 2-bit-packs and validates EVERY byte of the tile in its phase A -- 59 VALU
+// instructions per 16-byte chunk, two thirds of the kernel's instructions (profiles/r01_final) -- although
+// only the head of every fourth line is ever matched (reference tagdigger_fun.py:254-261: the sequence line,
+// and of it barcode + site + tag).  Here phase A only finds the line terminators; the tile's RAW bytes are
+// parked in LDS, and each wanted line is packed by the lane that matches it, from its own first byte
+// (unaligned LDS reads: no alignment shifts either):
+//
+//   A   per chunk: raw bytes -> LDS, '\n' mask (15 VALU) -> LDS; bytes >= 0x80 and '\r' are detected per wave
+//       ('\r' takes a second mask and the \r\n rule; bytes >= 0x80 the exact forms, and the tile is left to
+//       the fix-up pass); at its end: the line left PENDING by the previous tile is finished, the next
+//       tile's loads are issued, the pending count goes through the hot-cell cache
+//   B   block scan of the terminator counts; each thread's phase vote from the RAW first 8 bytes of the first
+//       line that starts in its span
+//   C   the tile's phase (as k_fast); tiles that are not "regular" (first / last of the buffer, bytes >= 0x80,
+//       more wanted lines than the list holds) are only COUNTED here (terminators) and flagged TI_SKIP:
+//       k_resolve queues them for the fix-up pass (k_fast<.., true>), which handles every irregularity
+//   D   wanted lines compacted through an LDS list (as k_fast); per line: 16-byte pieces from the line's first
+//       byte -> codes + validity -> barcode directory (LDS) -> tag words -> hash -> bucket loads left in flight
+//
+// Count updates go through a small per-wave cache of hot cells in LDS (hc_commit): a cell that keeps coming
+// back is counted there and written out once per flush, so that skewed libraries do not serialise on one
+// address in L2 (measured: Zipf 1.5 over the tags costs k_fast 45 ms instead of 12; same-address atomics
+// retire at ~12 ns each whatever the number of CUs issuing them).
+#pragma once
+#include "kernel_fast.hpp"
+
+namespace tdk {
+
+constexpr int HC_SLOTS = 128;                   // hot-cell cache: slots per wave (direct mapped)
+constexpr uint32_t HC_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t HC_AGE_TILES = 64;           // every so many tiles the cache is written out and cleared
+constexpr uint32_t HC_BYTES_PER_WAVE = HC_SLOTS * 8 + HC_SLOTS;
+
+__device__ __forceinline__ uint32_t hc_hash(uint32_t cell) {
+    return (((cell & 0xFFFFFFu) * 0x9E3779u) >> 13) & (uint32_t)(HC_SLOTS - 1);     // v_mul_u32_u24: full rate
+}
+
+// One count per lane with `hit`, through the wave's hot-cell cache (S: HC_SLOTS x {cell, count}, E: one byte
+// per slot for electing a writer).  All lanes of the wave execute this together; LDS operations of one wave
+// are performed in order, which is all the synchronisation there is.
+//   cell cached               -> count it in LDS (no global traffic)
+//   not cached, slot is cold  -> ONE of the lanes that want the slot writes the old entry out and takes it
+//   otherwise                 -> the plain global atomic
+__device__ __forceinline__ void hc_commit(uint32_t *counts, uint2 *S, uint8_t *E, bool hit, uint32_t cell, uint32_t lane, bool use_cache) {
+    if (!use_cache) {
+        if (hit) __hip_atomic_fetch_add(counts + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const uint32_t h = hc_hash(cell);
+    uint2 e = make_uint2(HC_EMPTY, 0u);
+    if (hit) e = S[h];
+    const bool same = hit && e.x == cell;
+    if (same) __hip_atomic_fetch_add(&S[h].y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const bool miss = hit && !same;
+    const bool repl = miss && e.y <= 1u;
+    if (repl) E[h] = (uint8_t)lane;
+    wave_lds_fence();
+    bool win = false;
+    if (repl) win = E[h] == (uint8_t)lane;
+    if (win) {
+        const uint2 old = S[h];                         // (includes what this step's `same` lanes added)
+        S[h] = make_uint2(cell, 1u);
+        if (old.y) __hip_atomic_fetch_add(counts + old.x, old.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (miss) {
+        __hip_atomic_fetch_add(counts + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    wave_lds_fence();
+}
+__device__ __forceinline__ void hc_flush(uint32_t *counts, uint2 *S, uint32_t lane) {
+#pragma unroll
+    for (int q = 0; q < HC_SLOTS / 64; q++) {
+        const uint2 e = S[q * 64 + lane];
+        if (e.y) __hip_atomic_fetch_add(counts + e.x, e.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S[q * 64 + lane] = make_uint2(HC_EMPTY, 0u);
+    }
+    wave_lds_fence();
+}
+
+// 16-bit mask of bytes equal to the byte replicated in c4, for a chunk of bytes < 0x80
+__device__ __forceinline__ uint32_t eq_mask16_ascii(const uint4 &v, uint32_t c4, uint32_t k7f) {
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t u = xor_add(x[d], c4, k7f) & 0x80808080u;       // 0x80 where the byte is NOT c
+        if (d == 0) lo = udot4(u, 0x08040201u, 0u);
+        else if (d == 1) lo = udot4(u, 0x80402010u, lo);
+        else if (d == 2) hi = udot4(u, 0x08040201u, 0u);
+        else hi = udot4(u, 0x80402010u, hi);
+    }
+    return ((lo >> 7) | (hi << 1)) ^ 0xFFFFu;
+}
+
+// codes (16 bases, first base in the top bits) and invalid flags (bit k = byte k is not a base) of 16 ASCII bytes
+__device__ __forceinline__ uint2 pack16_ascii(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+    const uint32_t x[4] = {x0, x1, x2, x3};
+    uint32_t cw = 0, ihi = 0, ilo = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t code = (x[d] >> 1) & 0x03030303u;
+        const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, code);
+        const uint32_t nz = (((x[d] & 0xDFDFDFDFu) ^ expect) + 0x7F7F7F7Fu) & 0x80808080u;   // 0x80 where the byte is not a base
+        cw = udot4(code, 0x01041040u, cw << 8);
+        if (d == 0) ilo = udot4(nz, 0x08040201u, 0u);
+        else if (d == 1) ilo = udot4(nz, 0x80402010u, ilo);
+        else if (d == 2) ihi = udot4(nz, 0x08040201u, 0u);
+        else ihi = udot4(nz, 0x80402010u, ihi);
+    }
+    return make_uint2(cw, (ihi << 1) | (ilo >> 7));
+}
+
+// 16 bytes of LDS at any byte offset
+__device__ __forceinline__ uint4 lds_read16(const uint8_t *p) {
+    uint4 q;
+    __builtin_memcpy(&q, p, 16);
+    return q;
+}
+
+// The matcher's first half for a line whose first byte sits at L_raw[srel] (raw ASCII bytes; at least
+// 16 * NQ bytes are staged behind it).  Returns 0 no barcode, 2 barcode+site only, 1 pending (pd filled,
+// bucket loads in flight), 6 the line opens with a blank (str.strip, reference :256): the caller re-reads it
+// from global memory.
+template <int W, int NQ>
+__device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx &cx, const uint8_t *L_raw, uint32_t srel,
+                                                 Pending<W> &pd) {
+    // NQ: 16-byte pieces packed from the line's first byte (compile time: all reads are issued before the
+    // first piece is packed, and the pieces' dependent chains interleave)
+    static_assert(NQ >= 2 && NQ <= 2 * W + 4, "pieces per line");
+    uint32_t S[NQ + 4];
+    uint32_t inv[(NQ + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (NQ + 1) / 2; i++) inv[i] = 0;
+    const uint8_t *src = L_raw + srel;
+    uint4 q[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) q[i] = lds_read16(src + 16 * i);
+    const uint32_t first = q[0].x & 0xFFu;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const uint2 e = pack16_ascii(q[i].x, q[i].y, q[i].z, q[i].w);
+        S[i] = e.x;
+        if (i & 1) inv[i >> 1] |= e.y << 16; else inv[i >> 1] |= e.y;
+    }
+#pragma unroll
+    for (int i = NQ; i < NQ + 4; i++) S[i] = 0;
+    if (NQ & 1) inv[NQ >> 1] |= 0xFFFF0000u;
+    if (inv[0] & 1u) return is_blank(first) ? 6u : 0u;      // the first byte is no base: blanks to strip, or no match
+    uint32_t nvalid = 0;
+    {
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < (NQ + 1) / 2; i++) {
+            if (!found) {
+                if (inv[i]) { nvalid += __builtin_ctz(inv[i]); found = true; }
+                else nvalid += 32;
+            }
+        }
+    }
+    // ---- barcode + cut site (reference :257)
+    const uint64_t K = ((uint64_t)S[0] << 32) | S[1];
+    uint32_t ci = cx.L_bdir[S[0] >> (32 - 2 * BDIR_BASES)];
+    uint32_t meta = 0;
+    bool bhit = false;
+    if (ci != 0xFFFFu) {
+        for (;;) {
+            const uint32_t m = cx.L_bmeta[ci];
+            const uint32_t len = m & 63u;
+            if (len <= nvalid && ((K ^ cx.L_bval[ci]) >> (64u - 2u * len)) == 0) { meta = m; bhit = true; break; }
+            if (m & BMETA_LAST) break;
+            ci++;
+        }
+    }
+    if (!bhit) return 0u;
+    const uint32_t off = (meta >> 6) & 63u, row = meta >> 16;
+    if (nvalid <= off) return 2u;
+    const uint32_t nrem = nvalid - off;
+    // ---- the read from the tag offset on (reference :260), as 64-bit words
+    const uint32_t wo = off >> 4, sh = 2u * (off & 15u);
+    for (uint32_t t = 0; t < p.maxwo; t++) {
+        if (wo > t) {
+#pragma unroll
+            for (int w = 0; w < NQ + 3; w++) S[w] = S[w + 1];
+            S[NQ + 3] = 0;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        // (pieces beyond NQ read as zero codes: they lie past every stored tag's end for this index)
+        const uint32_t s0 = 2 * w < NQ + 4 ? S[2 * w] : 0u, s1 = 2 * w + 1 < NQ + 4 ? S[2 * w + 1] : 0u, s2 = 2 * w + 2 < NQ + 4 ? S[2 * w + 2] : 0u;
+        const uint64_t hi = ((uint64_t)s0 << 32) | s1;
+        const uint64_t lo = ((uint64_t)s1 << 32) | s2;
+        pd.R[w] = ((uint64_t)(uint32_t)((hi << sh) >> 32) << 32) | (uint32_t)((lo << sh) >> 32);
+    }
+    constexpr int BUCKET_U4_ = W <= 3 ? 4 : 8;
+    pd.nr = min(nrem, 0x7FFFu) | (row << 16);
+    if (nrem >= p.m_bases && !(p.dbg & DBG_NO_PROBE)) {
+        pd.nr |= PD_PROBE;
+        const uint32_t bk = hash_key(pd.R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
+        pd.boff = bk * (uint32_t)(BUCKET_U4_ * 16);
+        const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(p.buckets) + pd.boff);
+#pragma unroll
+        for (int q = 0; q < BUCKET_U4_; q++) pd.b[q] = bp[q];   // in flight: first used by match_finish
+    } else if (p.nshort == 0) {
+        return 2u;
+    }
+    return 1u;
+}
+
+#ifndef TD_FAST2_WAVES
+#define TD_FAST2_WAVES 0        // 0: derived from the tile size (LDS decides how many workgroups share a CU)
+#endif
+template <int CPT> struct Fast2Waves { static constexpr int value = TD_FAST2_WAVES ? TD_FAST2_WAVES : (CPT <= 6 ? 4 : 3); };
+
+template <int CPT, int W, int NQ>
+__global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const FParams fp) {
+    const KParams &p = fp.k;
+    constexpr int TILE_CH = CPT * FBLOCK;
+    constexpr uint32_t TILE = TILE_CH * 16;
+    static_assert(FBLOCK == 256 && (CPT % 2) == 0, "k_fast2 is written for 256 threads and an even number of chunks per thread");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t halo = p.halo;                                       // bytes staged behind the tile (multiple of 64, >= 16 * nch)
+    uint8_t *L_raw = lds;
+    uint16_t *L_mask = reinterpret_cast<uint16_t *>(lds + TILE + halo);  // terminator mask per chunk; later the list of wanted line starts
+    uint32_t *L_misc = reinterpret_cast<uint32_t *>(lds + TILE + halo + TILE_CH * 2u);   // 64 dwords
+    uint8_t *L_hc = reinterpret_cast<uint8_t *>(L_misc + 64);
+    uint8_t *L_bidx = L_hc + 4 * HC_BYTES_PER_WAVE;
+    TileCtx cx{nullptr, 0u, reinterpret_cast<const unsigned long long *>(L_bidx),
+               reinterpret_cast<const uint32_t *>(L_bidx + p.off_bmeta),
+               reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir)};
+    // L_misc: [1] the tile holds a byte >= 0x80, [2] some chunk ends with '\r', [3] the halo holds a byte >= 0x80,
+    //         [4..7] wave totals, [8..11] wave votes
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint2 *hcS = reinterpret_cast<uint2 *>(L_hc + wave * HC_BYTES_PER_WAVE);
+    uint8_t *hcE = L_hc + wave * HC_BYTES_PER_WAVE + HC_SLOTS * 8;
+    for (uint32_t i = tid; i < p.bblob_bytes / 4; i += FBLOCK)
+        reinterpret_cast<uint32_t *>(L_bidx)[i] = p.bblob[i];
+    if (tid == 0) { L_misc[1] = 0; L_misc[2] = 0; L_misc[3] = 0; }
+#pragma unroll
+    for (int q = 0; q < HC_SLOTS / 64; q++) hcS[q * 64 + lane] = make_uint2(HC_EMPTY, 0u);
+    const bool use_cache = p.hot_cache != 0;
+
+    int st_reads = 0, st_bar = 0, st_tag = 0;
+    constexpr bool PIPE = W <= 3;
+    Pending<W> pd;
+    bool pd_valid = false;
+    const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
+    const uint64_t first_line = p.first_line + carried;
+    const uint32_t nwork = p.ntiles;
+
+    uint4 v[CPT];
+    const bool has_halo = (uint32_t)tid < halo / 16u;
+    auto tile_base = [&](uint32_t tile) -> const uint8_t * {
+        return tile >= p.tail_tile ? p.tail_buf + (uint64_t)(tile - p.tail_tile) * TILE : p.buf + (uint64_t)tile * TILE;
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t voff = (uint32_t)tid * 16u;
+    auto tile_rsrc = [&](uint32_t tile) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base(tile)), 0, (int)(TILE + 4096u), 0x00020000);
+    };
+    auto fetch_tile = [&](uint32_t tile) {
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(tile);
+        if (p.nt_loads) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * (FBLOCK * 16), 2 /* nt */);
+                v[j] = make_uint4(q.x, q.y, q.z, q.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * (FBLOCK * 16), 0);
+                v[j] = make_uint4(q.x, q.y, q.z, q.w);
+            }
+        }
+    };
+    // one wanted line finished: statistics, and the count through the hot-cell cache
+    auto finish_pending = [&](bool &hit, uint32_t &cell) {
+        vm_settled();
+        const uint64_t res = match_finish<W>(p, pd);
+        const uint32_t kind = (uint32_t)(res >> 62);
+        st_reads += 1;
+        if (kind >= 1) st_bar += 1;
+        if (kind == 2) st_tag += 1;
+        hit = kind == 2 && !(p.dbg & DBG_NO_ATOMIC);
+        cell = (uint32_t)res;
+    };
+
+    uint32_t it = blockIdx.x, t = it, aged = 0;
+    if (it < nwork) fetch_tile(t);
+    __syncthreads();
+
+    while (it < nwork) {
+        const uint64_t tbase = (uint64_t)t * TILE;
+        // ---------------- A: raw bytes and terminator masks -> LDS
+        {
+            uint4 vh = make_uint4(0u, 0u, 0u, 0u);
+            if (has_halo) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(t), voff, (int)TILE, 0);
+                vh = make_uint4(q.x, q.y, q.z, q.w);
+            }
+            uint32_t hiacc = 0;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) hiacc |= v[j].x | v[j].y | v[j].z | v[j].w;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) *reinterpret_cast<uint4 *>(L_raw + (size_t)(j * FBLOCK + tid) * 16u) = v[j];
+            const bool general = __any((hiacc & 0x80808080u) != 0);
+            if (__builtin_expect(!general, 1)) {
+                uint32_t cr_absent = 0x80808080u;
+#pragma unroll
+                for (int j = 0; j < CPT; j++) cr_absent_ascii(v[j], cr_absent);
+                const bool has_cr = __any((cr_absent & 0x80808080u) != 0x80808080u);
+                if (__builtin_expect(!has_cr, 1)) {
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) L_mask[j * FBLOCK + tid] = (uint16_t)nl_mask16_ascii(v[j]);
+                } else {
+                    uint32_t crb = 0;
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        const uint32_t nl = eq_mask16_ascii(v[j], 0x0A0A0A0Au, 0x7F7F7F7Fu), cr = eq_mask16_ascii(v[j], 0x0D0D0D0Du, 0x7F7F7F7Fu);
+                        L_mask[j * FBLOCK + tid] = (uint16_t)(nl | (cr & ~(nl >> 1)));      // (a '\r' in the last byte: settled in phase B)
+                        crb |= cr;
+                    }
+                    if (crb & 0x8000u) L_misc[2] = 1;
+                }
+            } else {
+                uint32_t crb = 0;
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    const uint32_t nl = eq_mask16(v[j], 0x0A0A0A0Au), cr = eq_mask16(v[j], 0x0D0D0D0Du);
+                    L_mask[j * FBLOCK + tid] = (uint16_t)(nl | (cr & ~(nl >> 1)));
+                    crb |= cr;
+                }
+                if (crb & 0x8000u) L_misc[2] = 1;
+                if (hiacc & 0x80808080u) L_misc[1] = 1;
+            }
+            if (has_halo) {
+                *reinterpret_cast<uint4 *>(L_raw + TILE + (size_t)tid * 16u) = vh;
+                // (lines that begin in this tile are packed from these bytes with the ASCII forms)
+                if ((vh.x | vh.y | vh.z | vh.w) & 0x80808080u) L_misc[3] = 1;
+            }
+        }
+        // ---------------- end of A: the pending line of the previous tile, the next tile's loads, the pending count
+        __builtin_amdgcn_s_setprio(3);
+        const uint32_t nit = it + gridDim.x;
+        bool phit = false;
+        uint32_t pcell = 0;
+        if (PIPE && pd_valid) { finish_pending(phit, pcell); pd_valid = false; }
+        if (nit < nwork) fetch_tile(nit);
+        if (PIPE) hc_commit(p.counts, hcS, hcE, phit, pcell, (uint32_t)lane, use_cache);
+        lds_barrier();
+        __builtin_amdgcn_s_setprio(1);
+
+        // ---------------- B: terminators of this thread's CPT consecutive chunks, block scan, vote
+        const bool tile_has_hi = L_misc[1] != 0;
+        const bool tile_crb = L_misc[2] != 0;
+        const bool halo_has_hi = L_misc[3] != 0;
+        uint32_t mm[CPT / 2];
+#pragma unroll
+        for (int i = 0; i < CPT / 2; i++) mm[i] = reinterpret_cast<const uint32_t *>(L_mask)[tid * (CPT / 2) + i];
+        const uint32_t span0 = tid * CPT * 16u;
+        if (__builtin_expect(tile_crb, 0)) {
+            // a chunk whose last byte is '\r': one terminator with the '\n' that opens the next chunk, if there is one
+#pragma unroll
+            for (int i = 0; i < CPT / 2; i++) {
+#pragma unroll
+                for (int hbit = 15; hbit < 32; hbit += 16) {
+                    if ((mm[i] >> hbit) & 1u) {
+                        const uint32_t at = span0 + 32u * i + (uint32_t)hbit;
+                        if (L_raw[at] == 0x0Du && L_raw[at + 1] == 0x0Au) mm[i] &= ~(1u << hbit);
+                    }
+                }
+            }
+        }
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < CPT / 2; i++) cnt += __builtin_popcount(mm[i]);
+        const uint32_t incl = wave_incl_scan(cnt, lane);
+        const bool predict = t != 0;
+        {
+            uint32_t fpos = 0;
+            bool found = false;
+#pragma unroll
+            for (int k = CPT / 2 - 1; k >= 0; k--) {
+                if (mm[k]) { fpos = 32u * k + __builtin_ctz(mm[k]); found = true; }
+            }
+            // the first line that starts in this span: do its first eight bytes read as bases?
+            uint2 q8;
+            __builtin_memcpy(&q8, L_raw + span0 + fpos + 1u, 8);
+            const uint32_t c0 = (q8.x >> 1) & 0x03030303u, c1 = (q8.y >> 1) & 0x03030303u;
+            const uint32_t d0 = (q8.x & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, c0);
+            const uint32_t d1 = (q8.y & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, c1);
+            const bool vote_good = found && (d0 | d1) == 0;
+            const uint32_t lclass = (incl - cnt) & 3u;
+            const uint64_t bg = __ballot(vote_good), b0 = __ballot((lclass & 1u) != 0), b1 = __ballot((lclass & 2u) != 0);
+            const uint32_t packed = (uint32_t)__builtin_popcountll(bg & ~b0 & ~b1) | ((uint32_t)__builtin_popcountll(bg & b0 & ~b1) << 8) |
+                                    ((uint32_t)__builtin_popcountll(bg & ~b0 & b1) << 16) | ((uint32_t)__builtin_popcountll(bg & b0 & b1) << 24);
+            if (lane == 63) { L_misc[4 + wave] = incl; L_misc[8 + wave] = packed; }
+        }
+        lds_barrier();
+        uint32_t wbase = 0, total = 0;
+        uint32_t v02 = 0, v13 = 0;
+#pragma unroll
+        for (int w = 0; w < FBLOCK / 64; w++) {
+            const uint32_t x = L_misc[4 + w], pk = L_misc[8 + w];
+            const uint32_t rot = 8u * (total & 3u);
+            const uint32_t r = rot ? ((pk << rot) | (pk >> (32u - rot))) : pk;
+            v02 += r & 0x00FF00FFu;
+            v13 += (r >> 8) & 0x00FF00FFu;
+            if (w < wave) wbase += x;
+            total += x;
+        }
+        const uint32_t excl = wbase + incl - cnt;
+        // ---------------- C: the tile's phase
+        uint32_t r0;
+        if (predict) {
+            const uint32_t votes[4] = {v02 & 0xFFFFu, v13 & 0xFFFFu, v02 >> 16, v13 >> 16};
+            uint32_t best = votes[0]; r0 = 0;
+            if (votes[1] > best) { best = votes[1]; r0 = 1; }
+            if (votes[2] > best) { best = votes[2]; r0 = 2; }
+            if (votes[3] > best) { best = votes[3]; r0 = 3; }
+        } else {
+            r0 = (4u - (uint32_t)(first_line & 3)) & 3u;
+        }
+        const uint32_t nwant = (total + 3u - r0) >> 2;
+        const bool regular = t != 0 && !tile_has_hi && !halo_has_hi && nwant <= (uint32_t)TILE_CH && tbase + TILE + halo <= p.nbytes;
+        if (tid == 0)
+            fp.tile_info[t] = total | (r0 << TI_R0_SHIFT) | (tile_has_hi ? TI_HI : 0u) | (regular ? 0u : TI_SKIP);
+        __builtin_amdgcn_s_setprio(2);
+
+        // ---------------- D: wanted lines, compacted, matched
+        if (regular && !(p.dbg & DBG_NO_PHASE2)) {
+            const uint32_t lc = (r0 - excl) & 3u;
+            const uint32_t nw = cnt > lc ? (cnt - lc + 3u) >> 2 : 0u;
+            uint16_t *L_list = L_mask;
+            if (nw) {
+                uint32_t r = lc, kbase = 0, m = mm[0];
+#pragma unroll
+                for (int k = 0; k < CPT / 2 - 1; k++) {
+                    const uint32_t c = __builtin_popcount(mm[k]);
+                    const bool next = kbase == 32u * k && r >= c;
+                    if (next) { r -= c; kbase = 32u * (k + 1); m = mm[k + 1]; }
+                }
+                const uint32_t m1 = m & (m - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
+                const uint32_t sel = r == 0 ? m : r == 1 ? m1 : r == 2 ? m2 : m3;
+                const uint32_t w0 = span0 + kbase + (sel ? __builtin_ctz(sel) : 0u) + 1u;
+                const uint32_t slot0 = (excl + 3u - r0) >> 2;
+                L_list[slot0] = (uint16_t)w0;
+                if (__builtin_expect(nw > 1, 0)) {
+                    uint32_t li = 0;
+#pragma unroll
+                    for (int k = 0; k < CPT / 2; k++) {
+                        uint32_t mk = mm[k];
+                        while (mk) {
+                            const uint32_t bit = __builtin_ctz(mk);
+                            mk &= mk - 1;
+                            if (li > lc && ((li - lc) & 3u) == 0) L_list[slot0 + ((li - lc) >> 2)] = (uint16_t)(span0 + 32u * k + bit + 1u);
+                            li++;
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+            const uint32_t j0 = ((uint32_t)tid + 64u * (t & 3u)) & (uint32_t)(FBLOCK - 1);
+#pragma nounroll
+            for (uint32_t j = j0; j < nwant; j += FBLOCK) {
+                const uint32_t srel = L_list[j];
+                // (a line that starts in the tile's last bytes and so has no terminator inside the tile is still
+                // whole in the staged window: the halo holds 16 * nch bytes)
+                const uint32_t k = line_prepare<W, NQ>(p, cx, L_raw, srel, pd);
+                if (k == 1u) {
+                    if (PIPE && j + FBLOCK >= nwant) pd_valid = true;
+                    else {
+                        bool h; uint32_t c;
+                        finish_pending(h, c);
+                        hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
+                        vm_settled();
+                    }
+                } else if (__builtin_expect(k == 6u, 0)) {
+                    TileCtx cold = cx;
+                    const uint64_t res = match_line<W, ML_SLOW>(p, cold, tbase + srel, srel, true);
+                    const uint32_t kind = (uint32_t)(res >> 62);
+                    st_reads += 1;
+                    if (kind >= 1) st_bar += 1;
+                    if (kind == 2) {
+                        st_tag += 1;
+                        if (!(p.dbg & DBG_NO_ATOMIC))
+                            __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    vm_settled();
+                } else {
+                    st_reads += 1;
+                    if (k == 2u) st_bar += 1;
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (tid == 0) { L_misc[1] = 0; L_misc[2] = 0; L_misc[3] = 0; }
+        if (use_cache && ++aged == HC_AGE_TILES) { aged = 0; hc_flush(p.counts, hcS, (uint32_t)lane); }
+        lds_barrier();                                    // LDS is reused by the next tile
+        it = nit; t = nit;
+    }
+    if (PIPE && pd_valid) {
+        bool h; uint32_t c;
+        finish_pending(h, c);
+        hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, use_cache);
+    }
+    if (use_cache) hc_flush(p.counts, hcS, (uint32_t)lane);
+
+    unsigned long long r = wave_sum64((unsigned long long)(long long)st_reads), b = wave_sum64((unsigned long long)(long long)st_bar),
+                       g = wave_sum64((unsigned long long)(long long)st_tag);
+    if (lane == 0) {
+        if (r) atomicAdd(p.stats + ST_READS, r);
+        if (b) atomicAdd(p.stats + ST_BARCUT, b);
+        if (g) atomicAdd(p.stats + ST_TAG, g);
+    }
+}
+
+}  // namespace tdk

@@ -97,6 +97,7 @@ struct KParams {
     uint32_t prio;           // fast path: wave priority per phase, see set_prio
     uint32_t stagger, stagger_div;   // start-up stagger of co-resident workgroups (units of 4096 cycles; 0 = off)
     uint32_t dbg;            // timing-only ablations (results wrong when nonzero); see DBG_*
+    uint32_t hot_cache;      // k_fast2: count through the per-wave hot-cell cache in LDS
 };
 
 // ---------------------------------------------------------------- small helpers

@@ -21,6 +21,7 @@
 #include "../../include/td_synth_spec.h"
 #include "kernels.hpp"
 #include "kernel_fast.hpp"
+#include "kernel_fast2.hpp"
 #include "kernel_splitter.hpp"
 #include "gz_source.hpp"
 
@@ -141,6 +142,7 @@ struct td_handle {
     uint32_t barnum = 0, ntags = 0;
     int W = 2;
     uint32_t nch = 0, maxwo = 0, halo = 128, m_bases = 32, nshort = 0, bucket_mask = 0;
+    uint32_t nch2 = 0;                        // k_fast2: 16-byte pieces packed from a line's first byte
     uint32_t bblob_bytes = 0, off_bmeta = 0, off_bdir = 0, off_bcand = 0;
     DevBuf<uint32_t> d_bblob;
     DevBuf<uint4> d_slots, d_shorts;
@@ -174,6 +176,9 @@ struct td_handle {
     uint32_t max_need = 0;                    // bases from a read's start that the matcher may look at
     // options
     int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1, nt_loads = 1;
+    int kernel_gen = 2;                       // main pass of the free-running path: 2 = k_fast2 (lazy packing), 1 = k_fast
+    int tile_kb2 = 24;                        // k_fast2's tile (16 | 24 | 32 KiB)
+    int hot_cache = 1;                        // k_fast2: count through the per-wave hot-cell cache
     uint64_t fast_max_matrix = 1ull << 32;    // the free-running kernel addresses cells as base + 32-bit byte offset
     uint32_t debug_ablate = 0;
     double table_load = 0.5;
@@ -218,6 +223,33 @@ FFn pick_fast(int tile_kb, int W, bool fix) {
     constexpr int C32 = 32 * 1024 / (tdk::FBLOCK * 16), C16 = 16 * 1024 / (tdk::FBLOCK * 16);      // chunks per thread
     if (fix) return tile_kb == 32 ? pick_fast_w<C32, true>(W) : pick_fast_w<C16, true>(W);
     return tile_kb == 32 ? pick_fast_w<C32, false>(W) : pick_fast_w<C16, false>(W);
+}
+
+// k_fast2 is instantiated for a few piece counts per tag width (NQ: 16-byte pieces packed per line);
+// fast2_pieces rounds an index's need up to the next one
+uint32_t fast2_pieces(int W, uint32_t need) {
+    static const uint32_t opts[3][3] = {{3, 4, 6}, {5, 6, 8}, {7, 8, 10}};
+    for (uint32_t o : opts[W - 1]) if (need <= o) return o;
+    return opts[W - 1][2];
+}
+template <int CPT> FFn pick_fast2_c(int W, uint32_t nq) {
+    switch (W) {
+    case 1: return nq == 3 ? tdk::k_fast2<CPT, 1, 3> : nq == 4 ? tdk::k_fast2<CPT, 1, 4> : tdk::k_fast2<CPT, 1, 6>;
+    case 2: return nq == 5 ? tdk::k_fast2<CPT, 2, 5> : nq == 6 ? tdk::k_fast2<CPT, 2, 6> : tdk::k_fast2<CPT, 2, 8>;
+    default: return nq == 7 ? tdk::k_fast2<CPT, 3, 7> : nq == 8 ? tdk::k_fast2<CPT, 3, 8> : tdk::k_fast2<CPT, 3, 10>;
+    }
+}
+FFn pick_fast2(int tile_kb, int W, uint32_t nq) {
+    return tile_kb == 32 ? pick_fast2_c<8>(W, nq) : pick_fast2_c<6>(W, nq);
+}
+FFn pick_fix(int tile_kb, int W) {          // the fix-up pass shares the main pass's tile size
+    if (tile_kb == 24) return pick_fast_w<6, true>(W);
+    return pick_fast(tile_kb, W, true);
+}
+size_t lds_bytes_fast2(const td_handle *h, int tile_kb) {
+    // raw tile + halo | terminator masks (later the list of wanted line starts) | misc | hot-cell cache | barcode index
+    const size_t tile = (size_t)tile_kb * 1024;
+    return tile + h->halo + tile / 16 * 2 + 256 + 4 * tdk::HC_BYTES_PER_WAVE + h->bblob_bytes;
 }
 
 size_t lds_bytes_fast(const td_handle *h, int tile_kb) {
@@ -266,7 +298,19 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     if (nbytes == 0) return TD_OK;
     if (max_reads == 0) max_reads = 1;
     const bool tassel = weights != 0;
-    const int tile_kb = tassel ? 16 : h->tile_kb;
+    // last countable sequence line: ordinal r (1-based) sits on line 4(r-1)+1
+    const uint64_t limit_line = max_reads >= (1ull << 60) ? ~0ull - 8 : 4 * (max_reads - 1) + 1;
+    // ---- the free-running path (predicted line phase, exact resolve, fix-up pass) is chosen when the maxreads
+    // limit cannot bite early (it is still applied exactly, by fix-ups); streamed pieces carry their true first
+    // line on the device, first_line_ub bounds it from above.  It addresses count cells as base + 32-bit offset.
+    const uint64_t fl_ub = std::max(first_line, first_line_ub);
+    const bool limit_far = limit_line >= ~0ull - 16 || limit_line - std::min(limit_line, fl_ub) >= nbytes / 16;
+    const bool counts32 = (uint64_t)h->barnum * h->ntags * 4 < h->fast_max_matrix;
+    const bool use_fast = h->fastpath && !tassel && !h->prescan && limit_far && counts32;
+    // its main pass: k_fast2 (raw tile in LDS, lines packed by the lane that matches them) where the tag width has
+    // the pipelined probe and the tile fits the LDS budget, else k_fast
+    const bool gen2 = use_fast && h->kernel_gen == 2 && h->W <= 3 && lds_bytes_fast2(h, h->tile_kb2) <= LDS_BUDGET;
+    const int tile_kb = tassel ? 16 : gen2 ? h->tile_kb2 : h->tile_kb;
     const uint64_t tile = (uint64_t)tile_kb * 1024;
     const uint64_t ntiles64 = (nbytes + tile - 1) / tile;
     if (ntiles64 > 0x7FFFFFFFull) return fail(TD_E_LIMIT, "buffer too large for one launch; split it");
@@ -287,8 +331,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
 
     tdk::KParams p{};
     p.buf = (const uint8_t *)d_fastq; p.nbytes = nbytes; p.first_line = first_line;
-    // last countable sequence line: ordinal r (1-based) sits on line 4(r-1)+1
-    p.limit_line = max_reads >= (1ull << 60) ? ~0ull - 8 : 4 * (max_reads - 1) + 1;
+    p.limit_line = limit_line;
     p.state = h->d_state.p; p.ticket = h->d_ticket.p; p.ntiles = ntiles; p.halo = h->halo;
     p.bblob = h->d_bblob.p; p.bblob_bytes = h->bblob_bytes; p.off_bmeta = h->off_bmeta;
     p.off_bdir = h->off_bdir; p.off_bcand = h->off_bcand;
@@ -303,14 +346,8 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     p.nt_loads = (uint32_t)h->nt_loads;
     p.prio = (uint32_t)h->prio;
 
-    // ---- fast path: free-running tiles with a predicted line phase, exact resolve, fix-up pass.
-    // Chosen when the maxreads limit cannot bite early (it is still applied exactly, by fix-ups).
-    // (streamed pieces carry their true first line on the device; first_line_ub bounds it from above)
-    const uint64_t fl_ub = std::max(first_line, first_line_ub);
-    const bool limit_far = p.limit_line >= ~0ull - 16 || p.limit_line - std::min(p.limit_line, fl_ub) >= nbytes / 16;
-    // (it addresses count cells as base + 32-bit byte offset)
-    const bool counts32 = (uint64_t)h->barnum * h->ntags * 4 < h->fast_max_matrix;
-    if (h->fastpath && !tassel && !h->prescan && limit_far && counts32) {
+    p.hot_cache = (uint32_t)h->hot_cache;
+    if (use_fast) {
         int rc = h->d_tileinfo.ensure(ntiles); if (rc) return rc;
         const uint32_t fix_cap = 3u * ntiles + 8u;
         rc = h->d_fixlist.ensure(fix_cap); if (rc) return rc;
@@ -330,12 +367,10 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
         tdk::FParams fp{};
         fp.k = p; fp.tile_info = h->d_tileinfo.p; fp.fixlist = h->d_fixlist.p; fp.nfix = h->d_nfix.p; fp.fix_cap = fix_cap;
         HIPCHK(hipMemsetAsync(h->d_nfix.p, 0, 4, stream));
-        FFn ffn = pick_fast(tile_kb, h->W, false), fixfn = pick_fast(tile_kb, h->W, true);
-        const size_t flds = lds_bytes_fast(h, tile_kb);
-        if (flds > 48 * 1024) {
-            HIPCHK(hipFuncSetAttribute((const void *)ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-            HIPCHK(hipFuncSetAttribute((const void *)fixfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-        }
+        FFn ffn = gen2 ? pick_fast2(tile_kb, h->W, h->nch2) : pick_fast(tile_kb, h->W, false), fixfn = pick_fix(tile_kb, h->W);
+        const size_t flds = gen2 ? lds_bytes_fast2(h, tile_kb) : lds_bytes_fast(h, tile_kb), fixlds = lds_bytes_fast(h, tile_kb);
+        if (flds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+        if (fixlds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)fixfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fixlds));
         int bpc = h->blocks_per_cu;
         if (bpc <= 0) {
             if (h->occ_fn != (const void *)ffn || h->occ_lds != flds) {
@@ -363,7 +398,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
             hipLaunchKernelGGL(tdk::k_resolve_sums, dim3(rblocks), dim3(256), 0, stream, fp, super);
             hipLaunchKernelGGL(tdk::k_resolve, dim3(rblocks), dim3(1024), 0, stream, fp, super);
         }
-        hipLaunchKernelGGL(fixfn, dim3(std::min<uint32_t>(grid, (uint32_t)h->num_cu * 2)), dim3(tdk::FBLOCK), flds, stream, fp);
+        hipLaunchKernelGGL(fixfn, dim3(std::min<uint32_t>(grid, (uint32_t)h->num_cu * 2)), dim3(tdk::FBLOCK), fixlds, stream, fp);
         HIPCHK(hipGetLastError());
         if (h->timing) HIPCHK(hipEventRecord(e1, stream));
         return TD_OK;
@@ -600,10 +635,14 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
     const uint32_t need = 15 + max_off + (uint32_t)maxlen;
     h->max_need = max_off + (uint32_t)maxlen;
     h->nch = std::min<uint32_t>(2 * W + 3, std::max<uint32_t>(3, (need + 15) / 16));
-    h->halo = (h->nch * 16 + 63) / 64 * 64;
+    h->nch2 = W <= 3 ? fast2_pieces(W, (h->max_need + 15) / 16) : 0;
+    // bytes staged behind a tile: a line that starts in its last byte is matched from there (k_fast: chunk-aligned,
+    // nch chunks; k_fast2: nch2 pieces from the line's own first byte, and its vote reads 8 bytes)
+    h->halo = (std::max(h->nch * 16, h->nch2 * 16 + 16) + 63) / 64 * 64;
     h->barnum = barnum; h->ntags = ntags;
     if (lds_bytes(h, 16) > LDS_BUDGET) return fail(TD_E_LIMIT, "barcode index does not fit the LDS budget");
     if (lds_bytes(h, h->tile_kb) > LDS_BUDGET) h->tile_kb = 16;
+    if (lds_bytes_fast2(h, h->tile_kb2) > LDS_BUDGET) h->tile_kb2 = 24;     // (beyond that too: k_fast takes over, launch_count)
 
     rc = h->d_bblob.ensure(h->bblob_bytes / 4); if (rc) return rc;
     HIPCHK(hipMemcpy(h->d_bblob.p, blob.data(), h->bblob_bytes, hipMemcpyHostToDevice));
@@ -939,6 +978,14 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     else if (n == "prescan") h->prescan = value ? 1 : 0;
     else if (n == "timing") h->timing = value ? 1 : 0;
     else if (n == "fastpath") h->fastpath = value ? 1 : 0;
+    else if (n == "kernel") {
+        if (value != 1 && value != 2) return fail(TD_E_ARG, "kernel must be 1 (k_fast) or 2 (k_fast2)");
+        h->kernel_gen = (int)value;
+    } else if (n == "tile_kb2") {
+        if (value != 24 && value != 32) return fail(TD_E_ARG, "tile_kb2 must be 24 or 32");
+        if (h->have_index && lds_bytes_fast2(h, (int)value) > LDS_BUDGET) return fail(TD_E_LIMIT, "tile does not fit the LDS budget with this index");
+        h->tile_kb2 = (int)value;
+    } else if (n == "hot_cache") h->hot_cache = value ? 1 : 0;
     else if (n == "stagger") h->stagger = (int)value;
     else if (n == "prio") h->prio = (int)value & 255;
     else if (n == "table_load_pct") h->table_load = std::max<int64_t>(10, std::min<int64_t>(value, 95)) / 100.0;

@@ -8,6 +8,28 @@ import numpy as np
 from oracle import c_oracle
 
 
+# Every way the count can be computed on the device (td_set_option names): the free-running path with its
+# second-generation main pass (k_fast2, 24 and 32 KiB tiles) and its first (k_fast, 32 and 16 KiB tiles), and
+# the exact look-back kernel.  All give the same counts.
+KERNEL_MODES = [
+    dict(fastpath=1, kernel=2, tile_kb2=24),
+    dict(fastpath=1, kernel=2, tile_kb2=32),
+    dict(fastpath=1, kernel=1, tile_kb=32),
+    dict(fastpath=1, kernel=1, tile_kb=16),
+    dict(fastpath=0, tile_kb=32),
+]
+DEFAULT_MODE = dict(fastpath=1, kernel=2, tile_kb2=24, tile_kb=32)
+
+
+def apply_mode(eng, mode):
+    for k, v in mode.items():
+        eng.set_option(k, v)
+
+
+def mode_id(mode):
+    return ",".join("%s=%s" % kv for kv in mode.items())
+
+
 def synth_params(cfg):
     return cfg.params(c_oracle.SynthParams)
 

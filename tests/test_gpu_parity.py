@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 from conftest import load_golden, write_case_file, case_payload
-from helpers import dirty_fastq, small_index, synth_expected, synth_host_bytes
+from helpers import (DEFAULT_MODE, KERNEL_MODES, apply_mode, dirty_fastq, mode_id, small_index, synth_expected,
+                     synth_host_bytes)
 from oracle import c_oracle
 from oracle import tagdigger_oracle as orc
 
@@ -53,8 +54,8 @@ def test_golden_find_tags_fastq(case, tmp_path):
         assert got == case["counts"]
 
 
-@pytest.mark.parametrize("tile_kb,prescan", [(16, 0), (32, 0), (16, 1), (32, 1)])
-def test_golden_all_kernel_modes(eng, tile_kb, prescan):
+@pytest.mark.parametrize("mode", KERNEL_MODES + [dict(prescan=1, tile_kb=16), dict(prescan=1, tile_kb=32)], ids=mode_id)
+def test_golden_all_kernel_modes(eng, mode):
     """Every non-raising, non-gz fixture through the in-memory path in each kernel configuration."""
     import base64, gzip
     try:
@@ -65,13 +66,12 @@ def test_golden_all_kernel_modes(eng, tile_kb, prescan):
             if case["filename"][-2:].lower() == "gz":
                 data = gzip.decompress(data)
             eng.set_index(case["barcodes"], case["tags"], case["kwargs"].get("cutsite", "TGCAG"))
-            eng.set_option("tile_kb", tile_kb)
-            eng.set_option("prescan", prescan)
+            apply_mode(eng, mode)
             eng.count_bytes(data, maxreads=case["kwargs"].get("maxreads", 5e9))
             assert eng.counts() == case["counts"], case["name"]
     finally:
-        eng.set_option("tile_kb", 16)
         eng.set_option("prescan", 0)
+        apply_mode(eng, DEFAULT_MODE)
 
 
 def test_synth_device_generator_and_counts(eng):
@@ -111,16 +111,18 @@ def test_fuzz_vs_oracle(eng, cutsite, nl, seed):
     ora = c_oracle.COracle(barcodes, tags, cutsite)
     ost = {}
     want = ora.count_bytes(data, stats=ost)
-    for tile_kb in (16, 32):
-        eng.set_index(barcodes, tags, cutsite)
-        eng.set_option("tile_kb", tile_kb)
-        lines = eng.count_bytes(data)
-        got = eng.counts_numpy()
-        st = eng.stats()
-        assert (got == want).all(), (cutsite, nl, tile_kb)
-        assert (st["reads"], st["barcut"], st["tag"]) == (ost["reads"], ost["barcut"], ost["tag"])
-        assert lines == st["lines"] == data.count(b"\n") + data.count(b"\r") - data.count(b"\r\n")
-    eng.set_option("tile_kb", 16)
+    try:
+        for mode in KERNEL_MODES:
+            eng.set_index(barcodes, tags, cutsite)
+            apply_mode(eng, mode)
+            lines = eng.count_bytes(data)
+            got = eng.counts_numpy()
+            st = eng.stats()
+            assert (got == want).all(), (cutsite, nl, mode)
+            assert (st["reads"], st["barcut"], st["tag"]) == (ost["reads"], ost["barcut"], ost["tag"]), mode
+            assert lines == st["lines"] == data.count(b"\n") + data.count(b"\r") - data.count(b"\r\n")
+    finally:
+        apply_mode(eng, DEFAULT_MODE)
 
 
 def test_fuzz_campaign(eng):
@@ -147,38 +149,46 @@ def test_fuzz_campaign(eng):
             ost = {}
             want = c_oracle.COracle(barcodes, tags, cutsite).count_bytes(data, stats=ost)
             eng.set_index(barcodes, tags, cutsite)
-            for tile_kb, fast in ((32, 1), (16, 1), (32, 0)):
-                eng.set_option("tile_kb", tile_kb)
-                eng.set_option("fastpath", fast)
+            for mode in KERNEL_MODES:
+                apply_mode(eng, mode)
                 eng.reset()
                 eng.count_bytes(data)
                 st = eng.stats()
-                assert (eng.counts_numpy() == want).all(), ("seed", seed0 + ncase, cutsite, nl, tile_kb, fast)
-                assert (st["reads"], st["barcut"], st["tag"]) == (ost["reads"], ost["barcut"], ost["tag"]), ("seed", seed0 + ncase)
+                assert (eng.counts_numpy() == want).all(), ("seed", seed0 + ncase, cutsite, nl, mode)
+                assert (st["reads"], st["barcut"], st["tag"]) == (ost["reads"], ost["barcut"], ost["tag"]), ("seed", seed0 + ncase, mode)
             ncase += 1
             if time.time() >= next_note:                      # (a long soak must not look hung)
                 print(" [%d cases so far] " % ncase, end="", flush=True)
                 next_note = time.time() + 30
     finally:
-        eng.set_option("tile_kb", 16)
-        eng.set_option("fastpath", 1)
+        apply_mode(eng, DEFAULT_MODE)
     print(" [fuzz campaign: %d cases] " % ncase, end="")
     assert ncase > 0
 
 
-def test_tile_boundary_sweep(eng):
-    """Slide a record across a tile boundary byte by byte (16 KiB tiles), with \\r\\n split across it."""
+@pytest.mark.parametrize("mode", KERNEL_MODES, ids=mode_id)
+def test_tile_boundary_sweep(eng, mode):
+    """Slide a record across a tile boundary byte by byte, with \\r\\n split across it -- the boundary
+    between the buffer's second and third tiles, so that both are ordinary tiles of the main pass (the
+    first and the last go through other code)."""
     barcodes, tags = ["AACG", "TTGACC"], ["TGCAGAAAC", "TGCAGGGGT"]
     rec = b"@h\r\nAACGTGCAGAAACTT\r\n+\r\nIIII\r\n"
     eng.set_index(barcodes, tags, "TGCAG")
     ora = c_oracle.COracle(barcodes, tags, "TGCAG")
-    for pad in list(range(16384 - 40, 16384 + 8)):
-        # a first record whose quality line is padded so the second record lands around the boundary
-        head = b"@p\nGGGG\n+\n" + b"I" * (pad - 10 - 1) + b"\n"
-        data = head + rec + rec
-        eng.reset()
-        eng.count_bytes(data)
-        assert (eng.counts_numpy() == ora.count_bytes(data)).all(), pad
+    tile = 1024 * (mode["tile_kb2"] if mode.get("kernel") == 2 else mode["tile_kb"])
+
+    def padded(n):          # one record of exactly n bytes
+        return b"@p\nGGGG\n+\n" + b"I" * (n - 10 - 1) + b"\n"
+    try:
+        apply_mode(eng, mode)
+        for pad in list(range(tile - 40, tile + 8)):
+            # tile 0 is one padded record; a second one ends `pad` bytes into tile 1 ... so that rec straddles 2 * tile
+            data = padded(tile) + padded(pad) + rec + rec + padded(tile) + padded(tile // 2) + rec
+            eng.reset()
+            eng.count_bytes(data)
+            assert (eng.counts_numpy() == ora.count_bytes(data)).all(), pad
+    finally:
+        apply_mode(eng, DEFAULT_MODE)
 
 
 def test_long_lines_and_phase_shifts(eng):
@@ -188,12 +198,14 @@ def test_long_lines_and_phase_shifts(eng):
     barcodes, tags, cutsites = small_index(rnd, "TGCAG", nbar=12, ntag=60)
     data = dirty_fastq(rnd, barcodes, tags, cutsites, nrec=4000, long_lines=True, permanent_shifts=True)
     want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data)
-    for tile_kb in (16, 32):
-        eng.set_index(barcodes, tags, "TGCAG")
-        eng.set_option("tile_kb", tile_kb)
-        eng.count_bytes(data)
-        assert (eng.counts_numpy() == want).all(), tile_kb
-    eng.set_option("tile_kb", 32)
+    try:
+        for mode in KERNEL_MODES:
+            eng.set_index(barcodes, tags, "TGCAG")
+            apply_mode(eng, mode)
+            eng.count_bytes(data)
+            assert (eng.counts_numpy() == want).all(), mode
+    finally:
+        apply_mode(eng, DEFAULT_MODE)
 
 
 def test_many_short_lines_overflow_rounds(eng):
@@ -202,12 +214,14 @@ def test_many_short_lines_overflow_rounds(eng):
     eng.set_index(barcodes, tags, "")
     body = b"\n".join([b"x", b"ACC", b"y", b"z"] * 3000) + b"\n" + b"\n" * 9000 + b"@\nAGT\n+\n!\n"
     ora = c_oracle.COracle(barcodes, tags, "")
-    for tile_kb in (16, 32):
-        eng.reset()
-        eng.set_option("tile_kb", tile_kb)
-        eng.count_bytes(body)
-        assert (eng.counts_numpy() == ora.count_bytes(body)).all()
-    eng.set_option("tile_kb", 16)
+    try:
+        for mode in KERNEL_MODES:
+            eng.reset()
+            apply_mode(eng, mode)
+            eng.count_bytes(body)
+            assert (eng.counts_numpy() == ora.count_bytes(body)).all(), mode
+    finally:
+        apply_mode(eng, DEFAULT_MODE)
 
 
 def test_streamed_pieces_and_maxreads(eng):
