@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--stagger", type=int, default=-1)
     ap.add_argument("--table-load", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
-    ap.add_argument("--prio", type=int, default=-1)
+    ap.add_argument("--prio", type=lambda v: int(v, 0), default=-1)
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to td_set_option (repeatable)")
     ap.add_argument("--debug-ablate", type=int, default=0, help="timing-only kernel ablation bits (implies --no-check)")
     args = ap.parse_args()

@@ -182,7 +182,11 @@ int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
  *   "nt_loads"       1 (default): stream the FASTQ with non-temporal loads
  *   "prio"           wave priority per phase of the fast path, two bits each: phase A | B-C << 2 |
  *                    D << 4 | end of A << 6 (default 0xE4)
- *   "table_load_pct" fill of the tag hash table, 10..95 (default 50); applies to the next td_set_index
+ *   "table_load_pct" fill of the tag hash table, 10..95 (default 25); applies to the next td_set_index
+ *   "kernel"         main pass of the free-running path: 2 (default) k_fast2 -- raw tile in LDS, lines packed by the
+ *                    lane that matches them, hot-cell cache (kernel_fast2.hpp); 1 k_fast (kernel_fast.hpp)
+ *   "tile_kb2"       k_fast2's tile: 0 (default: chosen from the barcode index's LDS footprint) | 16 | 24 | 32
+ *   "hot_cache"      1 (default): k_fast2 counts through its per-wave cache of hot cells in LDS
  *   "stagger"        start-up stagger of co-resident workgroups, in 4096-cycle units (default 0)
  *   "timing"         1: record HIP events around every launch for td_kernel_time_ms
  *   "fast_max_matrix_bytes"  count matrices of this many bytes and more go to the exact kernel (the

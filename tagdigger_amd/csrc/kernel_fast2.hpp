@@ -31,6 +31,7 @@ namespace tdk {
 constexpr int HC_SLOTS = 128;                   // hot-cell cache: slots per wave (direct mapped)
 constexpr uint32_t HC_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t HC_AGE_TILES = 64;           // every so many tiles the cache is written out and cleared
+constexpr uint32_t HC_REST = 15;                // ageing periods a wave leaves its cache off after one without hits
 constexpr uint32_t HC_BYTES_PER_WAVE = HC_SLOTS * 8 + HC_SLOTS;
 
 __device__ __forceinline__ uint32_t hc_hash(uint32_t cell) {
@@ -135,11 +136,11 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
     const uint8_t *src = L_raw + srel;
     uint4 q[NQ];
 #pragma unroll
-    for (int i = 0; i < NQ; i++) q[i] = lds_read16(src + 16 * i);
+    for (int i = 0; i < NQ; i++) q[i] = (p.dbg & DBG_NO_LINEPACK) && i > 1 ? q[1] : lds_read16(src + 16 * i);
     const uint32_t first = q[0].x & 0xFFu;
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
-        const uint2 e = pack16_ascii(q[i].x, q[i].y, q[i].z, q[i].w);
+        const uint2 e = (p.dbg & DBG_NO_LINEPACK) && i > 1 ? make_uint2(S[1], 0u) : pack16_ascii(q[i].x, q[i].y, q[i].z, q[i].w);
         S[i] = e.x;
         if (i & 1) inv[i >> 1] |= e.y << 16; else inv[i >> 1] |= e.y;
     }
@@ -197,11 +198,19 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
     pd.nr = min(nrem, 0x7FFFu) | (row << 16);
     if (nrem >= p.m_bases && !(p.dbg & DBG_NO_PROBE)) {
         pd.nr |= PD_PROBE;
-        const uint32_t bk = hash_key(pd.R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
+        const uint32_t hk = hash_key(pd.R[0] >> (64u - 2u * p.m_bases));
+        const uint32_t bk = hk & p.bucket_mask;
         pd.boff = bk * (uint32_t)(BUCKET_U4_ * 16);
         const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(p.buckets) + pd.boff);
+        pd.boff |= hk >> 27;                                // (the key's bit in the buckets' overflow filters)
+        if (p.dbg & DBG_PROBE_16B) {
+            pd.b[0] = bp[0];
 #pragma unroll
-        for (int q = 0; q < BUCKET_U4_; q++) pd.b[q] = bp[q];   // in flight: first used by match_finish
+            for (int q = 1; q < BUCKET_U4_; q++) pd.b[q] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+            for (int q = 0; q < BUCKET_U4_; q++) pd.b[q] = bp[q];   // in flight: first used by match_finish
+        }
     } else if (p.nshort == 0) {
         return 2u;
     }
@@ -213,35 +222,47 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
 #endif
 template <int CPT> struct Fast2Waves { static constexpr int value = TD_FAST2_WAVES ? TD_FAST2_WAVES : (CPT <= 6 ? 4 : 3); };
 
+// Layout of a tile over the workgroup: wave w owns the contiguous quarter [w, w + 1) * TILE / 4 -- it loads it
+// (1 KiB per load instruction: coalesced), writes its raw bytes and terminator masks to LDS and reads back
+// only its OWN masks, so phases A and B need no workgroup barrier between them; it also lists the starts of
+// the lines that follow its terminators, by wave-local ordinal, in the space of its masks.  ONE barrier then
+// publishes raw bytes, lists, totals and votes; after it wanted line j of the tile -- the line behind the
+// terminator with in-tile ordinal r0 + 4 j -- is found by three compares against the waves' running totals
+// and matched by thread j (full lanes).  Two barriers per tile (that one, and the one that frees the LDS).
 template <int CPT, int W, int NQ>
 __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const FParams fp) {
     const KParams &p = fp.k;
     constexpr int TILE_CH = CPT * FBLOCK;
     constexpr uint32_t TILE = TILE_CH * 16;
+    constexpr uint32_t WCH = CPT * 64;                // chunks per wave
+    constexpr uint32_t WBYTES = WCH * 16;
     static_assert(FBLOCK == 256 && (CPT % 2) == 0, "k_fast2 is written for 256 threads and an even number of chunks per thread");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t halo = p.halo;                                       // bytes staged behind the tile (multiple of 64, >= 16 * nch)
+    const uint32_t halo = p.halo;                                       // bytes staged behind the tile (multiple of 64, >= 16 * NQ + 16)
     uint8_t *L_raw = lds;
-    uint16_t *L_mask = reinterpret_cast<uint16_t *>(lds + TILE + halo);  // terminator mask per chunk; later the list of wanted line starts
+    uint16_t *L_mask = reinterpret_cast<uint16_t *>(lds + TILE + halo);  // terminator mask per chunk; then, per wave, its list of line starts
     uint32_t *L_misc = reinterpret_cast<uint32_t *>(lds + TILE + halo + TILE_CH * 2u);   // 64 dwords
     uint8_t *L_hc = reinterpret_cast<uint8_t *>(L_misc + 64);
     uint8_t *L_bidx = L_hc + 4 * HC_BYTES_PER_WAVE;
     TileCtx cx{nullptr, 0u, reinterpret_cast<const unsigned long long *>(L_bidx),
                reinterpret_cast<const uint32_t *>(L_bidx + p.off_bmeta),
                reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir)};
-    // L_misc: [1] the tile holds a byte >= 0x80, [2] some chunk ends with '\r', [3] the halo holds a byte >= 0x80,
-    //         [4..7] wave totals, [8..11] wave votes
+    // L_misc: [1] the tile holds a byte >= 0x80, [2] a wave has more terminators than its list holds,
+    //         [3] the halo holds a byte >= 0x80, [4..7] wave totals, [8..11] wave votes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint2 *hcS = reinterpret_cast<uint2 *>(L_hc + wave * HC_BYTES_PER_WAVE);
     uint8_t *hcE = L_hc + wave * HC_BYTES_PER_WAVE + HC_SLOTS * 8;
     for (uint32_t i = tid; i < p.bblob_bytes / 4; i += FBLOCK)
         reinterpret_cast<uint32_t *>(L_bidx)[i] = p.bblob[i];
-    if (tid == 0) { L_misc[1] = 0; L_misc[2] = 0; L_misc[3] = 0; }
+    if (tid == 0) { L_misc[0] = 0; L_misc[1] = 0; L_misc[2] = 0; L_misc[3] = 0; }
 #pragma unroll
     for (int q = 0; q < HC_SLOTS / 64; q++) hcS[q * 64 + lane] = make_uint2(HC_EMPTY, 0u);
-    const bool use_cache = p.hot_cache != 0;
+    // The hot-cell cache pays for itself only when cells repeat: each wave watches its own hit rate over an
+    // ageing period and leaves the cache off for the next HC_REST periods when hardly anything hit.
+    bool hc_on = p.hot_cache != 0;
+    uint32_t hc_hits = 0, hc_rest = 0;
 
     int st_reads = 0, st_bar = 0, st_tag = 0;
     constexpr bool PIPE = W <= 3;
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         return tile >= p.tail_tile ? p.tail_buf + (uint64_t)(tile - p.tail_tile) * TILE : p.buf + (uint64_t)tile * TILE;
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t voff = (uint32_t)tid * 16u;
+    const uint32_t voff = (uint32_t)wave * WBYTES + (uint32_t)lane * 16u;    // this thread's first chunk; load j is 1 KiB further
     auto tile_rsrc = [&](uint32_t tile) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base(tile)), 0, (int)(TILE + 4096u), 0x00020000);
     };
@@ -266,21 +287,21 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         if (p.nt_loads) {
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
-                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * (FBLOCK * 16), 2 /* nt */);
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * 1024, 2 /* nt */);
                 v[j] = make_uint4(q.x, q.y, q.z, q.w);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
-                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * (FBLOCK * 16), 0);
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * 1024, 0);
                 v[j] = make_uint4(q.x, q.y, q.z, q.w);
             }
         }
     };
-    // one wanted line finished: statistics, and the count through the hot-cell cache
+    // one wanted line finished: statistics, and whether / where to count
     auto finish_pending = [&](bool &hit, uint32_t &cell) {
         vm_settled();
-        const uint64_t res = match_finish<W>(p, pd);
+        const uint64_t res = (p.dbg & DBG_NO_COMPARE) ? (R_TAG | (uint64_t)(pd.b[0].y & 0xFFFFFu)) : match_finish<W>(p, pd);
         const uint32_t kind = (uint32_t)(res >> 62);
         st_reads += 1;
         if (kind >= 1) st_bar += 1;
@@ -289,24 +310,31 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         cell = (uint32_t)res;
     };
 
+#ifdef TD_PHASE_PROF
+    unsigned long long prof_acc[PROF_PHASES] = {};
+    unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t it = blockIdx.x, t = it, aged = 0;
     if (it < nwork) fetch_tile(t);
     __syncthreads();
 
     while (it < nwork) {
         const uint64_t tbase = (uint64_t)t * TILE;
-        // ---------------- A: raw bytes and terminator masks -> LDS
+        TD_STAMP(0);   // loop head
+        // ---------------- A: this wave's quarter: raw bytes and terminator masks -> LDS
+        bool wave_crb = false;           // a chunk of this wave ends with '\r' (wave-uniform)
         {
             uint4 vh = make_uint4(0u, 0u, 0u, 0u);
             if (has_halo) {
-                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(t), voff, (int)TILE, 0);
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(t), (uint32_t)tid * 16u, (int)TILE, 0);
                 vh = make_uint4(q.x, q.y, q.z, q.w);
             }
             uint32_t hiacc = 0;
 #pragma unroll
             for (int j = 0; j < CPT; j++) hiacc |= v[j].x | v[j].y | v[j].z | v[j].w;
 #pragma unroll
-            for (int j = 0; j < CPT; j++) *reinterpret_cast<uint4 *>(L_raw + (size_t)(j * FBLOCK + tid) * 16u) = v[j];
+            for (int j = 0; j < CPT; j++) *reinterpret_cast<uint4 *>(L_raw + voff + j * 1024) = v[j];
+            uint16_t *Lm = L_mask + wave * WCH + lane;
             const bool general = __any((hiacc & 0x80808080u) != 0);
             if (__builtin_expect(!general, 1)) {
                 uint32_t cr_absent = 0x80808080u;
@@ -315,26 +343,26 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                 const bool has_cr = __any((cr_absent & 0x80808080u) != 0x80808080u);
                 if (__builtin_expect(!has_cr, 1)) {
 #pragma unroll
-                    for (int j = 0; j < CPT; j++) L_mask[j * FBLOCK + tid] = (uint16_t)nl_mask16_ascii(v[j]);
+                    for (int j = 0; j < CPT; j++) Lm[j * 64] = (uint16_t)nl_mask16_ascii(v[j]);
                 } else {
-                    uint32_t crb = 0;
+                    uint32_t crs = 0;
 #pragma unroll
                     for (int j = 0; j < CPT; j++) {
                         const uint32_t nl = eq_mask16_ascii(v[j], 0x0A0A0A0Au, 0x7F7F7F7Fu), cr = eq_mask16_ascii(v[j], 0x0D0D0D0Du, 0x7F7F7F7Fu);
-                        L_mask[j * FBLOCK + tid] = (uint16_t)(nl | (cr & ~(nl >> 1)));      // (a '\r' in the last byte: settled in phase B)
-                        crb |= cr;
+                        Lm[j * 64] = (uint16_t)(nl | (cr & ~(nl >> 1)));      // (a '\r' in the chunk's last byte: settled in phase B)
+                        crs |= cr;
                     }
-                    if (crb & 0x8000u) L_misc[2] = 1;
+                    wave_crb = __any((crs & 0x8000u) != 0);
                 }
             } else {
-                uint32_t crb = 0;
+                uint32_t crs = 0;
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
                     const uint32_t nl = eq_mask16(v[j], 0x0A0A0A0Au), cr = eq_mask16(v[j], 0x0D0D0D0Du);
-                    L_mask[j * FBLOCK + tid] = (uint16_t)(nl | (cr & ~(nl >> 1)));
-                    crb |= cr;
+                    Lm[j * 64] = (uint16_t)(nl | (cr & ~(nl >> 1)));
+                    crs |= cr;
                 }
-                if (crb & 0x8000u) L_misc[2] = 1;
+                wave_crb = __any((crs & 0x8000u) != 0);
                 if (hiacc & 0x80808080u) L_misc[1] = 1;
             }
             if (has_halo) {
@@ -343,43 +371,41 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                 if ((vh.x | vh.y | vh.z | vh.w) & 0x80808080u) L_misc[3] = 1;
             }
         }
-        // ---------------- end of A: the pending line of the previous tile, the next tile's loads, the pending count
-        __builtin_amdgcn_s_setprio(3);
-        const uint32_t nit = it + gridDim.x;
-        bool phit = false;
-        uint32_t pcell = 0;
-        if (PIPE && pd_valid) { finish_pending(phit, pcell); pd_valid = false; }
-        if (nit < nwork) fetch_tile(nit);
-        if (PIPE) hc_commit(p.counts, hcS, hcE, phit, pcell, (uint32_t)lane, use_cache);
-        lds_barrier();
-        __builtin_amdgcn_s_setprio(1);
+        wave_lds_fence();          // this wave's masks and raw bytes are in LDS (nothing of another wave is read before the barrier)
+        TD_STAMP(1);   // A: wait for the tile's bytes, raw + masks -> LDS
+        if (p.prio & 0x100u) __builtin_amdgcn_s_setprio(1);      // (experiment: the serial phase B above the arithmetic of other workgroups' A)
 
-        // ---------------- B: terminators of this thread's CPT consecutive chunks, block scan, vote
-        const bool tile_has_hi = L_misc[1] != 0;
-        const bool tile_crb = L_misc[2] != 0;
-        const bool halo_has_hi = L_misc[3] != 0;
+        // ---------------- B: terminators of this thread's CPT consecutive chunks, wave scan, vote, list of line starts
         uint32_t mm[CPT / 2];
 #pragma unroll
         for (int i = 0; i < CPT / 2; i++) mm[i] = reinterpret_cast<const uint32_t *>(L_mask)[tid * (CPT / 2) + i];
         const uint32_t span0 = tid * CPT * 16u;
-        if (__builtin_expect(tile_crb, 0)) {
-            // a chunk whose last byte is '\r': one terminator with the '\n' that opens the next chunk, if there is one
+        const uint32_t wend = ((uint32_t)wave + 1u) * WBYTES;               // end of this wave's quarter
+        {
+            // a chunk whose last byte is '\r' (bit 15 of its mask is set for it -- or for a '\n' there): one terminator
+            // with the '\n' that opens the next chunk, if there is one
+            if (__builtin_expect(wave_crb, 0)) {
 #pragma unroll
-            for (int i = 0; i < CPT / 2; i++) {
+                for (int i = 0; i < CPT / 2; i++) {
 #pragma unroll
-                for (int hbit = 15; hbit < 32; hbit += 16) {
-                    if ((mm[i] >> hbit) & 1u) {
-                        const uint32_t at = span0 + 32u * i + (uint32_t)hbit;
-                        if (L_raw[at] == 0x0Du && L_raw[at + 1] == 0x0Au) mm[i] &= ~(1u << hbit);
+                    for (int hbit = 15; hbit < 32; hbit += 16) {
+                        if ((mm[i] >> hbit) & 1u) {
+                            const uint32_t at = span0 + 32u * i + (uint32_t)hbit;
+                            if (L_raw[at] == 0x0Du) {
+                                // (the next byte may belong to another wave's quarter, or to the halo: not in LDS yet)
+                                const uint32_t nx = at + 1u < wend ? (uint32_t)L_raw[at + 1u] : (uint32_t)tile_base(t)[at + 1u];
+                                if (nx == 0x0Au) mm[i] &= ~(1u << hbit);
+                            }
+                        }
                     }
                 }
+                vm_settled();
             }
         }
         uint32_t cnt = 0;
 #pragma unroll
         for (int i = 0; i < CPT / 2; i++) cnt += __builtin_popcount(mm[i]);
         const uint32_t incl = wave_incl_scan(cnt, lane);
-        const bool predict = t != 0;
         {
             uint32_t fpos = 0;
             bool found = false;
@@ -387,36 +413,69 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
             for (int k = CPT / 2 - 1; k >= 0; k--) {
                 if (mm[k]) { fpos = 32u * k + __builtin_ctz(mm[k]); found = true; }
             }
-            // the first line that starts in this span: do its first eight bytes read as bases?
-            uint2 q8;
-            __builtin_memcpy(&q8, L_raw + span0 + fpos + 1u, 8);
+            // the first line that starts in this span: do its first eight bytes (inside this wave's quarter) read as bases?
+            const uint32_t ls = span0 + fpos + 1u;
+            uint2 q8 = make_uint2(0u, 0u);
+            if (found && ls + 8u <= wend) __builtin_memcpy(&q8, L_raw + ls, 8);
             const uint32_t c0 = (q8.x >> 1) & 0x03030303u, c1 = (q8.y >> 1) & 0x03030303u;
             const uint32_t d0 = (q8.x & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, c0);
             const uint32_t d1 = (q8.y & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, c1);
-            const bool vote_good = found && (d0 | d1) == 0;
+            const bool vote_good = (d0 | d1) == 0;
             const uint32_t lclass = (incl - cnt) & 3u;
             const uint64_t bg = __ballot(vote_good), b0 = __ballot((lclass & 1u) != 0), b1 = __ballot((lclass & 2u) != 0);
             const uint32_t packed = (uint32_t)__builtin_popcountll(bg & ~b0 & ~b1) | ((uint32_t)__builtin_popcountll(bg & b0 & ~b1) << 8) |
                                     ((uint32_t)__builtin_popcountll(bg & ~b0 & b1) << 16) | ((uint32_t)__builtin_popcountll(bg & b0 & b1) << 24);
-            if (lane == 63) { L_misc[4 + wave] = incl; L_misc[8 + wave] = packed; }
-        }
-        lds_barrier();
-        uint32_t wbase = 0, total = 0;
-        uint32_t v02 = 0, v13 = 0;
+            // the lines behind this wave's terminators, by wave-local ordinal, into the space of its masks (every lane of
+            // the wave holds its masks in registers by now)
+            uint16_t *Ll = L_mask + wave * WCH;
+            uint32_t k = incl - cnt;
 #pragma unroll
-        for (int w = 0; w < FBLOCK / 64; w++) {
-            const uint32_t x = L_misc[4 + w], pk = L_misc[8 + w];
-            const uint32_t rot = 8u * (total & 3u);
-            const uint32_t r = rot ? ((pk << rot) | (pk >> (32u - rot))) : pk;
-            v02 += r & 0x00FF00FFu;
-            v13 += (r >> 8) & 0x00FF00FFu;
-            if (w < wave) wbase += x;
-            total += x;
+            for (int i = 0; i < CPT / 2; i++) {
+                uint32_t m = mm[i];
+                while (m) {
+                    const uint32_t bit = __builtin_ctz(m);
+                    m &= m - 1;
+                    if (k < WCH) Ll[k] = (uint16_t)(span0 + 32u * i + bit + 1u);
+                    k++;
+                }
+            }
+            if (lane == 63) {
+                L_misc[4 + wave] = incl; L_misc[8 + wave] = packed;
+                if (incl > WCH) L_misc[2] = 1;
+            }
         }
-        const uint32_t excl = wbase + incl - cnt;
-        // ---------------- C: the tile's phase
+        TD_STAMP(2);   // B: masks, scan, vote, list
+        // ---------------- the pending line of the previous tile, the next tile's loads, the pending count
+        __builtin_amdgcn_s_setprio(3);
+        const uint32_t nit = it + gridDim.x;
+        bool phit = false;
+        uint32_t pcell = 0;
+        if (PIPE && pd_valid) { finish_pending(phit, pcell); pd_valid = false; }
+        TD_STAMP(3);   // pending line: wait for its bucket, compares
+        if (nit < nwork) fetch_tile(nit);
+        if (PIPE) {
+            if (hc_on) {
+                // (cache hits of this step, for the hit-rate watch: lanes whose cell is already cached)
+                const uint32_t h = hc_hash(pcell);
+                hc_hits += (uint32_t)__builtin_popcountll(__ballot(phit && hcS[h].x == pcell));
+            }
+            hc_commit(p.counts, hcS, hcE, phit, pcell, (uint32_t)lane, hc_on);
+        }
+        TD_STAMP(4);   // next tile's loads issued, pending count committed
+        lds_barrier();
+        TD_STAMP(5);   // barrier 1
+        __builtin_amdgcn_s_setprio(2);
+
+        // ---------------- C: the tile's phase and the waves' running totals
+        const uint4 tot4 = *reinterpret_cast<const uint4 *>(L_misc + 4), pk4 = *reinterpret_cast<const uint4 *>(L_misc + 8);
+        const uint4 flg4 = *reinterpret_cast<const uint4 *>(L_misc);
+        const uint32_t wb1 = tot4.x, wb2 = wb1 + tot4.y, wb3 = wb2 + tot4.z, total = wb3 + tot4.w;
         uint32_t r0;
-        if (predict) {
+        if (t != 0) {
+            auto rot = [](uint32_t pk, uint32_t by) { const uint32_t r = 8u * (by & 3u); return r ? ((pk << r) | (pk >> (32u - r))) : pk; };
+            const uint32_t a = pk4.x, b = rot(pk4.y, wb1), c = rot(pk4.z, wb2), d = rot(pk4.w, wb3);
+            const uint32_t v02 = (a & 0x00FF00FFu) + (b & 0x00FF00FFu) + (c & 0x00FF00FFu) + (d & 0x00FF00FFu);
+            const uint32_t v13 = ((a >> 8) & 0x00FF00FFu) + ((b >> 8) & 0x00FF00FFu) + ((c >> 8) & 0x00FF00FFu) + ((d >> 8) & 0x00FF00FFu);
             const uint32_t votes[4] = {v02 & 0xFFFFu, v13 & 0xFFFFu, v02 >> 16, v13 >> 16};
             uint32_t best = votes[0]; r0 = 0;
             if (votes[1] > best) { best = votes[1]; r0 = 1; }
@@ -425,51 +484,24 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         } else {
             r0 = (4u - (uint32_t)(first_line & 3)) & 3u;
         }
+        const bool tile_has_hi = flg4.y != 0;
         const uint32_t nwant = (total + 3u - r0) >> 2;
-        const bool regular = t != 0 && !tile_has_hi && !halo_has_hi && nwant <= (uint32_t)TILE_CH && tbase + TILE + halo <= p.nbytes;
+        const bool regular = t != 0 && (flg4.y | flg4.z | flg4.w) == 0 && tbase + TILE + halo <= p.nbytes;
         if (tid == 0)
             fp.tile_info[t] = total | (r0 << TI_R0_SHIFT) | (tile_has_hi ? TI_HI : 0u) | (regular ? 0u : TI_SKIP);
-        __builtin_amdgcn_s_setprio(2);
+        TD_STAMP(6);   // C: phase
 
-        // ---------------- D: wanted lines, compacted, matched
+        // ---------------- D: wanted line j follows the terminator with in-tile ordinal r0 + 4 j
         if (regular && !(p.dbg & DBG_NO_PHASE2)) {
-            const uint32_t lc = (r0 - excl) & 3u;
-            const uint32_t nw = cnt > lc ? (cnt - lc + 3u) >> 2 : 0u;
-            uint16_t *L_list = L_mask;
-            if (nw) {
-                uint32_t r = lc, kbase = 0, m = mm[0];
-#pragma unroll
-                for (int k = 0; k < CPT / 2 - 1; k++) {
-                    const uint32_t c = __builtin_popcount(mm[k]);
-                    const bool next = kbase == 32u * k && r >= c;
-                    if (next) { r -= c; kbase = 32u * (k + 1); m = mm[k + 1]; }
-                }
-                const uint32_t m1 = m & (m - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
-                const uint32_t sel = r == 0 ? m : r == 1 ? m1 : r == 2 ? m2 : m3;
-                const uint32_t w0 = span0 + kbase + (sel ? __builtin_ctz(sel) : 0u) + 1u;
-                const uint32_t slot0 = (excl + 3u - r0) >> 2;
-                L_list[slot0] = (uint16_t)w0;
-                if (__builtin_expect(nw > 1, 0)) {
-                    uint32_t li = 0;
-#pragma unroll
-                    for (int k = 0; k < CPT / 2; k++) {
-                        uint32_t mk = mm[k];
-                        while (mk) {
-                            const uint32_t bit = __builtin_ctz(mk);
-                            mk &= mk - 1;
-                            if (li > lc && ((li - lc) & 3u) == 0) L_list[slot0 + ((li - lc) >> 2)] = (uint16_t)(span0 + 32u * k + bit + 1u);
-                            li++;
-                        }
-                    }
-                }
-            }
-            lds_barrier();
             const uint32_t j0 = ((uint32_t)tid + 64u * (t & 3u)) & (uint32_t)(FBLOCK - 1);
 #pragma nounroll
             for (uint32_t j = j0; j < nwant; j += FBLOCK) {
-                const uint32_t srel = L_list[j];
-                // (a line that starts in the tile's last bytes and so has no terminator inside the tile is still
-                // whole in the staged window: the halo holds 16 * nch bytes)
+                const uint32_t o = r0 + 4u * j;
+                const uint32_t w = (o >= wb1 ? 1u : 0u) + (o >= wb2 ? 1u : 0u) + (o >= wb3 ? 1u : 0u);
+                const uint32_t wb = w == 0 ? 0u : w == 1 ? wb1 : w == 2 ? wb2 : wb3;
+                const uint32_t srel = L_mask[w * WCH + (o - wb)];
+                // (a line that starts in the tile's last bytes is still whole in the staged window: the halo
+                // holds 16 NQ bytes and more)
                 const uint32_t k = line_prepare<W, NQ>(p, cx, L_raw, srel, pd);
                 if (k == 1u) {
                     if (PIPE && j + FBLOCK >= nwant) pd_valid = true;
@@ -480,8 +512,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                         vm_settled();
                     }
                 } else if (__builtin_expect(k == 6u, 0)) {
-                    TileCtx cold = cx;
-                    const uint64_t res = match_line<W, ML_SLOW>(p, cold, tbase + srel, srel, true);
+                    const uint64_t res = match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true);
                     const uint32_t kind = (uint32_t)(res >> 62);
                     st_reads += 1;
                     if (kind >= 1) st_bar += 1;
@@ -498,17 +529,31 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        TD_STAMP(7);   // D: lines packed and matched up to the bucket loads (thread 0's share)
         if (tid == 0) { L_misc[1] = 0; L_misc[2] = 0; L_misc[3] = 0; }
-        if (use_cache && ++aged == HC_AGE_TILES) { aged = 0; hc_flush(p.counts, hcS, (uint32_t)lane); }
+        if (p.hot_cache && ++aged == HC_AGE_TILES) {
+            aged = 0;
+            if (hc_on) {
+                hc_flush(p.counts, hcS, (uint32_t)lane);
+                // a wave commits ~TILE / 4 / 300 hits a tile: below ~3 % of them cached, the cache is only overhead
+                if (hc_hits * 32u < HC_AGE_TILES * (TILE / 1200u)) { hc_on = false; hc_rest = HC_REST; }
+                hc_hits = 0;
+            } else if (--hc_rest == 0) hc_on = true;
+        }
         lds_barrier();                                    // LDS is reused by the next tile
+        TD_STAMP(8);   // end barrier (the other waves' matching)
         it = nit; t = nit;
     }
     if (PIPE && pd_valid) {
         bool h; uint32_t c;
         finish_pending(h, c);
-        hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, use_cache);
+        hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
     }
-    if (use_cache) hc_flush(p.counts, hcS, (uint32_t)lane);
+    if (p.hot_cache) hc_flush(p.counts, hcS, (uint32_t)lane);
+#ifdef TD_PHASE_PROF
+    if (tid == 0)
+        for (int i = 0; i < PROF_PHASES; i++) atomicAdd(p.stats + 8 + i, prof_acc[i]);
+#endif
 
     unsigned long long r = wave_sum64((unsigned long long)(long long)st_reads), b = wave_sum64((unsigned long long)(long long)st_bar),
                        g = wave_sum64((unsigned long long)(long long)st_tag);

@@ -52,7 +52,7 @@ constexpr int IPL = 4;                     // line starts examined per lane per 
 
 // timing-only ablation switches (td_set_option "debug_ablate")
 constexpr uint32_t DBG_NO_ATOMIC = 1, DBG_NO_PROBE = 2, DBG_NO_PHASE2 = 4, DBG_NO_LOOKBACK = 8,
-                   DBG_NO_PACK = 16, DBG_STATIC_TILES = 32;
+                   DBG_NO_PACK = 16, DBG_STATIC_TILES = 32, DBG_PROBE_16B = 64, DBG_NO_LINEPACK = 128, DBG_NO_COMPARE = 256;
 
 // device-side error bits (stats[ST_ERR])
 constexpr unsigned long long ERR_NONASCII = 1, ERR_SPIN = 2, ERR_TASSEL = 4;
@@ -71,7 +71,8 @@ struct KParams {
     // bucket by bucket (an entry shorter than the directory key is repeated in every bucket it covers)
     const uint32_t *bblob;
     uint32_t bblob_bytes, off_bmeta, off_bdir, off_bcand;
-    // tag hash table: buckets of 64 B (W<=3) or 128 B; dword 0 = overflow flag, then slots of
+    // tag hash table: buckets of 64 B (W<=3) or 128 B; dword 0 = which keys went on to the next bucket because this
+    // one was full (a 32-bit Bloom filter indexed by the top five bits of the key's hash), then slots of
     // {W x u64 packed bases, u32 meta = col<<10 | len}; empty slot: meta 0
     const uint4 *buckets;
     uint32_t bucket_mask;
@@ -448,9 +449,11 @@ __device__ __forceinline__ uint64_t match_stream(const KParams &p, const TileCtx
     pd.nr = min(nrem, 0x7FFFu) | (row << 16);      // (tags are at most 32 W <= 320 bases: the cap loses nothing)
     if (nrem >= p.m_bases && !(p.dbg & DBG_NO_PROBE)) {
         pd.nr |= PD_PROBE;
-        const uint32_t bk = hash_key(R[0] >> (64u - 2u * p.m_bases)) & p.bucket_mask;
+        const uint32_t hk = hash_key(R[0] >> (64u - 2u * p.m_bases));
+        const uint32_t bk = hk & p.bucket_mask;
         pd.boff = bk * (uint32_t)(BUCKET_U4_ * 16);         // (the table is far below 4 GiB: td_set_index checks)
         const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(p.buckets) + pd.boff);
+        pd.boff |= hk >> 27;                                // (low bits are free: the key's bit in the buckets' overflow filters)
 #pragma unroll
         for (int q = 0; q < BUCKET_U4_; q++) pd.b[q] = bp[q];   // in flight: first used by match_finish
     } else if (p.nshort == 0) {
@@ -512,7 +515,8 @@ __device__ __forceinline__ uint64_t match_finish(const KParams &p, const Pending
                     T[w] = ((uint64_t)raw[1 + sl * SLOT_DW + 2 * w + 1] << 32) | raw[1 + sl * SLOT_DW + 2 * w];
                 if (len != 0 && len <= nrem && prefix_eq(T, len)) { thit = true; col = meta2 >> 10; }
             }
-            if (__builtin_expect(thit || !(raw[0] & 1u) || ++probes > p.bucket_mask, 1)) break;   // found, or the bucket never overflowed
+            // found, or no key with this one's filter bit ever went on from this bucket
+            if (__builtin_expect(thit || !((raw[0] >> (pd.boff & 31u)) & 1u) || ++probes > p.bucket_mask, 1)) break;
             bk = (bk + 1) & p.bucket_mask;
             const uint4 *bp = p.buckets + (size_t)bk * BUCKET_U4;
 #pragma unroll

@@ -177,11 +177,11 @@ struct td_handle {
     // options
     int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1, nt_loads = 1;
     int kernel_gen = 2;                       // main pass of the free-running path: 2 = k_fast2 (lazy packing), 1 = k_fast
-    int tile_kb2 = 24;                        // k_fast2's tile (16 | 24 | 32 KiB)
+    int tile_kb2 = 0;                         // k_fast2's tile (16 | 24 | 32 KiB; 0 = fast2_auto_tile)
     int hot_cache = 1;                        // k_fast2: count through the per-wave hot-cell cache
     uint64_t fast_max_matrix = 1ull << 32;    // the free-running kernel addresses cells as base + 32-bit byte offset
     uint32_t debug_ablate = 0;
-    double table_load = 0.5;
+    double table_load = 0.25;
     int stagger = 0;
     int prio = 0xE4;            // wave priority per phase of the fast path: A 0, B-C 1, D 2, end of A 3 (kernel_fast.hpp set_prio)
     // timing
@@ -240,16 +240,29 @@ template <int CPT> FFn pick_fast2_c(int W, uint32_t nq) {
     }
 }
 FFn pick_fast2(int tile_kb, int W, uint32_t nq) {
-    return tile_kb == 32 ? pick_fast2_c<8>(W, nq) : pick_fast2_c<6>(W, nq);
+    return tile_kb == 32 ? pick_fast2_c<8>(W, nq) : tile_kb == 24 ? pick_fast2_c<6>(W, nq) : pick_fast2_c<4>(W, nq);
 }
 FFn pick_fix(int tile_kb, int W) {          // the fix-up pass shares the main pass's tile size
     if (tile_kb == 24) return pick_fast_w<6, true>(W);
     return pick_fast(tile_kb, W, true);
 }
+// k_fast2's tile: four workgroups must share a CU's 160 KiB of LDS (measured: three cost a fifth of the throughput),
+// so a large barcode index (many barcodes x several concrete cut sites) takes the smaller tile
+int fast2_auto_tile(const td_handle *h);
 size_t lds_bytes_fast2(const td_handle *h, int tile_kb) {
     // raw tile + halo | terminator masks (later the list of wanted line starts) | misc | hot-cell cache | barcode index
     const size_t tile = (size_t)tile_kb * 1024;
     return tile + h->halo + tile / 16 * 2 + 256 + 4 * tdk::HC_BYTES_PER_WAVE + h->bblob_bytes;
+}
+
+int fast2_auto_tile(const td_handle *h) {
+    // measured (profiles/r02_*): 24 KiB tiles with four workgroups per CU first; a barcode index too large for
+    // that (config 5: 384 barcodes x 2 concrete cut sites) does better with 32 KiB tiles at three workgroups
+    // than with 16 KiB tiles at four (a 16 KiB tile holds 75 reads of 100 bp: a second, nearly empty round of matching)
+    if (lds_bytes_fast2(h, 24) <= 160 * 1024 / 4) return 24;
+    if (lds_bytes_fast2(h, 32) <= 160 * 1024 / 3) return 32;
+    if (lds_bytes_fast2(h, 24) <= LDS_BUDGET) return 24;
+    return 16;
 }
 
 size_t lds_bytes_fast(const td_handle *h, int tile_kb) {
@@ -309,8 +322,9 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     const bool use_fast = h->fastpath && !tassel && !h->prescan && limit_far && counts32;
     // its main pass: k_fast2 (raw tile in LDS, lines packed by the lane that matches them) where the tag width has
     // the pipelined probe and the tile fits the LDS budget, else k_fast
-    const bool gen2 = use_fast && h->kernel_gen == 2 && h->W <= 3 && lds_bytes_fast2(h, h->tile_kb2) <= LDS_BUDGET;
-    const int tile_kb = tassel ? 16 : gen2 ? h->tile_kb2 : h->tile_kb;
+    const int tkb2 = h->tile_kb2 ? h->tile_kb2 : fast2_auto_tile(h);
+    const bool gen2 = use_fast && h->kernel_gen == 2 && h->W <= 3 && lds_bytes_fast2(h, tkb2) <= LDS_BUDGET;
+    const int tile_kb = tassel ? 16 : gen2 ? tkb2 : h->tile_kb;
     const uint64_t tile = (uint64_t)tile_kb * 1024;
     const uint64_t ntiles64 = (nbytes + tile - 1) / tile;
     if (ntiles64 > 0x7FFFFFFFull) return fail(TD_E_LIMIT, "buffer too large for one launch; split it");
@@ -590,7 +604,7 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
     uint32_t m = 32;
     if (lens.size() > MAX_SHORT) m = std::min<uint32_t>(32, lens[MAX_SHORT]);
     m = std::max<uint32_t>(m, 1);
-    // buckets: dword 0 = overflow flag, then SPB slots of {W x u64, u32 meta = col<<10 | len}
+    // buckets: dword 0 = overflow filter (kernels.hpp KParams::buckets), then SPB slots of {W x u64, u32 meta = col<<10 | len}
     if (ntags >= (1u << 22)) return fail(TD_E_LIMIT, "more than 4M tags");
     const int bucket_dw = W <= 3 ? 16 : 32;
     const int slot_dw = 2 * W + 1;
@@ -598,8 +612,10 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
     size_t nlong = 0;
     for (auto &t : rt.out) if (t.first.size() >= m) nlong++;
     size_t nbuckets = 16;
-    // load: at most half of the slots (measured: a denser, smaller table loses more to second
-    // fetches on full buckets than it gains in L2 hits)
+    // load: a quarter of the slots.  A key that found its bucket full sits in the next one, and a read that
+    // matches it costs a second, dependent fetch -- for its whole wave.  At half load 3.5 % of the keys are
+    // displaced and four waves in five take that path; at a quarter 0.3 % and one wave in six (measured at
+    // 384 x 100 k: 12.4 -> 11.6 ms; at an eighth 11.3 ms but 500 k tags lose what they gain to the larger table)
     while ((double)nbuckets * spb * h->table_load < (double)nlong) nbuckets <<= 1;
     if ((uint64_t)nbuckets * bucket_dw * 4 >= (1ull << 32)) return fail(TD_E_LIMIT, "tag table beyond 4 GiB");   // 32-bit bucket offsets
     std::vector<uint32_t> slots(nbuckets * bucket_dw, 0);
@@ -613,7 +629,8 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
             shorts.push_back(L); shorts.push_back(t.second);
             continue;
         }
-        size_t b = hash_key(words[0] >> (64 - 2 * m)) & (nbuckets - 1);
+        const uint32_t hk = hash_key(words[0] >> (64 - 2 * m));
+        size_t b = hk & (nbuckets - 1);
         for (;;) {
             uint32_t *bp = &slots[b * bucket_dw];
             int free_slot = -1;
@@ -624,7 +641,7 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
                 sp[2 * W] = (t.second << 10) | L;
                 break;
             }
-            bp[0] |= 1u;                      // full: lookups that miss here must go on
+            bp[0] |= 1u << (hk >> 27);        // full: lookups of keys with this filter bit that miss here must go on
             b = (b + 1) & (nbuckets - 1);
         }
     }
@@ -642,7 +659,7 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
     h->barnum = barnum; h->ntags = ntags;
     if (lds_bytes(h, 16) > LDS_BUDGET) return fail(TD_E_LIMIT, "barcode index does not fit the LDS budget");
     if (lds_bytes(h, h->tile_kb) > LDS_BUDGET) h->tile_kb = 16;
-    if (lds_bytes_fast2(h, h->tile_kb2) > LDS_BUDGET) h->tile_kb2 = 24;     // (beyond that too: k_fast takes over, launch_count)
+    if (h->tile_kb2 && lds_bytes_fast2(h, h->tile_kb2) > LDS_BUDGET) h->tile_kb2 = 0;     // (back to the automatic choice)
 
     rc = h->d_bblob.ensure(h->bblob_bytes / 4); if (rc) return rc;
     HIPCHK(hipMemcpy(h->d_bblob.p, blob.data(), h->bblob_bytes, hipMemcpyHostToDevice));
@@ -982,12 +999,12 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
         if (value != 1 && value != 2) return fail(TD_E_ARG, "kernel must be 1 (k_fast) or 2 (k_fast2)");
         h->kernel_gen = (int)value;
     } else if (n == "tile_kb2") {
-        if (value != 24 && value != 32) return fail(TD_E_ARG, "tile_kb2 must be 24 or 32");
-        if (h->have_index && lds_bytes_fast2(h, (int)value) > LDS_BUDGET) return fail(TD_E_LIMIT, "tile does not fit the LDS budget with this index");
+        if (value != 0 && value != 16 && value != 24 && value != 32) return fail(TD_E_ARG, "tile_kb2 must be 0 (automatic), 16, 24 or 32");
+        if (value && h->have_index && lds_bytes_fast2(h, (int)value) > LDS_BUDGET) return fail(TD_E_LIMIT, "tile does not fit the LDS budget with this index");
         h->tile_kb2 = (int)value;
     } else if (n == "hot_cache") h->hot_cache = value ? 1 : 0;
     else if (n == "stagger") h->stagger = (int)value;
-    else if (n == "prio") h->prio = (int)value & 255;
+    else if (n == "prio") h->prio = (int)value & 0xFFFF;
     else if (n == "table_load_pct") h->table_load = std::max<int64_t>(10, std::min<int64_t>(value, 95)) / 100.0;
     else if (n == "nt_loads") h->nt_loads = value ? 1 : 0;
     else if (n == "fast_max_matrix_bytes")      // (tests: force the switch to the exact kernel; 0 = the built-in 4 GiB)

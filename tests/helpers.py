@@ -14,11 +14,12 @@ from oracle import c_oracle
 KERNEL_MODES = [
     dict(fastpath=1, kernel=2, tile_kb2=24),
     dict(fastpath=1, kernel=2, tile_kb2=32),
+    dict(fastpath=1, kernel=2, tile_kb2=16),
     dict(fastpath=1, kernel=1, tile_kb=32),
     dict(fastpath=1, kernel=1, tile_kb=16),
     dict(fastpath=0, tile_kb=32),
 ]
-DEFAULT_MODE = dict(fastpath=1, kernel=2, tile_kb2=24, tile_kb=32)
+DEFAULT_MODE = dict(fastpath=1, kernel=2, tile_kb2=0, tile_kb=32)
 
 
 def apply_mode(eng, mode):

@@ -11,6 +11,8 @@ from tagdigger_amd.synth import SynthConfig
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 cfg = SynthConfig(nreads=reads, nbar=384, nmarkers=50_000, seed=3)
 eng = tagdigger_amd.Engine(0)
+for kv in os.environ.get('TD_OPTS', '').split():      # e.g. TD_OPTS='kernel=1 table_load_pct=25'
+    k, v = kv.split('='); eng.set_option(k, int(v))
 nb = cfg.nbytes()
 d = eng.dev_alloc(nb)
 cfg.fill_device(eng, d, 0, reads)

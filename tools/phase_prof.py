@@ -23,6 +23,11 @@ NAMES = ["loop head", "A: wait bytes + masks + pack", "barrier A", "B: scan + lo
          "  pending: wait for bucket", "  pending: compares", "-", "-"]
 
 
+NAMES2 = ["loop head", "A: wait bytes, raw + masks -> LDS (own quarter)", "B: masks, scan, vote, list", "  pending: wait bucket + compares",
+          "  next loads issued, pending commit", "barrier 1", "C: phase", "D: pack + match (thread 0)", "end barrier",
+          "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=50_000_000)
@@ -31,6 +36,9 @@ def main():
     ap.add_argument("--tile-kb", type=int, default=16)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--prescan", type=int, default=0)
+    ap.add_argument("--kernel", type=int, default=2)
+    ap.add_argument("--tile-kb2", type=int, default=24)
+    ap.add_argument("--opt", action="append", default=[])
     a = ap.parse_args()
     import tagdigger_amd
     from tagdigger_amd.synth import SynthConfig
@@ -41,6 +49,11 @@ def main():
     eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
     eng.set_option("tile_kb", a.tile_kb)
     eng.set_option("prescan", a.prescan)
+    eng.set_option("kernel", a.kernel)
+    eng.set_option("tile_kb2", a.tile_kb2)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v, 0))
     if a.blocks_per_cu:
         eng.set_option("blocks_per_cu", a.blocks_per_cu)
     eng.count_device(d, cfg.nbytes())       # warm
@@ -50,10 +63,11 @@ def main():
     ms, _ = eng.kernel_time_ms()
     c = list(eng.debug_counters()[:20]); c[11] = 0
     tot = float(sum(c[:20])) or 1.0
-    ntiles = (cfg.nbytes() + a.tile_kb * 1024 - 1) // (a.tile_kb * 1024)
-    print("tile_kb=%d blocks_per_cu=%s prescan=%d  kernel %.2f ms (stamped build)  tiles=%d" % (
-        a.tile_kb, a.blocks_per_cu or "auto", a.prescan, ms, ntiles))
-    for n, v in zip(NAMES, c):
+    tkb = a.tile_kb2 if a.kernel == 2 else a.tile_kb
+    ntiles = (cfg.nbytes() + tkb * 1024 - 1) // (tkb * 1024)
+    print("kernel=%d tile_kb=%d blocks_per_cu=%s prescan=%d  kernel %.2f ms (stamped build)  tiles=%d" % (
+        a.kernel, tkb, a.blocks_per_cu or "auto", a.prescan, ms, ntiles))
+    for n, v in zip(NAMES2 if a.kernel == 2 else NAMES, c):
         print("  %-24s %6.2f %%   %8.0f cycles/tile" % (n, 100.0 * v / tot, v / ntiles))
     print("  %-24s            %8.0f cycles/tile" % ("total", tot / ntiles))
     eng.dev_free(d)

@@ -9,6 +9,8 @@ import tagdigger_amd
 from tagdigger_amd.synth import SynthConfig
 
 eng = tagdigger_amd.Engine(0)
+for kv in os.environ.get('TD_OPTS', '').split():      # e.g. TD_OPTS='kernel=1 table_load_pct=25'
+    k, v = kv.split('='); eng.set_option(k, int(v))
 for read_len, body in ((36, 20), (50, 30), (75, 45), (100, 59), (150, 59), (250, 59)):
     nreads = int(4e9 // (2 * read_len + 19))
     cfg = SynthConfig(nreads=nreads, nbar=96, nmarkers=5000, seed=2, read_len=read_len, body=body)
