@@ -161,6 +161,14 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
 int td_get_counts(td_handle *h, uint64_t *out_rows_by_cols);   /* barnum*ntags, row-major */
 int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
 
+/* K3 of SURVEY 8e: add this library's barcode rows into the run's sample rows on the device --
+ * d_dst[row_of_barcode[b]][c] += counts[b][c] for the handle's barnum x ntags uint32 matrix (bound or internal);
+ * d_dst is n_dst_rows x ntags uint32 in device memory (e.g. the torch tensor that is all-reduced over RCCL
+ * afterwards).  This is what the reference's combineReadCounts (tagdigger_fun.py:1061-1098) does with Python lists
+ * after every file: rows whose sample name was seen before are summed.  row_of_barcode is a HOST array of barnum
+ * entries.  Synchronous; waits for the handle's own work first and reports what a kernel flagged. */
+int td_fold_rows(td_handle *h, const uint32_t *row_of_barcode, uint32_t n_dst_rows, void *d_dst, void *stream);
+
 /* ---- environment ------------------------------------------------------------
  * TAGDIG_STAGE_THREADS    host threads that copy / pread a piece into pinned memory (default 8, 1..16)
  * TAGDIG_INFLATE_THREADS  host threads for BGZF member-parallel and gzip chunk-parallel inflate (default: cores, at most 16)

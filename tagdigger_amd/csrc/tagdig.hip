@@ -173,6 +173,7 @@ struct td_handle {
     DevBuf<tdk::SplitEntry> d_sp_entries;
     DevBuf<uint8_t> d_sp_pool;
     DevBuf<uint4> d_fixlist;
+    DevBuf<uint32_t> d_rowmap;                // td_fold_rows: sample row of every barcode row
     uint32_t max_need = 0;                    // bases from a read's start that the matcher may look at
     // options
     int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1, nt_loads = 1;
@@ -555,7 +556,7 @@ void td_destroy(td_handle *h) {
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
-    h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release();
+    h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release(); h->d_rowmap.release();
     for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &sl : h->sp_slot) {
         if (sl.pin) (void)hipHostFree(sl.pin);
@@ -1074,6 +1075,53 @@ int td_device_sync(td_handle *h) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
     return TD_OK;
+}
+
+}  // extern "C"
+
+// ---- K3: barcode rows of one library -> sample rows of the run (reference combineReadCounts,
+// tagdigger_fun.py:1061-1098: equal sample names are summed, on the host there, here on the device so that the
+// matrix that is all-reduced over RCCL is the samples x tags one and nothing passes through host lists)
+namespace {
+__global__ __launch_bounds__(256) void k_fold_rows(const uint32_t *src, uint32_t barnum, uint32_t ncols, const uint32_t *row_of,
+                                                   uint32_t *dst) {
+    // one workgroup column-strip per source row: dst[row_of[b]][c] += src[b][c]; two barcodes of one library may
+    // carry the same sample name, so the additions are atomic (no-return, one per non-zero cell)
+    const uint32_t b = blockIdx.y;
+    const uint32_t *s = src + (size_t)b * ncols;
+    uint32_t *d = dst + (size_t)row_of[b] * ncols;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) {
+        const uint32_t v = s[c];
+        if (v) atomicAdd(d + c, v);
+    }
+    (void)barnum;
+}
+}  // namespace
+
+extern "C" {
+
+int td_fold_rows(td_handle *h, const uint32_t *row_of_barcode, uint32_t n_dst_rows, void *d_dst, void *stream) {
+    if (!h || !row_of_barcode || !d_dst) return fail(TD_E_ARG, "NULL argument");
+    if (!h->have_index) return fail(TD_E_STATE, "td_set_index has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->used64) return fail(TD_E_STATE, "td_fold_rows folds the uint32 matrix; tassel_tagcount weights are 64-bit");
+    for (uint64_t v : h->host_acc) if (v) return fail(TD_E_STATE, "counts were flushed to the host accumulator; fold them on the host");
+    for (uint32_t b = 0; b < h->barnum; b++)
+        if (row_of_barcode[b] >= n_dst_rows) return fail(TD_E_ARG, "row_of_barcode entry beyond n_dst_rows");
+    hipStream_t s = (hipStream_t)stream;
+    // every launch enqueued through this handle first (they may be on its own streams), and what they flagged
+    HIPCHK(hipStreamSynchronize(h->work_stream));
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    int rc = h->d_rowmap.ensure(h->barnum); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_rowmap.p, row_of_barcode, (size_t)h->barnum * 4, hipMemcpyHostToDevice, s));
+    const uint32_t *src = h->bound_counts ? h->bound_counts : h->d_counts.p;
+    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((h->ntags + 255) / 256, 64));
+    hipLaunchKernelGGL(k_fold_rows, dim3(gx, h->barnum), dim3(256), 0, s, src, h->barnum, h->ntags, h->d_rowmap.p, (uint32_t *)d_dst);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    unsigned long long st[TD_STAT_NSTATS];
+    HIPCHK(hipMemcpy(st, h->d_stats.p, sizeof(st), hipMemcpyDeviceToHost));
+    return check_device_errors(h, st);
 }
 
 }  // extern "C"

@@ -1,11 +1,16 @@
 """Several libraries across several GPUs: one process per GPU (torch.distributed; backend
 "nccl" is RCCL over xGMI on ROCm, "gloo" for CPU rehearsal), libraries dealt round-robin,
-one integer all-reduce of the samples x tags matrix at the end.
+ONE integer all-reduce of the samples x tags matrix at the end.
 
 The result equals `combineReadCounts` of the reference (tagdigger_fun.py:1061-1098) applied to
 the per-file matrices -- files in sorted order, samples in order of first appearance, equal
 sample names summed -- whatever the number of ranks, because integer addition is associative.
+
+On GPUs nothing passes through Python lists: every library is counted into the engine's device
+matrix, folded into the run's [samples x tags] uint32 DEVICE tensor by K3 (td_fold_rows), that
+tensor is all-reduced in place, and rank 0 copies it to the host once.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -23,28 +28,52 @@ def sample_rows(bckeys):
     return order, rows
 
 
-def count_libraries(bckeys, tags, cutsite, counter=None, device=None):
-    """Every rank calls this with the same arguments.  `counter(file, barcodes, tags, cutsite)`
-    returns the per-barcode matrix of one file (default: the GPU find_tags_fastq on this rank's
-    device).  Returns [sample names, samples x tags counts] on every rank."""
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
+def _rank_world():
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def count_libraries(bckeys, tags, cutsite, counter=None, device=None, maxreads=5e9, as_array=False):
+    """Every rank calls this with the same arguments.  Returns [sample names, samples x tags counts]
+    on every rank (counts: list of lists like the reference's, or an int64 numpy array with `as_array`).
+
+    counter=None (the product path): this rank's GPU (`device`: a torch.device or an index) counts its
+    libraries; barcode rows are folded into sample rows on the device (K3) and the [samples x tags] uint32
+    device tensor is all-reduced in place -- no host lists anywhere.
+    counter(file, barcodes, tags, cutsite) -> matrix: a stand-in for the per-file counter (the CPU rehearsal
+    of the sharding and the reduction in tests/test_multi_gloo.py passes the oracle); the matrices are folded
+    with numpy and reduced as an int64 host tensor."""
+    rank, world = _rank_world()
+    order, rows = sample_rows(bckeys)
+    files = sorted(bckeys.keys())
+    mine = [f for k, f in enumerate(files) if k % world == rank]
     if counter is None:
         from . import tagdigger_fun
-        dev_index = device.index if isinstance(device, torch.device) and device.index is not None else 0
-
-        def counter(f, barcodes, tgs, cs):
-            return tagdigger_fun.find_tags_fastq(f, barcodes, tgs, cutsite=cs, device=dev_index)
-    order, rows = sample_rows(bckeys)
-    total = torch.zeros((len(order), len(tags)), dtype=torch.int64, device=device if device is not None else "cpu")
-    for k, f in enumerate(sorted(bckeys.keys())):
-        if k % world != rank:
-            continue
-        m = torch.tensor(counter(f, bckeys[f][0], tags, cutsite), dtype=torch.int64).reshape(len(bckeys[f][0]), len(tags))
-        total.index_add_(0, torch.tensor(rows[f], dtype=torch.int64, device=total.device), m.to(total.device))
-    if world > 1:
-        dist.all_reduce(total, op=dist.ReduceOp.SUM)
-    return [order, total.cpu().tolist()]
+        if isinstance(device, torch.device):
+            dev = device if device.index is not None else torch.device("cuda", 0)
+        else:
+            dev = torch.device("cuda", int(device or 0))
+        eng = tagdigger_fun.default_engine(dev.index)
+        total = torch.zeros((len(order), len(tags)), dtype=torch.int32, device=dev)     # uint32 counts: bit pattern == int32's
+        torch.cuda.synchronize(dev)
+        for f in mine:
+            eng.set_index(bckeys[f][0], tags, cutsite)          # (kept when the barcode set repeats: only the counts are zeroed)
+            eng.count_file(f, maxreads)
+            eng.fold_rows(rows[f], total.data_ptr(), len(order))
+        if world > 1:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)        # the path's one exchange: RCCL over xGMI
+        out = total.cpu().numpy().view(np.uint32).astype(np.int64)
+    else:
+        total = np.zeros((len(order), len(tags)), dtype=np.int64)
+        for f in mine:
+            m = np.asarray(counter(f, bckeys[f][0], tags, cutsite), dtype=np.int64).reshape(len(bckeys[f][0]), len(tags))
+            np.add.at(total, rows[f], m)
+        if world > 1:
+            t = torch.from_numpy(total)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out = total
+    return [order, out if as_array else out.tolist()]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -86,7 +115,6 @@ def shard_bounds(path, world):
 
 def count_terminators(data):
     """Line terminators (\\n, \\r\\n, bare \\r) in a bytes-like object of whole lines."""
-    import numpy as np
     a = np.frombuffer(data, dtype=np.uint8)
     n = int((a == 0x0A).sum())
     cr = np.flatnonzero(a == 0x0D)
@@ -96,46 +124,67 @@ def count_terminators(data):
     return n
 
 
-def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, counter=None, device=None):
+def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, counter=None, device=None, as_array=False):
     """find_tags_fastq on one plain FASTQ file, byte-sharded over the ranks of the default process
     group (every rank calls this with the same arguments; backend "nccl" = RCCL for GPUs).
-    `counter(data, barcodes, tags, cutsite, first_line, maxreads)` returns one shard's matrix
-    (default: this rank's GPU).  Returns the whole file's matrix on every rank, bit-identical to the
-    single-GPU result for any number of ranks."""
+    Returns the whole file's matrix on every rank, bit-identical to the single-GPU result for any
+    number of ranks.
+
+    counter=None (the product path): the shard is read into pinned-able host memory once, copied to this
+    rank's GPU, its line terminators are counted THERE (td_count_lines_device), the counts are all-gathered
+    (-> this shard's first line index), the shard is counted in place with the global maxreads bound, and the
+    device matrix is all-reduced.
+    counter(data, barcodes, tags, cutsite, first_line, maxreads) -> matrix stands in for the GPU in the CPU
+    rehearsal."""
     import math
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank, world = _rank_world()
     if path[-2:].lower() == 'gz':
         raise ValueError("byte sharding needs an uncompressed file; split gzip input per library instead")
-    if counter is None:
-        from . import tagdigger_fun
-        dev_index = device.index if isinstance(device, torch.device) and device.index is not None else 0
-
-        def counter(data, bcs, tgs, cs, first_line, mreads):
-            eng = tagdigger_fun.default_engine(dev_index)
-            eng.set_index(bcs, tgs, cs)
-            eng.count_bytes(data, first_line=first_line, maxreads=mreads)
-            return eng.counts()
     start, end = shard_bounds(path, world)[rank]
-    with open(path, "rb") as fh:
-        fh.seek(start)
-        data = fh.read(end - start)
-    mine = torch.tensor([count_terminators(data)], dtype=torch.int64, device=device if device is not None else "cpu")
-    if world > 1:
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        first_line = int(sum(int(t[0]) for t in every[:rank]))
-    else:
-        first_line = 0
+    data = np.fromfile(path, dtype=np.uint8, count=end - start, offset=start)
     # The maxreads bound is global and so is the line index each shard is counted with: device and oracle
     # both compare the bound with the GLOBAL read ordinal (first_line + lines seen), so it is passed on
     # unchanged; a shard that starts at or past the bound is skipped.
     bound = max(1, int(math.ceil(min(maxreads, 2 ** 62))))
-    reads_before = (first_line + 2) // 4               # sequence lines (index 1 mod 4) below first_line
-    total = torch.zeros((len(barcodes), len(tags)), dtype=torch.int64, device=device if device is not None else "cpu")
-    if len(data) and reads_before < bound:
-        m = counter(data, barcodes, tags, cutsite, first_line, bound)
-        total += torch.tensor(m, dtype=torch.int64).reshape(len(barcodes), len(tags)).to(total.device)
-    if world > 1:
-        dist.all_reduce(total, op=dist.ReduceOp.SUM)
-    return total.cpu().tolist()
+
+    def first_line_of(my_terminators, where):
+        mine = torch.tensor([my_terminators], dtype=torch.int64, device=where)
+        if world == 1:
+            return 0
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return int(sum(int(t[0]) for t in every[:rank]))
+
+    if counter is None:
+        from . import tagdigger_fun
+        if isinstance(device, torch.device):
+            dev = device if device.index is not None else torch.device("cuda", 0)
+        else:
+            dev = torch.device("cuda", int(device or 0))
+        eng = tagdigger_fun.default_engine(dev.index)
+        eng.set_index(barcodes, tags, cutsite)
+        total = torch.zeros(len(barcodes) * len(tags), dtype=torch.int32, device=dev)
+        shard = torch.empty(max(16, data.size), dtype=torch.uint8, device=dev)         # (torch allocations are 256-byte aligned)
+        if data.size:
+            shard[:data.size].copy_(torch.from_numpy(data))
+        torch.cuda.synchronize(dev)
+        terms = eng.count_lines_device(shard.data_ptr(), int(data.size)) if data.size else 0
+        first_line = first_line_of(terms, dev)
+        eng.bind_counts(total.data_ptr())
+        try:
+            if data.size and (first_line + 2) // 4 < bound:
+                eng.count_device(shard.data_ptr(), int(data.size), first_line=first_line, maxreads=bound)
+            eng.stats()                                        # (synchronises; raises what a kernel flagged)
+        finally:
+            eng.bind_counts(0)
+        if world > 1:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        out = total.cpu().numpy().view(np.uint32).astype(np.int64).reshape(len(barcodes), len(tags))
+    else:
+        first_line = first_line_of(count_terminators(data), "cpu")
+        out = np.zeros((len(barcodes), len(tags)), dtype=np.int64)
+        if data.size and (first_line + 2) // 4 < bound:     # sequence lines (index 1 mod 4) below first_line: (first_line + 2) // 4
+            out += np.asarray(counter(data.tobytes(), barcodes, tags, cutsite, first_line, bound), dtype=np.int64).reshape(out.shape)
+        if world > 1:
+            dist.all_reduce(torch.from_numpy(out), op=dist.ReduceOp.SUM)
+    return out if as_array else out.tolist()

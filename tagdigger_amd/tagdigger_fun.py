@@ -14,7 +14,7 @@ enzymes = {'ApeKI': 'CWGC', 'EcoT22I': 'TGCAT', 'NcoI': 'CATGG',
 
 
 def find_tags_fastq(fqfile, barcodes, tags, cutsite="TGCAG", maxreads=5e9, tassel_tagcount=False,
-                    device=0):
+                    device=0, as_array=False):
     """Count barcode x tag combinations in one FASTQ file (plain or .gz by name).
 
     Returns list[list[int]] shaped [len(barcodes)][len(tags)], rows and columns
@@ -27,6 +27,8 @@ def find_tags_fastq(fqfile, barcodes, tags, cutsite="TGCAG", maxreads=5e9, tasse
     eng = default_engine(device)
     eng.set_index(barcodes, tags, cutsite)          # asserts + index, before the file is opened (:198-233)
     eng.count_file(fqfile, maxreads, tassel_tagcount)
+    if as_array:                                    # (this build only: the matrix as a numpy array, no Python lists)
+        return eng.counts_numpy(signed=bool(tassel_tagcount))
     return eng.counts(signed=bool(tassel_tagcount))
 
 
@@ -727,11 +729,25 @@ def sanitizeTags(taglist):
     return taglist
 
 
+def _is_array(x):
+    return type(x).__module__ == "numpy"
+
+
 def combineReadCounts(countsdict, bckeys):
     """Per-barcode rows of every library -> per-sample rows: files in sorted order, samples in
     order of first appearance, equal names summed (reference tagdigger_fun.py:1061-1098).
-    This is also what a multi-GPU run must equal after its all-reduce."""
+    This is also what a multi-GPU run must equal after its all-reduce.
+    Matrices given as numpy arrays (Engine.counts_numpy, what the command line uses) are summed with
+    numpy and the totals come back as one int64 array; lists give lists, as in the reference."""
     files = sorted(bckeys.keys())
+    if files and all(_is_array(countsdict[f]) for f in files):
+        import numpy as np
+        from .multi import sample_rows
+        order, rows = sample_rows(bckeys)
+        totals = np.zeros((len(order), countsdict[files[0]].shape[1]), dtype=np.int64)
+        for f in files:
+            np.add.at(totals, rows[f], countsdict[f].astype(np.int64, copy=False))
+        return [order, totals]
     order, totals = [], []
     slot = {}
     for f in files:
@@ -746,10 +762,35 @@ def combineReadCounts(countsdict, bckeys):
     return [order, totals]
 
 
+def _csv_cell(text):
+    """One field exactly as csv.writer (default dialect, minimal quoting) writes it."""
+    import io
+    buf = io.StringIO()
+    _csv.writer(buf).writerow([text])
+    return buf.getvalue()[:-2]                      # (without the row's \r\n)
+
+
 def writeCounts(filename, counts, samnames, tagnames):
-    """Samples x tags CSV, csv.writer defaults (CRLF rows) (reference tagdigger_fun.py:1100-1111)."""
+    """Samples x tags CSV, csv.writer defaults (CRLF rows) (reference tagdigger_fun.py:1100-1111).
+    A numpy matrix is written row by row with ndarray.tofile (decimal integers, the same bytes)."""
     assert len(samnames) == len(counts), "Length of samnames should be the same as length of counts."
     assert len(tagnames) == len(counts[0]), "Length of tagnames should be length of second dimension of counts."
+    if _is_array(counts):
+        import io
+        import locale
+        import numpy as np
+        enc = locale.getpreferredencoding(False)            # (what open(..., 'w') would encode with)
+        head = io.StringIO()
+        _csv.writer(head).writerow([""] + tagnames)
+        rows = np.ascontiguousarray(counts, dtype=np.int64)
+        with open(filename, mode='wb') as fb:
+            fb.write(head.getvalue().encode(enc))
+            for name, row in zip(samnames, rows):
+                fb.write((_csv_cell(name) + ",").encode(enc))
+                fb.flush()
+                row.tofile(fb, sep=",", format="%d")
+                fb.write(b"\r\n")
+        return
     with open(filename, mode='w', newline='') as fh:
         out = _csv.writer(fh)
         out.writerow([""] + tagnames)
@@ -783,14 +824,22 @@ def writeDiploidGeno(filename, counts, samnames, tagnames):
     try:
         if not all(set(a[0]) <= {'0', '1'} for a in alleles):
             raise Exception("All allele names must be '0' or '1'.")
-        rows = []
-        for s in range(len(samnames)):
-            calls = []
-            for a in alleles:
-                c0 = counts[s][a[1][a[0].index('0')]]
-                c1 = counts[s][a[1][a[0].index('1')]]
-                calls.append('1' if c0 > 0 and c1 > 0 else '0' if c0 > 0 else '2' if c1 > 0 else '')
-            rows.append(calls)
+        if _is_array(counts):
+            import numpy as np
+            i0 = np.array([a[1][a[0].index('0')] for a in alleles], dtype=np.int64)
+            i1 = np.array([a[1][a[0].index('1')] for a in alleles], dtype=np.int64)
+            has0, has1 = counts[:, i0] > 0, counts[:, i1] > 0
+            table = np.array(['', '0', '2', '1'])                  # neither, allele 0 only, allele 1 only, both
+            rows = table[has0 + 2 * has1].tolist()
+        else:
+            rows = []
+            for s in range(len(samnames)):
+                calls = []
+                for a in alleles:
+                    c0 = counts[s][a[1][a[0].index('0')]]
+                    c1 = counts[s][a[1][a[0].index('1')]]
+                    calls.append('1' if c0 > 0 and c1 > 0 else '0' if c0 > 0 else '2' if c1 > 0 else '')
+                rows.append(calls)
         with open(filename, mode='w', newline='') as fh:
             out = _csv.writer(fh)
             out.writerow([""] + markers)

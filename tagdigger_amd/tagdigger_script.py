@@ -53,6 +53,10 @@ def build_parser():
     ap.add_argument("-o", "--outputcounts", required=True, metavar="FILE", help="samples x tags CSV to write")
     ap.add_argument("-g", "--outputgen", metavar="FILE", help="0/1/2 genotype CSV to write (binary markers only)")
     ap.add_argument("--td-device", type=int, default=0, help="GPU to count on (this build only)")
+    ap.add_argument("--td-devices", metavar="LIST", help="several GPUs, e.g. 0,1,2,3: one process per GPU, the key file's "
+                    "libraries dealt over them, barcode rows folded into sample rows on the device and ONE all-reduce of the "
+                    "samples x tags matrix over RCCL (this build only; same output files)")
+    ap.add_argument("--td-timing", action="store_true", help="print where the wall time went, per stage (this build only)")
     return ap
 
 
@@ -94,6 +98,7 @@ def checked(value, what):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    clock = _Clock(args.td_timing)
     site = cut_site(args)
     if args.directory is not None:
         if not os.path.isdir(args.directory):
@@ -102,7 +107,9 @@ def main(argv=None):
     fmt = tag_format(args)
     keep = checked(tf.readMarkerNames(args.tokeep), "marker names to keep") if args.tokeep is not None else None
     tags = checked(TAG_FORMATS[fmt][1](args, keep, args.binaryOnly == "T"), "tags")
+    clock.lap("tag reader")
     names, sequences = tf.sanitizeTags(tags)
+    clock.lap("sanitizeTags")
     keys = checked(tf.readBarcodeKeyfile(args.barcodefile), "barcode file")
     libraries = sorted(keys)
     unreadable = [f for f in libraries if not tf.isFastq(f)]
@@ -112,13 +119,80 @@ def main(argv=None):
         raise Exception("Cannot read all FASTQ files.")
     if args.outputgen is not None and {n[-1] for n in names} != {"0", "1"}:
         raise Exception("Cannot output numeric genotypes for non-binary markers.")
-    per_file = {f: tf.find_tags_fastq(f, keys[f][0], sequences, cutsite=site, device=args.td_device)     # the hot path
-                for f in libraries}
+    clock.lap("checks")
+    devices = [int(d) for d in args.td_devices.split(",")] if args.td_devices else [args.td_device]
+    if len(devices) > 1:
+        # one process per GPU (reference loop :123-126 dealt over the ranks); rank 0 writes the files
+        import socket
+        import torch.multiprocessing as mp
+        if "MASTER_PORT" not in os.environ:             # (a free port for the ranks' rendezvous on this host)
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        mp.spawn(_rank_main, args=(devices, keys, sequences, site, names, args.outputcounts, args.outputgen),
+                 nprocs=len(devices), join=True)
+        clock.lap("count on %d GPUs + combine + write" % len(devices))
+        clock.report()
+        return 0
+    # the hot path; matrices stay numpy arrays from the device to the CSV writer (no Python lists of ints)
+    per_file = {}
+    for f in libraries:
+        per_file[f] = tf.find_tags_fastq(f, keys[f][0], sequences, cutsite=site, device=devices[0], as_array=True)
+    clock.lap("find_tags_fastq (index build + count + counts to host)")
     samples, counts = tf.combineReadCounts(per_file, keys)
+    clock.lap("combineReadCounts")
     tf.writeCounts(args.outputcounts, counts, samples, names)
+    clock.lap("writeCounts")
     if args.outputgen is not None:
         tf.writeDiploidGeno(args.outputgen, counts, samples, names)
+        clock.lap("writeDiploidGeno")
+    clock.report()
     return 0
+
+
+class _Clock:
+    """--td-timing: wall time per stage of the command (reference stages: readers, sanitizeTags, key file, the
+    per-file find_tags_fastq loop, combineReadCounts, the writers)."""
+    def __init__(self, on):
+        import time
+        self.on, self.now, self.t, self.laps = on, time.perf_counter, time.perf_counter(), []
+
+    def lap(self, what):
+        t = self.now()
+        self.laps.append((what, t - self.t))
+        self.t = t
+
+    def report(self):
+        if self.on:
+            for what, dt in self.laps:
+                print("[td-timing] %-58s %8.3f s" % (what, dt), file=sys.stderr)
+            print("[td-timing] %-58s %8.3f s" % ("total", sum(dt for _, dt in self.laps)), file=sys.stderr)
+
+
+def _rank_main(rank, devices, keys, sequences, site, names, outputcounts, outputgen):
+    """One rank of a --td-devices run: RCCL ("nccl") over distinct GPUs; the same GPU listed more than once is a
+    rehearsal of the code path over gloo."""
+    import torch
+    import torch.distributed as dist
+    from . import multi
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", devices[rank])
+    torch.cuda.set_device(dev)
+    distinct = len(set(devices)) == len(devices)
+    if distinct:
+        dist.init_process_group("nccl", rank=rank, world_size=len(devices), device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=len(devices))
+    try:
+        samples, counts = multi.count_libraries(keys, sequences, site, device=dev, as_array=True)
+        if rank == 0:
+            tf.writeCounts(outputcounts, counts, samples, names)
+            if outputgen is not None:
+                tf.writeDiploidGeno(outputgen, counts, samples, names)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -139,3 +139,61 @@ def test_two_ranks_shard_one_file(tmp_path, maxreads):
     out = str(tmp_path / "res.pt")
     mp.spawn(_shard_worker, args=(2, _free_port(), path, barcodes, tags, maxreads, out), nprocs=2, join=True)
     assert torch.load(out) == want
+
+
+# ---------------------------------------------------------------- the device-resident path (GPU box)
+def _device_worker(rank, world, port, bckeys, tags, out):
+    """count_libraries with the product's own counter: this rank's GPU counts, K3 folds on the device, the
+    [samples x tags] device tensor is all-reduced (gloo here: both ranks rehearse on GPU 0)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tagdigger_amd import multi
+    res = multi.count_libraries(bckeys, tags, "TGCAG", device=torch.device("cuda", 0))
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_device_path_equals_combine_read_counts(tmp_path):
+    from tagdigger_amd import multi, tagdigger_fun as tf
+    bckeys, tags = _make_inputs(str(tmp_path))
+    countsdict = {f: _oracle_counter(f, bckeys[f][0], tags, "TGCAG") for f in bckeys}
+    want = tf.combineReadCounts(countsdict, bckeys)
+    # one process: every library on GPU 0, folded on the device, no collective
+    assert multi.count_libraries(bckeys, tags, "TGCAG", device=0) == want
+    got = multi.count_libraries(bckeys, tags, "TGCAG", device=torch.device("cuda", 0), as_array=True)
+    assert got[0] == want[0] and got[1].tolist() == want[1]
+    # two ranks
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_device_worker, args=(2, _free_port(), bckeys, tags, out), nprocs=2, join=True)
+    assert torch.load(out) == want
+
+
+def _device_shard_worker(rank, world, port, path, barcodes, tags, maxreads, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tagdigger_amd import multi
+    res = multi.count_file_sharded(path, barcodes, tags, "TGCAG", maxreads=maxreads, device=torch.device("cuda", 0))
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maxreads", [5e9, 150, 300])
+def test_device_path_byte_sharded_file(tmp_path, maxreads):
+    """One file over two ranks, the shard's terminators counted on the device (td_count_lines_device), the global
+    maxreads bound applied in the shard it falls into."""
+    from oracle import c_oracle
+    from tagdigger_amd import multi
+    path, data, barcodes, tags = _dirty_file(tmp_path, "mixed", seed=11)
+    want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data, maxreads=maxreads).tolist()
+    assert multi.count_file_sharded(path, barcodes, tags, "TGCAG", maxreads=maxreads, device=0) == want
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_device_shard_worker, args=(2, _free_port(), path, barcodes, tags, maxreads, out), nprocs=2, join=True)
+    assert torch.load(out) == want

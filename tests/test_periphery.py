@@ -90,8 +90,12 @@ def test_cli_plumbing_with_oracle_counts(tmp_path, monkeypatch):
     """Everything around the hot path, byte for byte, with the CPU oracle standing in for the GPU."""
     from oracle import c_oracle
     from tagdigger_amd import tagdigger_fun as tf
-    monkeypatch.setattr(tf, "find_tags_fastq",
-                        lambda f, b, t, cutsite="TGCAG", device=0: c_oracle.find_tags_fastq(f, b, t, cutsite=cutsite))
+    import numpy as np
+
+    def oracle_counts(f, b, t, cutsite="TGCAG", device=0, as_array=False):
+        m = c_oracle.find_tags_fastq(f, b, t, cutsite=cutsite)
+        return np.array(m, dtype=np.uint64) if as_array else m
+    monkeypatch.setattr(tf, "find_tags_fastq", oracle_counts)
     d, stdout = _run_cli(tmp_path)
     assert open(os.path.join(d, "counts.csv"), "rb").read() == base64.b64decode(CLI["counts_csv_b64"])
     assert open(os.path.join(d, "geno.csv"), "rb").read() == base64.b64decode(CLI["geno_csv_b64"])
@@ -120,5 +124,20 @@ def test_cli_flag_rules():
 def test_cli_end_to_end_gpu(tmp_path):
     """The drop-in command line on an MI355X: counts.csv and geno.csv byte-identical to the reference's."""
     d, _ = _run_cli(tmp_path)
+    assert open(os.path.join(d, "counts.csv"), "rb").read() == base64.b64decode(CLI["counts_csv_b64"])
+    assert open(os.path.join(d, "geno.csv"), "rb").read() == base64.b64decode(CLI["geno_csv_b64"])
+
+
+@pytest.mark.gpu
+def test_cli_several_devices(tmp_path):
+    """--td-devices: one process per listed GPU (the same GPU twice here: the rehearsal form, over gloo), libraries
+    dealt over the ranks, K3 + one all-reduce of the samples x tags device matrix, rank 0 writes: same bytes."""
+    from tagdigger_amd import tagdigger_script
+    d = _stage_cli(tmp_path)
+    old = os.getcwd()
+    try:
+        tagdigger_script.main(CLI["argv"] + ["-w", d, "--td-devices", "0,0"])
+    finally:
+        os.chdir(old)
     assert open(os.path.join(d, "counts.csv"), "rb").read() == base64.b64decode(CLI["counts_csv_b64"])
     assert open(os.path.join(d, "geno.csv"), "rb").read() == base64.b64decode(CLI["geno_csv_b64"])
