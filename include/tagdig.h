@@ -149,6 +149,12 @@ int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, co
 int td_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line,
                     int32_t *d_out, uint64_t out_capacity, void *stream, uint64_t *n_terminators);
 
+/* Both per-read branches over one resident buffer (BASELINE config 5: counting + adapter trim): td_count_device's
+ * pass, then td_split_device's, enqueued on the same stream; arguments as theirs.  Synchronous. */
+int td_count_and_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line,
+                              uint64_t max_reads, int32_t *d_out, uint64_t out_capacity, void *stream,
+                              uint64_t *n_terminators);
+
 /* The whole loop on a file (plain or gzip by name, :1318-1321): out_paths[nbar] are created
  * (truncated) and receive the clipped records of their barcode; stops after max_reads records
  * (:1361-1362).  stats = reads, reads with barcode+cut site, reads clipped on the 3' end (:1359). */

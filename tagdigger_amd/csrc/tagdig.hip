@@ -1578,6 +1578,19 @@ int td_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t
     return check_device_errors(h, st);
 }
 
+int td_count_and_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, uint64_t max_reads,
+                              int32_t *d_out, uint64_t out_capacity, void *stream, uint64_t *n_terminators) {
+    // BASELINE config 5: the counting path and the adapter-trim branch over ONE buffer resident in HBM -- the count
+    // pass is enqueued, the splitter's line prefix and decisions follow it on the same stream (the bytes are still
+    // in the Infinity Cache for buffers that fit it); one synchronisation at the end
+    if (!h || !d_out) return fail(TD_E_ARG, "NULL argument");
+    if (!h->have_splitter) return fail(TD_E_STATE, "td_set_splitter has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = launch_count(h, d_fastq, nbytes, first_line, max_reads, 0, (hipStream_t)stream);
+    if (rc) return rc;
+    return td_split_device(h, d_fastq, nbytes, first_line, d_out, out_capacity, stream, n_terminators);
+}
+
 int td_split_file(td_handle *h, const char *in_path, const char *const *out_paths, uint64_t max_reads, uint64_t stats[3]) {
     if (!h || !in_path || !out_paths) return fail(TD_E_ARG, "NULL argument");
     if (!h->have_splitter) return fail(TD_E_STATE, "td_set_splitter has not been called");

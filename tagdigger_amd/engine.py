@@ -192,6 +192,21 @@ class Engine:
         # lines of the buffer: one per terminator, plus an unterminated last line (the caller knows)
         return np.frombuffer(raw, dtype=np.int32).reshape(-1, 2), terms.value
 
+    def count_and_split_device(self, d_ptr, nbytes, first_line=0, maxreads=5e9, stream=0):
+        """Counting and the splitter's per-read decisions over ONE buffer in HBM (BASELINE config 5); the counts land
+        in the engine's matrix, the decisions come back as split_device's."""
+        import numpy as np
+        cap = (self.count_lines_device(d_ptr, nbytes, stream) + 1) // 4 + 2
+        d_out = self.dev_alloc(cap * 8)
+        try:
+            terms = C.c_uint64(0)
+            B.check(self._L.td_count_and_split_device(self._h, C.c_void_p(d_ptr), nbytes, first_line, effective_maxreads(maxreads),
+                                                      C.c_void_p(d_out), cap, C.c_void_p(stream) if stream else None, C.byref(terms)))
+            raw = self.d2h(d_out, cap * 8)
+        finally:
+            self.dev_free(d_out)
+        return np.frombuffer(raw, dtype=np.int32).reshape(-1, 2), terms.value
+
     def split_file(self, in_path, out_paths, maxreads=500000000):
         """The record loop of barcodeSplitter (tagdigger_fun.py:1318-1368); returns (reads, with
         barcode and cut site, clipped on the 3' end)."""
