@@ -292,7 +292,7 @@ def main():
                        "fastq_bytes_per_gpu": nbytes, "sharding": sharding},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "tdk::k_fast (+k_resolve, fix-up pass)", "kernel_ms": kms,
+                         "kernel": "tdk::k_fast2 main pass + k_resolve + k_fast fix-up pass (HIP events around the three)", "kernel_ms": kms,
                          "kernel_ms_min": min(ktimes) if ktimes else None, "kernel_ms_max": max(ktimes) if ktimes else None,
                          "fixup_queue": fixups, "kernel_launches": len(ktimes),
                          "algorithmic_bytes_per_launch": algo_bytes},
@@ -458,7 +458,7 @@ def tiers(eng, cfg, reads):
         os.unlink(gzp)
         bz = os.path.join(tmp, "tiers_lib.bgzf.fq.gz")
         with open(bz, "wb") as fh:
-            fh.write(bgzf_bytes(part, level=1))
+            fh.write(bgzf_bytes(part, level=1, threads=16))
         r = timed(lambda: eng.count_file(bz), nz, wz)
         r["reads"] = nz
         r["gz_bytes"] = os.path.getsize(bz)

@@ -9,10 +9,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -36,10 +39,53 @@ struct GzSource {
     uint8_t *map = nullptr;
     size_t map_len = 0;
     bool use_fi = false;
-    FILE *bf = nullptr;         // BGZF
+    bool bgzf = false;          // BGZF: members located in the mapping of the file, inflated by a pool that lives as long as the source
+    size_t bpos = 0, bsize = 0; //       next member / size of the file
     int threads = 1;
-    std::vector<uint8_t> comp;  // compressed bytes of the request being served
     std::vector<uint8_t> spill; // a member that did not fit the caller's buffer, handed out in parts
+
+    // worker threads for the BGZF members of one request after another (created once: a request is 32 MiB, a
+    // millisecond of work for thirty threads -- creating them per request costs as much again)
+    struct Pool {
+        std::vector<std::thread> th;
+        std::mutex mu;
+        std::condition_variable cv;
+        uint64_t gen = 0;
+        uint32_t running = 0;
+        bool quit = false;
+        std::function<void()> job;
+        void start(int n) {
+            for (int t = 0; t < n; t++)
+                th.emplace_back([this]() {
+                    uint64_t seen = 0;
+                    for (;;) {
+                        std::function<void()> j;
+                        {
+                            std::unique_lock<std::mutex> g(mu);
+                            cv.wait(g, [&]() { return quit || gen != seen; });
+                            if (quit) return;
+                            seen = gen; j = job;
+                        }
+                        j();
+                        { std::lock_guard<std::mutex> g(mu); running--; }
+                        cv.notify_all();
+                    }
+                });
+        }
+        void run(const std::function<void()> &j) {        // on every worker and on the caller; returns when all are done
+            { std::lock_guard<std::mutex> g(mu); job = j; running = (uint32_t)th.size(); gen++; }
+            cv.notify_all();
+            j();
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&]() { return running == 0; });
+        }
+        void stop() {
+            { std::lock_guard<std::mutex> g(mu); quit = true; }
+            cv.notify_all();
+            for (auto &t : th) t.join();
+            th.clear(); quit = false;
+        }
+    } pool;
     size_t spill_pos = 0;
     bool bad = false;
 
@@ -67,12 +113,12 @@ struct GzSource {
         uint32_t bs = 0, hs = 0;
         const char *env = getenv("TAGDIG_INFLATE_THREADS");
         int want = env ? atoi(env) : (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
-        if (want > 1 && bgzf_header(head, n, &bs, &hs)) {
-            rewind(f);
-            bf = f; threads = want;
+        fclose(f);
+        if (want > 1 && bgzf_header(head, n, &bs, &hs) && map_only(path)) {
+            bgzf = true; bpos = 0; threads = want;
+            pool.start(want - 1);
             return true;
         }
-        fclose(f);
         if (!getenv("TAGDIG_ZLIB") && map_file(path, want)) return true;
         zf = gzopen(path, "rb");
         if (zf) gzbuffer(zf, 1 << 20);
@@ -80,7 +126,7 @@ struct GzSource {
     }
     // the file followed by at least FastInflate::PAD readable zero bytes: an anonymous mapping one
     // page longer than the file, the file mapped over its beginning
-    bool map_file(const char *path, int want_threads) {
+    bool map_only(const char *path) {
         const int fd = ::open(path, O_RDONLY);
         if (fd < 0) return false;
         struct stat sb;
@@ -94,7 +140,12 @@ struct GzSource {
         ::close(fd);
         if (over == MAP_FAILED) { munmap(base, total); return false; }
         (void)madvise(base, n, MADV_SEQUENTIAL);
-        map = (uint8_t *)base; map_len = total;
+        map = (uint8_t *)base; map_len = total; bsize = n;
+        return true;
+    }
+    bool map_file(const char *path, int want_threads) {
+        if (!map_only(path)) return false;
+        const size_t n = bsize;
         // chunk-parallel above 8 MiB of compressed data (TAGDIG_PAR_INFLATE=1: always, =0: never)
         const char *par = getenv("TAGDIG_PAR_INFLATE");
         if (want_threads > 1 && (par ? atoi(par) > 0 : n >= ((size_t)8 << 20))) {
@@ -109,10 +160,10 @@ struct GzSource {
     }
     void close() {
         pi.close();
+        if (bgzf) pool.stop();
         if (zf) gzclose(zf);
-        if (bf) fclose(bf);
         if (map) munmap(map, map_len);
-        zf = nullptr; bf = nullptr; map = nullptr; use_fi = false; use_pi = false;
+        zf = nullptr; bgzf = false; map = nullptr; use_fi = false; use_pi = false;
     }
     ~GzSource() { close(); }
 
@@ -121,89 +172,74 @@ struct GzSource {
         if (use_pi) return pi.read(dst, want);
         if (use_fi) return fi.read(dst, want);
         if (zf) return gzread(zf, dst, (unsigned)std::min<size_t>(want, 1u << 30));
-        if (bad) return -1;
+        if (bad || !bgzf) return -1;
         if (spill_pos < spill.size()) {
             const size_t n = std::min(want, spill.size() - spill_pos);
             memcpy(dst, spill.data() + spill_pos, n);
             spill_pos += n;
             return (long)n;
         }
-        struct Member { size_t in_off, in_len, out_off; uint32_t out_len, crc; size_t at, size; };   // at/size: the whole member
+        struct Member { size_t at, size, hs, out_off; uint32_t out_len, crc; };   // at/size: the whole member in the mapping
         std::vector<Member> mem;
-        comp.clear();
         size_t out_total = 0;
-        for (;;) {
-            uint8_t head[18];
-            const long at = ftell(bf);
-            const size_t n = fread(head, 1, sizeof(head), bf);
-            if (n == 0) break;                                         // end of file
+        while (bpos < bsize) {
             uint32_t bs = 0, hs = 0;
-            if (!bgzf_header(head, n, &bs, &hs) || hs > 18 || bs < hs + 8) { bad = true; return -1; }
-            const size_t base = comp.size();
-            comp.resize(base + bs);
-            memcpy(comp.data() + base, head, n);
-            if (fread(comp.data() + base + n, 1, bs - n, bf) != bs - n) { bad = true; return -1; }
-            const uint8_t *tail = comp.data() + base + bs - 8;
+            if (!bgzf_header(map + bpos, bsize - bpos, &bs, &hs) || bs < hs + 8 || bpos + bs > bsize) { bad = true; return -1; }
+            const uint8_t *tail = map + bpos + bs - 8;
             const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
             const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
             if (out_total + isize > want) {                            // does not fit any more
-                if (!mem.empty()) { comp.resize(base); fseek(bf, at, SEEK_SET); break; }     // next request
+                if (!mem.empty()) break;                                   // next request
                 // not even one member fits: inflate it aside and hand it out in parts
                 spill.assign(isize, 0); spill_pos = 0;
                 z_stream zs;
                 memset(&zs, 0, sizeof(zs));
                 if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return -1; }
-                zs.next_in = comp.data() + base + hs; zs.avail_in = (uInt)(bs - hs - 8);
+                zs.next_in = map + bpos + hs; zs.avail_in = (uInt)(bs - hs - 8);
                 zs.next_out = spill.data(); zs.avail_out = isize;
                 const int r = inflate(&zs, Z_FINISH);
                 inflateEnd(&zs);
                 if (r != Z_STREAM_END || zs.avail_out != 0 ||
                     (uint32_t)crc32(crc32(0L, Z_NULL, 0), spill.data(), isize) != crc) { bad = true; return -1; }
-                comp.clear();
+                bpos += bs;
                 return read(dst, want);
             }
-            mem.push_back({base + hs, (size_t)bs - hs - 8, out_total, isize, crc, base, (size_t)bs});
+            mem.push_back({bpos, (size_t)bs, (size_t)hs, out_total, isize, crc});
             out_total += isize;
+            bpos += bs;
         }
         if (mem.empty()) return 0;
-        comp.resize(comp.size() + FastInflate::PAD, 0);              // (the decoder may read that far past a member)
         std::atomic<size_t> next{0};
         std::atomic<bool> failed{false};
         const bool own_decoder = !getenv("TAGDIG_ZLIB");
-        auto work_fast = [&]() {                                      // every member is a complete gzip member
-            FastInflate dec;
-            for (;;) {
-                const size_t k = next.fetch_add(1);
-                if (k >= mem.size() || failed) break;
-                const Member &m = mem[k];
-                dec.open(comp.data() + m.at, m.size);
-                uint8_t extra;
-                if (dec.read(dst + m.out_off, m.out_len) != (long)m.out_len || dec.read(&extra, 1) != 0) { failed = true; break; }
-            }
-        };
+        // members are claimed in runs of eight (neighbours in the file and in the destination)
         auto work = [&]() {
-            if (own_decoder) { work_fast(); return; }
+            FastInflate dec;
             z_stream zs;
             memset(&zs, 0, sizeof(zs));
-            if (inflateInit2(&zs, -15) != Z_OK) { failed = true; return; }
+            if (!own_decoder && inflateInit2(&zs, -15) != Z_OK) { failed = true; return; }
             for (;;) {
-                const size_t k = next.fetch_add(1);
-                if (k >= mem.size() || failed) break;
-                const Member &m = mem[k];
-                inflateReset(&zs);
-                zs.next_in = comp.data() + m.in_off; zs.avail_in = (uInt)m.in_len;
-                zs.next_out = dst + m.out_off; zs.avail_out = m.out_len;
-                const int r = m.out_len || m.in_len ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
-                if (r != Z_STREAM_END || zs.avail_out != 0 ||
-                    (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst + m.out_off, m.out_len) != m.crc) { failed = true; break; }
+                const size_t k0 = next.fetch_add(8);
+                if (k0 >= mem.size() || failed) break;
+                for (size_t k = k0; k < std::min(mem.size(), k0 + 8); k++) {
+                    const Member &m = mem[k];
+                    if (own_decoder) {                                     // every member is a complete gzip member
+                        dec.open(map + m.at, m.size);
+                        uint8_t extra;
+                        if (dec.read(dst + m.out_off, m.out_len) != (long)m.out_len || dec.read(&extra, 1) != 0) { failed = true; break; }
+                    } else {
+                        inflateReset(&zs);
+                        zs.next_in = map + m.at + m.hs; zs.avail_in = (uInt)(m.size - m.hs - 8);
+                        zs.next_out = dst + m.out_off; zs.avail_out = m.out_len;
+                        const int r = m.out_len || zs.avail_in ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
+                        if (r != Z_STREAM_END || zs.avail_out != 0 ||
+                            (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst + m.out_off, m.out_len) != m.crc) { failed = true; break; }
+                    }
+                }
             }
-            inflateEnd(&zs);
+            if (!own_decoder) inflateEnd(&zs);
         };
-        const int nt = (int)std::min<size_t>((size_t)threads, mem.size());
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
+        pool.run(work);
         if (failed) { bad = true; return -1; }
         return (long)out_total;
     }

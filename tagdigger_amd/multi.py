@@ -15,17 +15,7 @@ import torch
 import torch.distributed as dist
 
 
-def sample_rows(bckeys):
-    """Global sample order exactly as combineReadCounts builds it, and per file the row of each barcode."""
-    order, slot, rows = [], {}, {}
-    for f in sorted(bckeys.keys()):
-        rows[f] = []
-        for sample in bckeys[f][1]:
-            if sample not in slot:
-                slot[sample] = len(order)
-                order.append(sample)
-            rows[f].append(slot[sample])
-    return order, rows
+from .tagdigger_fun import sample_rows  # noqa: F401  (the sample order combineReadCounts builds; re-exported)
 
 
 def _rank_world():

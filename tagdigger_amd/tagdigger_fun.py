@@ -733,6 +733,19 @@ def _is_array(x):
     return type(x).__module__ == "numpy"
 
 
+def sample_rows(bckeys):
+    """Global sample order exactly as combineReadCounts builds it, and per file the row of each barcode."""
+    order, slot, rows = [], {}, {}
+    for f in sorted(bckeys.keys()):
+        rows[f] = []
+        for sample in bckeys[f][1]:
+            if sample not in slot:
+                slot[sample] = len(order)
+                order.append(sample)
+            rows[f].append(slot[sample])
+    return order, rows
+
+
 def combineReadCounts(countsdict, bckeys):
     """Per-barcode rows of every library -> per-sample rows: files in sorted order, samples in
     order of first appearance, equal names summed (reference tagdigger_fun.py:1061-1098).
@@ -742,7 +755,6 @@ def combineReadCounts(countsdict, bckeys):
     files = sorted(bckeys.keys())
     if files and all(_is_array(countsdict[f]) for f in files):
         import numpy as np
-        from .multi import sample_rows
         order, rows = sample_rows(bckeys)
         totals = np.zeros((len(order), countsdict[files[0]].shape[1]), dtype=np.int64)
         for f in files:
