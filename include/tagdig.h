@@ -175,6 +175,11 @@ int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
  * entries.  Synchronous; waits for the handle's own work first and reports what a kernel flagged. */
 int td_fold_rows(td_handle *h, const uint32_t *row_of_barcode, uint32_t n_dst_rows, void *d_dst, void *stream);
 
+/* Host helper of the CSV writers: vals[0..n) as decimal integers separated by commas (what csv.writer writes for a
+ * row of ints, reference writeCounts tagdigger_fun.py:1100-1111) into out[0..capacity); returns the bytes written,
+ * -1 when they do not fit (24 bytes per value always do). */
+int64_t td_format_csv_row(const int64_t *vals, uint64_t n, char *out, uint64_t capacity);
+
 /* ---- environment ------------------------------------------------------------
  * TAGDIG_STAGE_THREADS    host threads that copy / pread a piece into pinned memory (default 8, 1..16)
  * TAGDIG_INFLATE_THREADS  host threads for BGZF member-parallel and gzip chunk-parallel inflate (default: cores, at most 16)
@@ -201,6 +206,8 @@ int td_fold_rows(td_handle *h, const uint32_t *row_of_barcode, uint32_t n_dst_ro
  *                    lane that matches them, hot-cell cache (kernel_fast2.hpp); 1 k_fast (kernel_fast.hpp)
  *   "tile_kb2"       k_fast2's tile: 0 (default: chosen from the barcode index's LDS footprint) | 16 | 24 | 32
  *   "hot_cache"      1 (default): k_fast2 counts through its per-wave cache of hot cells in LDS
+ *   "run"            consecutive tiles a workgroup of k_fast2 takes per turn (default 8): the line phase is carried
+ *                    inside a run, only its first tile votes
  *   "stagger"        start-up stagger of co-resident workgroups, in 4096-cycle units (default 0)
  *   "timing"         1: record HIP events around every launch for td_kernel_time_ms
  *   "fast_max_matrix_bytes"  count matrices of this many bytes and more go to the exact kernel (the

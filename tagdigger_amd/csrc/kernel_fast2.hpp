@@ -35,7 +35,7 @@ constexpr uint32_t HC_REST = 15;                // ageing periods a wave leaves 
 constexpr uint32_t HC_BYTES_PER_WAVE = HC_SLOTS * 8 + HC_SLOTS;
 
 __device__ __forceinline__ uint32_t hc_hash(uint32_t cell) {
-    return (((cell & 0xFFFFFFu) * 0x9E3779u) >> 13) & (uint32_t)(HC_SLOTS - 1);     // v_mul_u32_u24: full rate
+    return (__umul24(cell, 0x9E3779u) >> 13) & (uint32_t)(HC_SLOTS - 1);          // v_mul_u32_u24: full rate
 }
 
 // One count per lane with `hit`, through the wave's hot-cell cache (S: HC_SLOTS x {cell, count}, E: one byte
@@ -97,19 +97,18 @@ __device__ __forceinline__ uint32_t eq_mask16_ascii(const uint4 &v, uint32_t c4,
 // codes (16 bases, first base in the top bits) and invalid flags (bit k = byte k is not a base) of 16 ASCII bytes
 __device__ __forceinline__ uint2 pack16_ascii(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
     const uint32_t x[4] = {x0, x1, x2, x3};
-    uint32_t cw = 0, ihi = 0, ilo = 0;
+    uint32_t c[4], f[4];
+    // (four independent chains: a dot product that feeds the next one costs wait states)
 #pragma unroll
     for (int d = 0; d < 4; d++) {
         const uint32_t code = (x[d] >> 1) & 0x03030303u;
         const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, code);
         const uint32_t nz = (((x[d] & 0xDFDFDFDFu) ^ expect) + 0x7F7F7F7Fu) & 0x80808080u;   // 0x80 where the byte is not a base
-        cw = udot4(code, 0x01041040u, cw << 8);
-        if (d == 0) ilo = udot4(nz, 0x08040201u, 0u);
-        else if (d == 1) ilo = udot4(nz, 0x80402010u, ilo);
-        else if (d == 2) ihi = udot4(nz, 0x08040201u, 0u);
-        else ihi = udot4(nz, 0x80402010u, ihi);
+        c[d] = udot4(code, 0x01041040u, 0u);                                 // four codes = 8 bits
+        f[d] = udot4(nz, (d & 1) ? 0x80402010u : 0x08040201u, 0u);           // 128 x (four flags in bits 0-3 or 4-7)
     }
-    return make_uint2(cw, (ihi << 1) | (ilo >> 7));
+    const uint32_t cw = (((c[0] << 8) | c[1]) << 16) | (c[2] << 8) | c[3];
+    return make_uint2(cw, (((f[2] | f[3]) << 1) | ((f[0] | f[1]) >> 7)));
 }
 
 // 16 bytes of LDS at any byte offset
@@ -136,17 +135,17 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
     const uint8_t *src = L_raw + srel;
     uint4 q[NQ];
 #pragma unroll
-    for (int i = 0; i < NQ; i++) q[i] = (p.dbg & DBG_NO_LINEPACK) && i > 1 ? q[1] : lds_read16(src + 16 * i);
+    for (int i = 0; i < NQ; i++) q[i] = lds_read16(src + 16 * i);
     const uint32_t first = q[0].x & 0xFFu;
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
-        const uint2 e = (p.dbg & DBG_NO_LINEPACK) && i > 1 ? make_uint2(S[1], 0u) : pack16_ascii(q[i].x, q[i].y, q[i].z, q[i].w);
+        const uint2 e = pack16_ascii(q[i].x, q[i].y, q[i].z, q[i].w);
         S[i] = e.x;
         if (i & 1) inv[i >> 1] |= e.y << 16; else inv[i >> 1] |= e.y;
     }
 #pragma unroll
     for (int i = NQ; i < NQ + 4; i++) S[i] = 0;
-    if (NQ & 1) inv[NQ >> 1] |= 0xFFFF0000u;
+    if constexpr ((NQ & 1) != 0) inv[NQ >> 1] |= 0xFFFF0000u;
     if (inv[0] & 1u) return is_blank(first) ? 6u : 0u;      // the first byte is no base: blanks to strip, or no match
     uint32_t nvalid = 0;
     {
@@ -203,14 +202,8 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
         pd.boff = bk * (uint32_t)(BUCKET_U4_ * 16);
         const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(p.buckets) + pd.boff);
         pd.boff |= hk >> 27;                                // (the key's bit in the buckets' overflow filters)
-        if (p.dbg & DBG_PROBE_16B) {
-            pd.b[0] = bp[0];
 #pragma unroll
-            for (int q = 1; q < BUCKET_U4_; q++) pd.b[q] = make_uint4(0u, 0u, 0u, 0u);
-        } else {
-#pragma unroll
-            for (int q = 0; q < BUCKET_U4_; q++) pd.b[q] = bp[q];   // in flight: first used by match_finish
-        }
+        for (int q = 0; q < BUCKET_U4_; q++) pd.b[q] = bp[q];   // in flight: first used by match_finish
     } else if (p.nshort == 0) {
         return 2u;
     }
@@ -301,7 +294,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
     // one wanted line finished: statistics, and whether / where to count
     auto finish_pending = [&](bool &hit, uint32_t &cell) {
         vm_settled();
-        const uint64_t res = (p.dbg & DBG_NO_COMPARE) ? (R_TAG | (uint64_t)(pd.b[0].y & 0xFFFFFu)) : match_finish<W>(p, pd);
+        const uint64_t res = match_finish<W>(p, pd);
         const uint32_t kind = (uint32_t)(res >> 62);
         st_reads += 1;
         if (kind >= 1) st_bar += 1;
@@ -314,11 +307,17 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
     unsigned long long prof_acc[PROF_PHASES] = {};
     unsigned long long prof_last = __builtin_amdgcn_s_memtime();
 #endif
-    uint32_t it = blockIdx.x, t = it, aged = 0;
-    if (it < nwork) fetch_tile(t);
+    // Tiles are dealt to the workgroups in RUNS of p.run consecutive tiles (run r of the buffer goes to workgroup
+    // r mod gridDim): inside a run the line phase is CARRIED from tile to tile -- exact given the run's first tile --
+    // and only the first tile of a run votes (k_resolve checks every tile's phase all the same).
+    const uint32_t RUN = p.run ? p.run : 1u;
+    uint32_t run_pos = 0;                                  // position inside the current run
+    uint32_t t = blockIdx.x * RUN, aged = 0, carry_r0 = 0;
+    bool carry_ok = false;
+    if (t < nwork) fetch_tile(t);
     __syncthreads();
 
-    while (it < nwork) {
+    while (t < nwork) {
         const uint64_t tbase = (uint64_t)t * TILE;
         TD_STAMP(0);   // loop head
         // ---------------- A: this wave's quarter: raw bytes and terminator masks -> LDS
@@ -373,7 +372,6 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         }
         wave_lds_fence();          // this wave's masks and raw bytes are in LDS (nothing of another wave is read before the barrier)
         TD_STAMP(1);   // A: wait for the tile's bytes, raw + masks -> LDS
-        if (p.prio & 0x100u) __builtin_amdgcn_s_setprio(1);      // (experiment: the serial phase B above the arithmetic of other workgroups' A)
 
         // ---------------- B: terminators of this thread's CPT consecutive chunks, wave scan, vote, list of line starts
         uint32_t mm[CPT / 2];
@@ -413,30 +411,57 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
             for (int k = CPT / 2 - 1; k >= 0; k--) {
                 if (mm[k]) { fpos = 32u * k + __builtin_ctz(mm[k]); found = true; }
             }
-            // the first line that starts in this span: do its first eight bytes (inside this wave's quarter) read as bases?
-            const uint32_t ls = span0 + fpos + 1u;
-            uint2 q8 = make_uint2(0u, 0u);
-            if (found && ls + 8u <= wend) __builtin_memcpy(&q8, L_raw + ls, 8);
-            const uint32_t c0 = (q8.x >> 1) & 0x03030303u, c1 = (q8.y >> 1) & 0x03030303u;
-            const uint32_t d0 = (q8.x & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, c0);
-            const uint32_t d1 = (q8.y & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, c1);
-            const bool vote_good = (d0 | d1) == 0;
-            const uint32_t lclass = (incl - cnt) & 3u;
-            const uint64_t bg = __ballot(vote_good), b0 = __ballot((lclass & 1u) != 0), b1 = __ballot((lclass & 2u) != 0);
-            const uint32_t packed = (uint32_t)__builtin_popcountll(bg & ~b0 & ~b1) | ((uint32_t)__builtin_popcountll(bg & b0 & ~b1) << 8) |
-                                    ((uint32_t)__builtin_popcountll(bg & ~b0 & b1) << 16) | ((uint32_t)__builtin_popcountll(bg & b0 & b1) << 24);
+            uint32_t packed = 0;
+            if (!carry_ok) {
+                // the first line that starts in this span: do its first eight bytes (inside this wave's quarter) read as bases?
+                const uint32_t ls = span0 + fpos + 1u;
+                uint2 q8 = make_uint2(0u, 0u);
+                if (found && ls + 8u <= wend) __builtin_memcpy(&q8, L_raw + ls, 8);
+                const uint32_t c0 = (q8.x >> 1) & 0x03030303u, c1 = (q8.y >> 1) & 0x03030303u;
+                const uint32_t d0 = (q8.x & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, c0);
+                const uint32_t d1 = (q8.y & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, c1);
+                const bool vote_good = (d0 | d1) == 0;
+                const uint32_t lclass = (incl - cnt) & 3u;
+                const uint64_t bg = __ballot(vote_good), b0 = __ballot((lclass & 1u) != 0), b1 = __ballot((lclass & 2u) != 0);
+                packed = (uint32_t)__builtin_popcountll(bg & ~b0 & ~b1) | ((uint32_t)__builtin_popcountll(bg & b0 & ~b1) << 8) |
+                         ((uint32_t)__builtin_popcountll(bg & ~b0 & b1) << 16) | ((uint32_t)__builtin_popcountll(bg & b0 & b1) << 24);
+            }
             // the lines behind this wave's terminators, by wave-local ordinal, into the space of its masks (every lane of
             // the wave holds its masks in registers by now)
             uint16_t *Ll = L_mask + wave * WCH;
             uint32_t k = incl - cnt;
+            // Two terminators per 32-byte word without a branch (FASTQ: the "+" line's two, two bytes apart) -- a
+            // lane without one stores to a spare word; words with more (lines of a few bytes) take the loop, for
+            // the whole wave only when some lane has one.  A wave with more terminators than its list holds
+            // writes nothing: the tile goes to the fix-up pass (L_misc[2] below).
+            const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (__builtin_expect(wtot <= WCH, 1)) {
+                uint16_t *spare = reinterpret_cast<uint16_t *>(L_misc + 60);
+                uint32_t rest = 0;
 #pragma unroll
-            for (int i = 0; i < CPT / 2; i++) {
-                uint32_t m = mm[i];
-                while (m) {
-                    const uint32_t bit = __builtin_ctz(m);
-                    m &= m - 1;
-                    if (k < WCH) Ll[k] = (uint16_t)(span0 + 32u * i + bit + 1u);
-                    k++;
+                for (int i = 0; i < CPT / 2; i++) {
+                    const uint32_t m = mm[i], m1 = m & (m - 1u);
+                    const uint32_t base = span0 + 32u * i + 1u;
+                    uint16_t *d0 = m ? Ll + k : spare;
+                    *d0 = (uint16_t)(base + (uint32_t)__builtin_ctz(m | 0x80000000u));
+                    k += m ? 1u : 0u;
+                    uint16_t *d1 = m1 ? Ll + k : spare;
+                    *d1 = (uint16_t)(base + (uint32_t)__builtin_ctz(m1 | 0x80000000u));
+                    k += m1 ? 1u : 0u;
+                    rest |= m1 & (m1 - 1u);
+                }
+                if (__builtin_expect(__any(rest != 0), 0)) {
+                    k = incl - cnt;
+#pragma unroll
+                    for (int i = 0; i < CPT / 2; i++) {
+                        uint32_t m = mm[i];
+                        while (m) {
+                            const uint32_t bit = __builtin_ctz(m);
+                            m &= m - 1;
+                            Ll[k] = (uint16_t)(span0 + 32u * i + bit + 1u);
+                            k++;
+                        }
+                    }
                 }
             }
             if (lane == 63) {
@@ -447,7 +472,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         TD_STAMP(2);   // B: masks, scan, vote, list
         // ---------------- the pending line of the previous tile, the next tile's loads, the pending count
         __builtin_amdgcn_s_setprio(3);
-        const uint32_t nit = it + gridDim.x;
+        const uint32_t nit = run_pos + 1u < RUN ? t + 1u : t + 1u + (gridDim.x - 1u) * RUN;      // next tile of this workgroup
         bool phit = false;
         uint32_t pcell = 0;
         if (PIPE && pd_valid) { finish_pending(phit, pcell); pd_valid = false; }
@@ -471,7 +496,9 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         const uint4 flg4 = *reinterpret_cast<const uint4 *>(L_misc);
         const uint32_t wb1 = tot4.x, wb2 = wb1 + tot4.y, wb3 = wb2 + tot4.z, total = wb3 + tot4.w;
         uint32_t r0;
-        if (t != 0) {
+        if (carry_ok) {
+            r0 = carry_r0;
+        } else if (t != 0) {
             auto rot = [](uint32_t pk, uint32_t by) { const uint32_t r = 8u * (by & 3u); return r ? ((pk << r) | (pk >> (32u - r))) : pk; };
             const uint32_t a = pk4.x, b = rot(pk4.y, wb1), c = rot(pk4.z, wb2), d = rot(pk4.w, wb3);
             const uint32_t v02 = (a & 0x00FF00FFu) + (b & 0x00FF00FFu) + (c & 0x00FF00FFu) + (d & 0x00FF00FFu);
@@ -496,10 +523,13 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
             const uint32_t j0 = ((uint32_t)tid + 64u * (t & 3u)) & (uint32_t)(FBLOCK - 1);
 #pragma nounroll
             for (uint32_t j = j0; j < nwant; j += FBLOCK) {
+                // (the wave whose list holds ordinal o, and o's place in it: selects, no branches)
                 const uint32_t o = r0 + 4u * j;
-                const uint32_t w = (o >= wb1 ? 1u : 0u) + (o >= wb2 ? 1u : 0u) + (o >= wb3 ? 1u : 0u);
-                const uint32_t wb = w == 0 ? 0u : w == 1 ? wb1 : w == 2 ? wb2 : wb3;
-                const uint32_t srel = L_mask[w * WCH + (o - wb)];
+                uint32_t sel = 0u;
+                sel = o >= wb1 ? 1u * WCH - wb1 : sel;
+                sel = o >= wb2 ? 2u * WCH - wb2 : sel;
+                sel = o >= wb3 ? 3u * WCH - wb3 : sel;
+                const uint32_t srel = L_mask[o + sel];
                 // (a line that starts in the tile's last bytes is still whole in the staged window: the halo
                 // holds 16 NQ bytes and more)
                 const uint32_t k = line_prepare<W, NQ>(p, cx, L_raw, srel, pd);
@@ -542,7 +572,11 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         }
         lds_barrier();                                    // LDS is reused by the next tile
         TD_STAMP(8);   // end barrier (the other waves' matching)
-        it = nit; t = nit;
+        // the next tile of the run starts (total) terminators further on: its wanted ordinals are r0 - total (mod 4)
+        carry_r0 = (r0 - total) & 3u;
+        carry_ok = nit == t + 1u && t != 0;
+        run_pos = run_pos + 1u < RUN ? run_pos + 1u : 0u;
+        t = nit;
     }
     if (PIPE && pd_valid) {
         bool h; uint32_t c;

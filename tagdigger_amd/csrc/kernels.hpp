@@ -52,7 +52,7 @@ constexpr int IPL = 4;                     // line starts examined per lane per 
 
 // timing-only ablation switches (td_set_option "debug_ablate")
 constexpr uint32_t DBG_NO_ATOMIC = 1, DBG_NO_PROBE = 2, DBG_NO_PHASE2 = 4, DBG_NO_LOOKBACK = 8,
-                   DBG_NO_PACK = 16, DBG_STATIC_TILES = 32, DBG_PROBE_16B = 64, DBG_NO_LINEPACK = 128, DBG_NO_COMPARE = 256;
+                   DBG_NO_PACK = 16, DBG_STATIC_TILES = 32;
 
 // device-side error bits (stats[ST_ERR])
 constexpr unsigned long long ERR_NONASCII = 1, ERR_SPIN = 2, ERR_TASSEL = 4;
@@ -99,6 +99,7 @@ struct KParams {
     uint32_t stagger, stagger_div;   // start-up stagger of co-resident workgroups (units of 4096 cycles; 0 = off)
     uint32_t dbg;            // timing-only ablations (results wrong when nonzero); see DBG_*
     uint32_t hot_cache;      // k_fast2: count through the per-wave hot-cell cache in LDS
+    uint32_t run;            // k_fast2: consecutive tiles per workgroup turn (the line phase is carried inside a run)
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -150,9 +151,14 @@ __device__ __forceinline__ bool is_blank(uint32_t b) {  // str.strip() set minus
 }
 
 __device__ __forceinline__ uint32_t hash_key(uint64_t key) {  // must match host hash_key()
-    uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-    uint32_t h = (lo * 0x9E3779B1u) ^ ((hi + 0x7F4A7C15u) * 0x85EBCA77u);
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+    // 24 x 24-bit multiplies only (v_mul_u32_u24 issues at the full rate, v_mul_lo_u32 at a quarter of it);
+    // the key's 64 bits enter as 22 + 21 + 21 bit fields
+    const uint32_t a = (uint32_t)key & 0x3FFFFFu, b = (uint32_t)(key >> 22) & 0x1FFFFFu, c = (uint32_t)(key >> 43);
+    uint32_t h = __umul24(a, 0x9E3779u) ^ (__umul24(b, 0x85EBCBu) + 0x7F4A7C15u);
+    h ^= __umul24(c, 0xC2B2AFu) << 3;
+    h ^= h >> 15;
+    h = __umul24(h & 0xFFFFFFu, 0x2C1B3Du) ^ (h >> 9);
+    h ^= h >> 13;
     return h;
 }
 

@@ -49,10 +49,14 @@ void pack_bases(const std::string &s, uint64_t *words, int nwords) {
     for (size_t i = 0; i < s.size(); i++)
         words[i >> 5] |= (uint64_t)base_code(s[i]) << (62 - 2 * (i & 31));
 }
-inline uint32_t hash_key(uint64_t key) {   // must match tdk::hash_key
-    uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-    uint32_t h = (lo * 0x9E3779B1u) ^ ((hi + 0x7F4A7C15u) * 0x85EBCA77u);
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+inline uint32_t hash_key(uint64_t key) {   // must match tdk::hash_key (24-bit multiplies: low 32 bits of the product of the low 24 bits)
+    auto mul24 = [](uint32_t x, uint32_t y) -> uint32_t { return (uint32_t)((uint64_t)(x & 0xFFFFFFu) * (uint64_t)(y & 0xFFFFFFu)); };
+    const uint32_t a = (uint32_t)key & 0x3FFFFFu, b = (uint32_t)(key >> 22) & 0x1FFFFFu, c = (uint32_t)(key >> 43);
+    uint32_t h = mul24(a, 0x9E3779u) ^ (mul24(b, 0x85EBCBu) + 0x7F4A7C15u);
+    h ^= mul24(c, 0xC2B2AFu) << 3;
+    h ^= h >> 15;
+    h = mul24(h & 0xFFFFFFu, 0x2C1B3Du) ^ (h >> 9);
+    h ^= h >> 13;
     return h;
 }
 
@@ -179,6 +183,7 @@ struct td_handle {
     int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1, nt_loads = 1;
     int kernel_gen = 2;                       // main pass of the free-running path: 2 = k_fast2 (lazy packing), 1 = k_fast
     int tile_kb2 = 0;                         // k_fast2's tile (16 | 24 | 32 KiB; 0 = fast2_auto_tile)
+    int run = 8;                              // k_fast2: consecutive tiles per workgroup turn (measured: 4-16 alike, 1 and 64+ slower)
     int hot_cache = 1;                        // k_fast2: count through the per-wave hot-cell cache
     uint64_t fast_max_matrix = 1ull << 32;    // the free-running kernel addresses cells as base + 32-bit byte offset
     uint32_t debug_ablate = 0;
@@ -362,6 +367,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     p.prio = (uint32_t)h->prio;
 
     p.hot_cache = (uint32_t)h->hot_cache;
+    p.run = (uint32_t)h->run;
     if (use_fast) {
         int rc = h->d_tileinfo.ensure(ntiles); if (rc) return rc;
         const uint32_t fix_cap = 3u * ntiles + 8u;
@@ -1004,6 +1010,7 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
         if (value && h->have_index && lds_bytes_fast2(h, (int)value) > LDS_BUDGET) return fail(TD_E_LIMIT, "tile does not fit the LDS budget with this index");
         h->tile_kb2 = (int)value;
     } else if (n == "hot_cache") h->hot_cache = value ? 1 : 0;
+    else if (n == "run") h->run = (int)std::max<int64_t>(1, std::min<int64_t>(value, 4096));
     else if (n == "stagger") h->stagger = (int)value;
     else if (n == "prio") h->prio = (int)value & 0xFFFF;
     else if (n == "table_load_pct") h->table_load = std::max<int64_t>(10, std::min<int64_t>(value, 95)) / 100.0;
@@ -1078,6 +1085,24 @@ int td_device_sync(td_handle *h) {
 }
 
 }  // extern "C"
+
+// ---- a row of the count matrix as the text csv.writer gives it (decimal integers, commas): the 38 M cells of a
+// 384 x 100 k matrix take the reference's writeCounts (tagdigger_fun.py:1100-1111) half a minute through Python ints
+extern "C" int64_t td_format_csv_row(const int64_t *vals, uint64_t n, char *out, uint64_t capacity) {
+    char *o = out, *const end = out + capacity;
+    for (uint64_t i = 0; i < n; i++) {
+        if (end - o < 24) return -1;
+        int64_t v = vals[i];
+        if (i) *o++ = ',';
+        unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        if (v < 0) *o++ = '-';
+        char tmp[20];
+        int k = 0;
+        do { tmp[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+        while (k) *o++ = tmp[--k];
+    }
+    return (int64_t)(o - out);
+}
 
 // ---- K3: barcode rows of one library -> sample rows of the run (reference combineReadCounts,
 // tagdigger_fun.py:1061-1098: equal sample names are summed, on the host there, here on the device so that the
