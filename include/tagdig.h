@@ -175,6 +175,10 @@ int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
  * entries.  Synchronous; waits for the handle's own work first and reports what a kernel flagged. */
 int td_fold_rows(td_handle *h, const uint32_t *row_of_barcode, uint32_t n_dst_rows, void *d_dst, void *stream);
 
+/* The raw-DEFLATE decoder the GPU runs one BGZF member per lane with (csrc/gpu_inflate.hpp), on the host: inflates
+ * in[0..in_len) into out[0..out_len), out_len being the exact inflated size; 0 or a decoder error code (tests). */
+int td_inflate_raw_host(const void *in, uint32_t in_len, void *out, uint32_t out_len);
+
 /* Host helper of the CSV writers: vals[0..n) as decimal integers separated by commas (what csv.writer writes for a
  * row of ints, reference writeCounts tagdigger_fun.py:1100-1111) into out[0..capacity); returns the bytes written,
  * -1 when they do not fit (24 bytes per value always do). */

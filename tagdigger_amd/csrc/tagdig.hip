@@ -24,6 +24,7 @@
 #include "kernel_fast2.hpp"
 #include "kernel_splitter.hpp"
 #include "gz_source.hpp"
+#include "gpu_inflate.hpp"
 
 namespace {
 
@@ -178,6 +179,12 @@ struct td_handle {
     DevBuf<uint8_t> d_sp_pool;
     DevBuf<uint4> d_fixlist;
     DevBuf<uint32_t> d_rowmap;                // td_fold_rows: sample row of every barcode row
+    // BGZF members inflated on the GPU (count_bgzf_gpu): two batches in flight
+    struct ZSlot { uint8_t *pin = nullptr, *d_in = nullptr, *d_out = nullptr; tdinf::Member *pin_mem = nullptr, *d_mem = nullptr;
+                   uint32_t *d_status = nullptr, *pin_status = nullptr; uint8_t *pin_tail = nullptr; hipEvent_t copied = nullptr; } zslot[2];
+    uint8_t *d_zscratch = nullptr; uint32_t *d_crctab = nullptr;
+    int gpu_inflate = 1;                      // BGZF input: inflate on the GPU (0: member-parallel on the host)
+    int gpu_inflate_crc = 1;                  // ... and check every member's CRC-32 there
     uint32_t max_need = 0;                    // bases from a read's start that the matcher may look at
     // options
     int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1, nt_loads = 1;
@@ -571,6 +578,19 @@ void td_destroy(td_handle *h) {
         if (sl.res_pin) (void)hipHostFree(sl.res_pin);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    for (auto &z : h->zslot) {
+        if (z.pin) (void)hipHostFree(z.pin);
+        if (z.d_in) (void)hipFree(z.d_in);
+        if (z.d_out) (void)hipFree(z.d_out);
+        if (z.pin_mem) (void)hipHostFree(z.pin_mem);
+        if (z.d_mem) (void)hipFree(z.d_mem);
+        if (z.d_status) (void)hipFree(z.d_status);
+        if (z.pin_status) (void)hipHostFree(z.pin_status);
+        if (z.pin_tail) (void)hipHostFree(z.pin_tail);
+        if (z.copied) (void)hipEventDestroy(z.copied);
+    }
+    if (h->d_zscratch) (void)hipFree(h->d_zscratch);
+    if (h->d_crctab) (void)hipFree(h->d_crctab);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->work_stream) (void)hipStreamDestroy(h->work_stream);
     delete h;
@@ -866,6 +886,118 @@ int pump(td_handle *h, Reader &&reader, uint64_t size_hint, uint64_t first_line,
 }
 }  // namespace
 
+// ---- BGZF input inflated on the GPU (second option).  The host only maps the file and walks the member
+// headers; batches of compressed members go over PCIe (a quarter of the bytes), tdinf::k_bgzf_inflate inflates one
+// member per lane, every member's size and CRC-32 are checked on the device, the batch is cut at its last line end
+// and counted where it lies, and what is left of the last line moves to the front of the next batch's buffer.
+namespace {
+constexpr uint32_t ZB_MEMBERS = 16384;                       // members per batch (1 GiB of FASTQ at 64 KiB each)
+constexpr size_t ZB_IN = (size_t)384 << 20;                  // compressed bytes per batch, at most
+constexpr size_t ZB_CARRY = (size_t)4 << 20;                 // longest line end-less tail carried to the next batch
+constexpr size_t ZB_TAIL = (size_t)1 << 20;                  // bytes of a batch's end looked at for its last line end
+
+int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weights, bool *not_bgzf) {
+    *not_bgzf = false;
+    tdhost::GzSource src;
+    if (!src.map_only(path)) { *not_bgzf = true; return TD_OK; }           // (empty or unreadable: the host path reports it)
+    uint32_t bs0 = 0, hs0 = 0;
+    if (!tdhost::GzSource::bgzf_header(src.map, src.bsize, &bs0, &hs0)) { *not_bgzf = true; return TD_OK; }
+    const size_t out_cap = (size_t)ZB_MEMBERS * 65536 + ZB_CARRY + 4096;
+    for (auto &z : h->zslot) {
+        if (z.pin) continue;
+        HIPCHK(hipHostMalloc((void **)&z.pin, ZB_IN + 64, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&z.d_in, ZB_IN + 64));
+        HIPCHK(hipMalloc((void **)&z.d_out, out_cap));
+        HIPCHK(hipHostMalloc((void **)&z.pin_mem, (size_t)ZB_MEMBERS * sizeof(tdinf::Member), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&z.d_mem, (size_t)ZB_MEMBERS * sizeof(tdinf::Member)));
+        HIPCHK(hipMalloc((void **)&z.d_status, (size_t)ZB_MEMBERS * 4));
+        HIPCHK(hipHostMalloc((void **)&z.pin_status, (size_t)ZB_MEMBERS * 4, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&z.pin_tail, ZB_TAIL, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&z.copied, hipEventDisableTiming));
+    }
+    if (!h->d_zscratch) HIPCHK(hipMalloc((void **)&h->d_zscratch, (size_t)ZB_MEMBERS * tdinf::SCRATCH_BYTES));
+    if (!h->d_crctab) {
+        uint32_t T[256];
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; T[i] = c; }
+        HIPCHK(hipMalloc((void **)&h->d_crctab, sizeof(T)));
+        HIPCHK(hipMemcpy(h->d_crctab, T, sizeof(T), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemsetAsync(h->d_cursor.p, 0, 16, h->work_stream));
+    struct Batch { uint32_t n = 0; size_t out_total = 0; bool last = false; };
+    size_t pos = 0;
+    // members of the next batch: descriptors and compressed bytes into the slot's pinned buffers, then on their way to the device
+    auto prepare = [&](int slot, Batch &b) -> int {
+        td_handle::ZSlot &z = h->zslot[slot];
+        b = Batch();
+        const size_t first = pos;
+        while (pos < src.bsize && b.n < ZB_MEMBERS) {
+            uint32_t bs = 0, hs = 0;
+            if (!tdhost::GzSource::bgzf_header(src.map + pos, src.bsize - pos, &bs, &hs) || bs < hs + 8 || pos + bs > src.bsize)
+                return fail(TD_E_IO, "damaged BGZF member header");
+            if (pos + bs - first > ZB_IN) break;
+            const uint8_t *tail = src.map + pos + bs - 8;
+            const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+            const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+            if (isize > 65536) return fail(TD_E_IO, "BGZF member larger than 64 KiB");
+            z.pin_mem[b.n] = tdinf::Member{pos + hs - first, b.out_total, bs - hs - 8, isize, crc, 0};
+            b.out_total += isize; b.n++;
+            pos += bs;
+        }
+        b.last = pos >= src.bsize;
+        const size_t nin = pos - first;
+        if (nin) stage_parallel(nin, [&](size_t off, size_t len) { memcpy(z.pin + off, src.map + first + off, len); return true; });
+        memset(z.pin + nin, 0, 64);
+        HIPCHK(hipMemcpyAsync(z.d_in, z.pin, nin + 64, hipMemcpyHostToDevice, h->copy_stream));
+        if (b.n) HIPCHK(hipMemcpyAsync(z.d_mem, z.pin_mem, (size_t)b.n * sizeof(tdinf::Member), hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(hipEventRecord(z.copied, h->copy_stream));
+        return TD_OK;
+    };
+    Batch cur, nxt;
+    int slot = 0;
+    int rc = prepare(0, cur); if (rc) return rc;
+    size_t carry = 0;                                       // bytes of an unfinished line at the front of this slot's output
+    uint64_t bytes_submitted = 0;
+    unsigned pieces = 0;
+    for (;;) {
+        td_handle::ZSlot &z = h->zslot[slot];
+        HIPCHK(hipStreamWaitEvent(h->work_stream, z.copied, 0));
+        if (cur.n) {
+            hipLaunchKernelGGL(tdinf::k_bgzf_inflate, dim3((cur.n + 63) / 64), dim3(64), 64 * tdinf::TABLE_U16 * 2, h->work_stream,
+                               z.d_in, z.d_out + carry, z.d_mem, cur.n, h->d_zscratch, z.d_status, h->d_crctab, (uint32_t)h->gpu_inflate_crc);
+            HIPCHK(hipGetLastError());
+        }
+        const size_t total = carry + cur.out_total;
+        const size_t ntail = std::min(total, ZB_TAIL);
+        if (cur.n) HIPCHK(hipMemcpyAsync(z.pin_status, z.d_status, (size_t)cur.n * 4, hipMemcpyDeviceToHost, h->work_stream));
+        if (ntail && !cur.last) HIPCHK(hipMemcpyAsync(z.pin_tail, z.d_out + total - ntail, ntail, hipMemcpyDeviceToHost, h->work_stream));
+        // the next batch is read and sent while this one inflates
+        if (!cur.last) { rc = prepare(slot ^ 1, nxt); if (rc) return rc; }
+        HIPCHK(hipStreamSynchronize(h->work_stream));
+        for (uint32_t i = 0; i < cur.n; i++)
+            if (z.pin_status[i]) return fail(TD_E_IO, z.pin_status[i] == 100 ? "BGZF member fails its CRC-32" : "inflate error in a BGZF member");
+        size_t cut = total;
+        if (!cur.last && total) {
+            const size_t c = cut_at_line_end(z.pin_tail, ntail);
+            if (c == 0 || total - (total - ntail + c) > ZB_CARRY) return fail(TD_E_LIMIT, "a single line exceeds the staging buffer");
+            cut = total - ntail + c;
+        }
+        if (cut) {
+            rc = launch_count(h, z.d_out, cut, 0, max_reads, weights, h->work_stream, h->d_cursor.p + (pieces & 1),
+                              h->d_cursor.p + ((pieces + 1) & 1), bytes_submitted);
+            if (rc) return rc;
+            bytes_submitted += cut; pieces++;
+        }
+        if (cur.last) break;
+        carry = total - cut;
+        if (carry) HIPCHK(hipMemcpyAsync(h->zslot[slot ^ 1].d_out, z.d_out + cut, carry, hipMemcpyDeviceToDevice, h->work_stream));
+        cur = nxt; slot ^= 1;
+    }
+    HIPCHK(hipStreamSynchronize(h->work_stream));
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    return TD_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int td_count_host(td_handle *h, const void *fastq, uint64_t nbytes, uint64_t first_line, uint64_t max_reads,
@@ -914,6 +1046,12 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
     const size_t len = strlen(path);
     const bool gz = len >= 2 && (path[len - 2] == 'g' || path[len - 2] == 'G') && (path[len - 1] == 'z' || path[len - 1] == 'Z');
     if (gz) {
+        static const bool env_off = getenv("TAGDIG_GPU_INFLATE") && atoi(getenv("TAGDIG_GPU_INFLATE")) == 0;
+        if (h->gpu_inflate && !env_off && !getenv("TAGDIG_ZLIB")) {          // BGZF: members inflated on the GPU
+            bool not_bgzf = false;
+            const int rc = count_bgzf_gpu(h, path, max_reads, weights, &not_bgzf);
+            if (rc || !not_bgzf) return rc;
+        }
         tdhost::GzSource src;
         if (!src.open(path)) return fail(TD_E_IO, std::string("cannot open ") + path);
         auto reader = [&](uint8_t *dst, size_t want) -> long { return src.read(dst, want); };
@@ -1011,6 +1149,8 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
         h->tile_kb2 = (int)value;
     } else if (n == "hot_cache") h->hot_cache = value ? 1 : 0;
     else if (n == "run") h->run = (int)std::max<int64_t>(1, std::min<int64_t>(value, 4096));
+    else if (n == "gpu_inflate") h->gpu_inflate = value ? 1 : 0;
+    else if (n == "gpu_inflate_crc") h->gpu_inflate_crc = value ? 1 : 0;
     else if (n == "stagger") h->stagger = (int)value;
     else if (n == "prio") h->prio = (int)value & 0xFFFF;
     else if (n == "table_load_pct") h->table_load = std::max<int64_t>(10, std::min<int64_t>(value, 95)) / 100.0;
@@ -1085,6 +1225,18 @@ int td_device_sync(td_handle *h) {
 }
 
 }  // extern "C"
+
+// ---- the per-lane DEFLATE decoder of gpu_inflate.hpp, run on the host (tests: against zlib, without a GPU)
+extern "C" int td_inflate_raw_host(const void *in, uint32_t in_len, void *out, uint32_t out_len) {
+    std::vector<uint8_t> padded((size_t)in_len + 16, 0);
+    if (in_len) memcpy(padded.data(), in, in_len);
+    std::vector<uint16_t> tab(tdinf::TABLE_U16);
+    std::vector<uint8_t> scratch(tdinf::SCRATCH_BYTES);
+    tdinf::Stream s{};
+    s.in = padded.data(); s.in_len = in_len; s.out = (uint8_t *)out; s.out_len = out_len;
+    s.tab = tab.data(); s.tstride = 1; s.scratch = scratch.data();
+    return (int)tdinf::run(s);
+}
 
 // ---- a row of the count matrix as the text csv.writer gives it (decimal integers, commas): the 38 M cells of a
 // 384 x 100 k matrix take the reference's writeCounts (tagdigger_fun.py:1100-1111) half a minute through Python ints

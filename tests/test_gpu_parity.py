@@ -328,21 +328,69 @@ def test_idempotent_relaunch_and_accumulate(eng):
 
 
 @pytest.mark.gpu
-def test_bgzf_file_counts_like_plain(tmp_path):
-    """A bgzip-style file goes through the member-parallel inflate: same matrix as the plain bytes."""
+@pytest.mark.parametrize("where", ["gpu", "host"])
+@pytest.mark.parametrize("level", [1, 6, 0])
+def test_bgzf_file_counts_like_plain(tmp_path, where, level):
+    """A bgzip-style file: its members inflated on the GPU (one per lane, csrc/gpu_inflate.hpp; the default) or
+    member-parallel on the host -- same matrix as the plain bytes.  Level 0 = stored blocks."""
     import tagdigger_amd
     from tagdigger_amd.synth import SynthConfig
     from helpers import bgzf_bytes, synth_host_bytes, synth_expected
     cfg = SynthConfig(nreads=300_000, nbar=8, nmarkers=50, seed=1234)      # 66 MB: several staging pieces
     data = bytes(synth_host_bytes(cfg, 0, cfg.nreads))
     p = tmp_path / "lib.fq.gz"
-    p.write_bytes(bgzf_bytes(data, level=1))
+    p.write_bytes(bgzf_bytes(data, level=level, threads=8))
     eng = tagdigger_amd.Engine(0)
     try:
         eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        eng.set_option("gpu_inflate", 1 if where == "gpu" else 0)
         eng.count_file(str(p))
         want, _ = synth_expected(cfg, 0, cfg.nreads)
         assert (eng.counts_numpy() == want).all()
+        # a read limit inside the file
+        eng.reset()
+        eng.count_file(str(p), maxreads=123_456)
+        w2, _ = synth_expected(cfg, 0, 123_456)
+        assert (eng.counts_numpy() == w2).all()
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_bgzf_gpu_inflate_dirty_and_damaged(tmp_path):
+    """Members that end inside lines (odd block sizes), CRLF and unterminated last lines through the GPU inflater;
+    a flipped bit in a member's payload or a wrong CRC-32 in its trailer is an error, not a different matrix."""
+    import tagdigger_amd
+    from helpers import bgzf_bytes
+    rnd = random.Random(5)
+    barcodes, tags, cutsites = small_index(rnd, "TGCAG", nbar=8, ntag=40)
+    data = dirty_fastq(rnd, barcodes, tags, cutsites, nrec=40_000, nl_choices=("\n", "\r\n")).rstrip(b"\r\n")
+    want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data)
+    eng = tagdigger_amd.Engine(0)
+    try:
+        eng.set_index(barcodes, tags, "TGCAG")
+        for block in (0xFF00, 4093, 65280 // 7):
+            p = tmp_path / ("d%d.fq.gz" % block)
+            p.write_bytes(bgzf_bytes(data, block=block, level=6, threads=8))
+            eng.reset()
+            eng.count_file(str(p))
+            assert (eng.counts_numpy() == want).all(), block
+        blob = bytearray(bgzf_bytes(data, level=6, threads=8))
+        bad = tmp_path / "bad.fq.gz"
+        flipped = bytearray(blob)
+        flipped[len(blob) // 2] ^= 0x10                                   # somewhere in a member's deflate stream
+        bad.write_bytes(bytes(flipped))
+        eng.reset()
+        with pytest.raises(tagdigger_amd.TagdigError):
+            eng.count_file(str(bad))
+        import struct
+        bsize = struct.unpack("<H", blob[16:18])[0] + 1                  # first member: its CRC-32 sits 8 bytes before its end
+        wrong = bytearray(blob)
+        wrong[bsize - 8] ^= 0xFF
+        bad.write_bytes(bytes(wrong))
+        eng.reset()
+        with pytest.raises(tagdigger_amd.TagdigError):
+            eng.count_file(str(bad))
     finally:
         eng.close()
 

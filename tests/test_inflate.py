@@ -237,3 +237,46 @@ def test_parallel_decoder_is_the_default_for_large_files(tmp_path, monkeypatch, 
     rc, got = gunzip(p, len(small))
     assert rc == 0 and got == small
     assert _stats_line(capfd) is None
+
+
+# ------------------------------------------------------------------ the decoder the GPU runs per lane, on the host
+def test_lane_decoder_against_zlib():
+    """csrc/gpu_inflate.hpp through td_inflate_raw_host: stored, fixed and dynamic blocks, several blocks per
+    stream, codes longer than the primary tables' index, every zlib level -- and damaged streams fail cleanly."""
+    import ctypes as C
+    import random
+    import zlib
+    from tagdigger_amd import _binding as B
+    L = B.load()
+
+    def inflate(comp, n):
+        out = (C.c_char * max(1, n))()
+        return L.td_inflate_raw_host(comp, len(comp), out, n), bytes(out[:n])
+    rnd = random.Random(7)
+
+    def fastq(n):
+        return "".join("@r%012d\n%s\n+\n%s\n" % (i, "".join(rnd.choice("ACGT") for _ in range(100)),
+                                                     "".join(rnd.choice("IIIIIHGF#5<") for _ in range(100))) for i in range(n)).encode()
+    inputs = [b"", b"a", b"abc" * 5, bytes(rnd.randrange(256) for _ in range(9000)), fastq(290), b"A" * 65000,
+              bytes(rnd.choice(b"ACGT") for _ in range(60000)), bytes(range(256)) * 200, fastq(300)[:0xFF00]]
+    for data in inputs:
+        for level in (0, 1, 4, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY):
+                co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+                comp = co.compress(data) + co.flush()
+                rc, out = inflate(comp, len(data))
+                assert rc == 0 and out == data, (len(data), level, strategy, rc)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    d1, d2 = fastq(100), bytes(rnd.randrange(256) for _ in range(3000))
+    comp = co.compress(d1) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(d2) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(d1) + co.flush()
+    assert inflate(comp, len(d1 + d2 + d1)) == (0, d1 + d2 + d1)
+    assert inflate(comp, len(d1 + d2 + d1) - 3)[0] != 0 and inflate(comp, len(d1 + d2 + d1) + 3)[0] != 0     # the size is part of the contract
+    data = fastq(200)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    for _ in range(400):                                                   # no crash, no hang; mostly rejected
+        b = bytearray(comp)
+        for _ in range(rnd.randint(1, 5)):
+            b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        inflate(bytes(b), len(data))
+    assert inflate(comp[:len(comp) // 2], len(data))[0] != 0
