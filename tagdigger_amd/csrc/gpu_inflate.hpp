@@ -42,6 +42,8 @@ struct Stream {
     uint32_t bc, ipos, opos;
     uint32_t state, err, last_block;
     uint32_t copy_len, copy_dist;
+    uint64_t pat;           // COPY with a distance below 8: the eight bytes written last (the next eight follow from them)
+    uint32_t ahead;         // the input word after the bit buffer's, loaded one refill early (its latency runs under the decoding)
 };
 
 TDI_FN uint32_t load32(const uint8_t *p) {                    // (any alignment: one load on the device)
@@ -49,10 +51,18 @@ TDI_FN uint32_t load32(const uint8_t *p) {                    // (any alignment:
     __builtin_memcpy(&v, p, 4);
     return v;
 }
+TDI_FN uint64_t load64(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+TDI_FN void store64(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+// ipos = the input consumed into the bit buffer; `ahead` holds in[ipos .. ipos + 4)
 TDI_FN void refill(Stream &s) {
     if (s.bc <= 32) {
-        s.bb |= (uint64_t)load32(s.in + s.ipos) << s.bc;
+        s.bb |= (uint64_t)s.ahead << s.bc;
         s.ipos += 4; s.bc += 32;
+        s.ahead = load32(s.in + s.ipos);
     }
 }
 TDI_FN uint32_t peek(const Stream &s, uint32_t n) { return (uint32_t)s.bb & ((1u << n) - 1u); }
@@ -128,6 +138,7 @@ TDI_FN void header(Stream &s) {
         if ((len ^ nlen) != 0xFFFFu) { s.state = ST_ERROR; s.err = ERR_STORED; return; }
         // the bytes still in the bit buffer go back to the input
         s.ipos -= s.bc >> 3; s.bb = 0; s.bc = 0;
+        s.ahead = load32(s.in + s.ipos);
         s.copy_len = len;
         s.state = len ? ST_STORED : (s.last_block ? ST_DONE : ST_HEADER);
         return;
@@ -204,6 +215,17 @@ TDI_FN void step_symbol(Stream &s) {
     if (dist > s.opos) { s.state = ST_ERROR; s.err = ERR_DIST; return; }
     if (s.opos + length > s.out_len) { s.state = ST_ERROR; s.err = ERR_OVERRUN; return; }
     s.copy_len = length; s.copy_dist = dist;
+    if (dist < 8u) {
+        // the eight bytes "before" the copy's first byte, as if the pattern had been running: byte k of pat = out[opos - 8 + k]
+        // for the last `dist` of them, the others by periodicity
+        const uint64_t last = load64(s.out + s.opos - dist) ;              // (its first `dist` bytes are what counts)
+        uint64_t pat = 0;
+        for (uint32_t k = 0; k < 8u; k++) {
+            const uint32_t from = (k + 8u * dist - 8u) % dist;             // out[opos - 8 + k] == out[opos - dist + ((k - 8) mod dist)]
+            pat |= ((last >> (8u * from)) & 0xFFull) << (8u * k);
+        }
+        s.pat = pat;
+    }
     s.state = ST_COPY;
 }
 
@@ -213,12 +235,24 @@ TDI_FN void step(Stream &s) {
     case ST_HEADER: header(s); break;
     case ST_SYMBOL: step_symbol(s); break;
     case ST_COPY: {
-        uint32_t n = s.copy_len < 8u ? s.copy_len : 8u;
-        s.copy_len -= n;
+        const uint32_t n = s.copy_len < 8u ? s.copy_len : 8u;
         uint8_t *o = s.out + s.opos;
-        const uint8_t *f = o - s.copy_dist;
-        s.opos += n;
-        while (n--) *o++ = *f++;
+        uint64_t v;
+        if (s.copy_dist >= 8u) {
+            v = load64(o - s.copy_dist);                                   // source and destination do not overlap within 8 bytes
+        } else {
+            // byte k of the next eight = the byte `dist` before it: from the previous eight, or from these
+            const uint32_t d = s.copy_dist;
+            v = 0;
+            for (uint32_t k = 0; k < 8u; k++) {
+                const uint64_t b = k < d ? (s.pat >> (8u * (8u - d + k))) & 0xFFull : (v >> (8u * (k - d))) & 0xFFull;
+                v |= b << (8u * k);
+            }
+            s.pat = v;
+        }
+        if (n == 8u) store64(o, v);
+        else for (uint32_t k = 0; k < n; k++) o[k] = (uint8_t)(v >> (8u * k));     // (exact: the next member's output follows)
+        s.opos += n; s.copy_len -= n;
         if (s.copy_len == 0) s.state = ST_SYMBOL;
         break;
     }
@@ -227,7 +261,7 @@ TDI_FN void step(Stream &s) {
         if (s.opos + n > s.out_len || s.ipos + n > s.in_len) { s.state = ST_ERROR; s.err = ERR_OVERRUN; return; }
         s.copy_len -= n;
         while (n--) s.out[s.opos++] = s.in[s.ipos++];
-        if (s.copy_len == 0) s.state = s.last_block ? ST_DONE : ST_HEADER;
+        if (s.copy_len == 0) { s.ahead = load32(s.in + s.ipos); s.state = s.last_block ? ST_DONE : ST_HEADER; }
         break;
     }
     default: break;
@@ -238,7 +272,8 @@ TDI_FN void step(Stream &s) {
 // block header, and a block holds at least its end code: 4 (in + out) + 64 steps are more than any valid stream takes.
 TDI_FN uint32_t run(Stream &s) {
     s.bb = 0; s.bc = 0; s.ipos = 0; s.opos = 0; s.state = ST_HEADER; s.err = ERR_NONE; s.last_block = 0;
-    s.copy_len = 0; s.copy_dist = 0;
+    s.copy_len = 0; s.copy_dist = 0; s.pat = 0;
+    s.ahead = load32(s.in);
     uint64_t budget = 4ull * ((uint64_t)s.in_len + s.out_len) + 64;
     while (s.state < ST_DONE) {
         if (budget-- == 0) { s.state = ST_ERROR; s.err = ERR_STEPS; break; }
@@ -258,17 +293,26 @@ struct Member {
     uint32_t crc;           // CRC-32 of the inflated bytes (the member's trailer)
     uint32_t pad;
 };
-// bitwise-free CRC-32 of a member's output, four bytes a step (slicing-by-4 over a 4 KiB table in LDS would be
-// faster still; this keeps the LDS for the Huffman tables): the table of the low byte only, in constant memory
-__device__ __forceinline__ uint32_t crc32_bytes(const uint8_t *p, uint32_t n, const uint32_t *T) {
-    uint32_t c = 0xFFFFFFFFu;
-    for (uint32_t i = 0; i < n; i++) c = T[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+// CRC-32 of a member's output, four bytes a step (slicing-by-4: T[k][b] = the CRC of byte b followed by k zero
+// bytes; the four tables, 4 KiB, sit in LDS beside the Huffman tables)
+__device__ __forceinline__ uint32_t crc32_lds(const uint8_t *p, uint32_t n, const uint32_t *T) {
+    uint32_t c = 0xFFFFFFFFu, i = 0;
+    for (; i + 4 <= n; i += 4) {
+        c ^= load32(p + i);
+        c = T[768 + (c & 0xFFu)] ^ T[512 + ((c >> 8) & 0xFFu)] ^ T[256 + ((c >> 16) & 0xFFu)] ^ T[c >> 24];
+    }
+    for (; i < n; i++) c = T[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
     return ~c;
 }
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, uint8_t *out, const Member *mem, uint32_t n, uint8_t *scratch,
-                                                     uint32_t *status, const uint32_t *crc_table, uint32_t check_crc) {
+                                                     uint32_t *status, const uint32_t *crc_tables, uint32_t check_crc) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint32_t *L_crc = reinterpret_cast<uint32_t *>(lds + 64 * TABLE_U16 * 2);
     const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
+    if (check_crc) {
+        for (uint32_t k = lane; k < 1024u; k += 64u) L_crc[k] = crc_tables[k];
+        __syncthreads();
+    }
     if (i >= n) return;
     const Member m = mem[i];
     Stream s{};
@@ -276,7 +320,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, uint8_t 
     s.tab = reinterpret_cast<uint16_t *>(lds) + lane; s.tstride = 64;
     s.scratch = scratch + (size_t)i * SCRATCH_BYTES;
     uint32_t rc = run(s);
-    if (rc == ERR_NONE && check_crc && crc32_bytes(s.out, m.out_len, crc_table) != m.crc) rc = 100;
+    if (rc == ERR_NONE && check_crc && crc32_lds(s.out, m.out_len, L_crc) != m.crc) rc = 100;
     status[i] = rc;
 }
 #endif

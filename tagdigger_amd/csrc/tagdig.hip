@@ -180,8 +180,9 @@ struct td_handle {
     DevBuf<uint4> d_fixlist;
     DevBuf<uint32_t> d_rowmap;                // td_fold_rows: sample row of every barcode row
     // BGZF members inflated on the GPU (count_bgzf_gpu): two batches in flight
-    struct ZSlot { uint8_t *pin = nullptr, *d_in = nullptr, *d_out = nullptr; tdinf::Member *pin_mem = nullptr, *d_mem = nullptr;
+    struct ZSlot { uint8_t *d_in = nullptr, *d_out = nullptr; tdinf::Member *pin_mem = nullptr, *d_mem = nullptr;
                    uint32_t *d_status = nullptr, *pin_status = nullptr; uint8_t *pin_tail = nullptr; hipEvent_t copied = nullptr; } zslot[2];
+    struct ZPiece { uint8_t *pin = nullptr; hipEvent_t sent = nullptr; bool busy = false; } zpiece[2];     // pinned staging of the compressed bytes
     uint8_t *d_zscratch = nullptr; uint32_t *d_crctab = nullptr;
     int gpu_inflate = 1;                      // BGZF input: inflate on the GPU (0: member-parallel on the host)
     int gpu_inflate_crc = 1;                  // ... and check every member's CRC-32 there
@@ -578,8 +579,11 @@ void td_destroy(td_handle *h) {
         if (sl.res_pin) (void)hipHostFree(sl.res_pin);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    for (auto &zp : h->zpiece) {
+        if (zp.pin) (void)hipHostFree(zp.pin);
+        if (zp.sent) (void)hipEventDestroy(zp.sent);
+    }
     for (auto &z : h->zslot) {
-        if (z.pin) (void)hipHostFree(z.pin);
         if (z.d_in) (void)hipFree(z.d_in);
         if (z.d_out) (void)hipFree(z.d_out);
         if (z.pin_mem) (void)hipHostFree(z.pin_mem);
@@ -891,8 +895,12 @@ int pump(td_handle *h, Reader &&reader, uint64_t size_hint, uint64_t first_line,
 // member per lane, every member's size and CRC-32 are checked on the device, the batch is cut at its last line end
 // and counted where it lies, and what is left of the last line moves to the front of the next batch's buffer.
 namespace {
-constexpr uint32_t ZB_MEMBERS = 16384;                       // members per batch (1 GiB of FASTQ at 64 KiB each)
-constexpr size_t ZB_IN = (size_t)384 << 20;                  // compressed bytes per batch, at most
+// members per batch: one lane each, and the decoder's speed is all latency (one dependent table look-up and memory
+// access after the other) -- 16 384 members are ONE wave per CU (13-19 GB/s measured), 49 152 fill the three waves
+// per CU that the LDS tables allow
+constexpr uint32_t ZB_MEMBERS = 49152;
+constexpr size_t ZB_IN = (size_t)1280 << 20;                 // compressed bytes per batch, at most
+constexpr size_t ZB_PIECE = (size_t)64 << 20;                // ... staged through pinned memory in pieces of this size
 constexpr size_t ZB_CARRY = (size_t)4 << 20;                 // longest line end-less tail carried to the next batch
 constexpr size_t ZB_TAIL = (size_t)1 << 20;                  // bytes of a batch's end looked at for its last line end
 
@@ -903,9 +911,13 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
     uint32_t bs0 = 0, hs0 = 0;
     if (!tdhost::GzSource::bgzf_header(src.map, src.bsize, &bs0, &hs0)) { *not_bgzf = true; return TD_OK; }
     const size_t out_cap = (size_t)ZB_MEMBERS * 65536 + ZB_CARRY + 4096;
+    for (auto &zp : h->zpiece) {
+        if (zp.pin) continue;
+        HIPCHK(hipHostMalloc((void **)&zp.pin, ZB_PIECE + 64, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&zp.sent, hipEventDisableTiming));
+    }
     for (auto &z : h->zslot) {
-        if (z.pin) continue;
-        HIPCHK(hipHostMalloc((void **)&z.pin, ZB_IN + 64, hipHostMallocDefault));
+        if (z.d_in) continue;
         HIPCHK(hipMalloc((void **)&z.d_in, ZB_IN + 64));
         HIPCHK(hipMalloc((void **)&z.d_out, out_cap));
         HIPCHK(hipHostMalloc((void **)&z.pin_mem, (size_t)ZB_MEMBERS * sizeof(tdinf::Member), hipHostMallocDefault));
@@ -917,11 +929,14 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
     }
     if (!h->d_zscratch) HIPCHK(hipMalloc((void **)&h->d_zscratch, (size_t)ZB_MEMBERS * tdinf::SCRATCH_BYTES));
     if (!h->d_crctab) {
-        uint32_t T[256];
+        uint32_t T[1024];                                        // slicing-by-4: T[256 k + b] = CRC of byte b followed by k zero bytes
         for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; T[i] = c; }
+        for (uint32_t k = 1; k < 4; k++)
+            for (uint32_t i = 0; i < 256; i++) T[256 * k + i] = T[T[256 * (k - 1) + i] & 0xFFu] ^ (T[256 * (k - 1) + i] >> 8);
         HIPCHK(hipMalloc((void **)&h->d_crctab, sizeof(T)));
         HIPCHK(hipMemcpy(h->d_crctab, T, sizeof(T), hipMemcpyHostToDevice));
     }
+    HIPCHK(hipFuncSetAttribute((const void *)tdinf::k_bgzf_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * tdinf::TABLE_U16 * 2 + 4096));
     HIPCHK(hipMemsetAsync(h->d_cursor.p, 0, 16, h->work_stream));
     struct Batch { uint32_t n = 0; size_t out_total = 0; bool last = false; };
     size_t pos = 0;
@@ -945,9 +960,18 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
         }
         b.last = pos >= src.bsize;
         const size_t nin = pos - first;
-        if (nin) stage_parallel(nin, [&](size_t off, size_t len) { memcpy(z.pin + off, src.map + first + off, len); return true; });
-        memset(z.pin + nin, 0, 64);
-        HIPCHK(hipMemcpyAsync(z.d_in, z.pin, nin + 64, hipMemcpyHostToDevice, h->copy_stream));
+        // the compressed bytes, through the two pinned pieces in turn (+ 64 zero bytes: the decoder reads a little ahead)
+        int k = 0;
+        for (size_t off = 0; off < nin + 64; off += ZB_PIECE, k ^= 1) {
+            td_handle::ZPiece &zp = h->zpiece[k];
+            if (zp.busy) { HIPCHK(hipEventSynchronize(zp.sent)); zp.busy = false; }
+            const size_t want = std::min(ZB_PIECE, nin + 64 - off), have = off < nin ? std::min(want, nin - off) : 0;
+            if (have) stage_parallel(have, [&](size_t o2, size_t len) { memcpy(zp.pin + o2, src.map + first + off + o2, len); return true; });
+            if (want > have) memset(zp.pin + have, 0, want - have);
+            HIPCHK(hipMemcpyAsync(z.d_in + off, zp.pin, want, hipMemcpyHostToDevice, h->copy_stream));
+            HIPCHK(hipEventRecord(zp.sent, h->copy_stream));
+            zp.busy = true;
+        }
         if (b.n) HIPCHK(hipMemcpyAsync(z.d_mem, z.pin_mem, (size_t)b.n * sizeof(tdinf::Member), hipMemcpyHostToDevice, h->copy_stream));
         HIPCHK(hipEventRecord(z.copied, h->copy_stream));
         return TD_OK;
@@ -962,7 +986,7 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
         td_handle::ZSlot &z = h->zslot[slot];
         HIPCHK(hipStreamWaitEvent(h->work_stream, z.copied, 0));
         if (cur.n) {
-            hipLaunchKernelGGL(tdinf::k_bgzf_inflate, dim3((cur.n + 63) / 64), dim3(64), 64 * tdinf::TABLE_U16 * 2, h->work_stream,
+            hipLaunchKernelGGL(tdinf::k_bgzf_inflate, dim3((cur.n + 63) / 64), dim3(64), 64 * tdinf::TABLE_U16 * 2 + 4096, h->work_stream,
                                z.d_in, z.d_out + carry, z.d_mem, cur.n, h->d_zscratch, z.d_status, h->d_crctab, (uint32_t)h->gpu_inflate_crc);
             HIPCHK(hipGetLastError());
         }
