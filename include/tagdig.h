@@ -104,7 +104,8 @@ int td_count_device(td_handle *h, const void *d_fastq, uint64_t nbytes,
 
 /* Same for a host buffer: staged through pinned memory in pieces cut at line
  * ends, copies overlapped with counting.  Synchronous.  *lines_out (optional)
- * receives the number of lines consumed. */
+ * receives the number of lines consumed; like the reference's loop (:272) the
+ * input stops being consumed soon after read number max_reads. */
 int td_count_host(td_handle *h, const void *fastq, uint64_t nbytes,
                   uint64_t first_line, uint64_t max_reads, int weights, uint64_t *lines_out);
 

@@ -533,28 +533,32 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                 // (a line that starts in the tile's last bytes is still whole in the staged window: the halo
                 // holds 16 NQ bytes and more)
                 const uint32_t k = line_prepare<W, NQ>(p, cx, L_raw, srel, pd);
+                // k: 0 no barcode, 2 barcode only, 1 pending (bucket in flight), 6 leading blank (rare: raw bytes re-read)
+                st_reads += k != 6u ? 1 : 0;
+                st_bar += k == 2u ? 1 : 0;
                 if (k == 1u) {
-                    if (PIPE && j + FBLOCK >= nwant) pd_valid = true;
+                    if (PIPE && j + FBLOCK >= nwant) { pd_valid = true; st_reads -= 1; }     // (counted when it is finished)
                     else {
                         bool h; uint32_t c;
+                        st_reads -= 1;
                         finish_pending(h, c);
                         hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
                         vm_settled();
                     }
-                } else if (__builtin_expect(k == 6u, 0)) {
-                    const uint64_t res = match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true);
-                    const uint32_t kind = (uint32_t)(res >> 62);
-                    st_reads += 1;
-                    if (kind >= 1) st_bar += 1;
-                    if (kind == 2) {
-                        st_tag += 1;
-                        if (!(p.dbg & DBG_NO_ATOMIC))
-                            __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (__builtin_expect(__any(k == 6u), 0)) {
+                    if (k == 6u) {
+                        const uint64_t res = match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true);
+                        const uint32_t kind = (uint32_t)(res >> 62);
+                        st_reads += 1;
+                        if (kind >= 1) st_bar += 1;
+                        if (kind == 2) {
+                            st_tag += 1;
+                            if (!(p.dbg & DBG_NO_ATOMIC))
+                                __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                     vm_settled();
-                } else {
-                    st_reads += 1;
-                    if (k == 2u) st_bar += 1;
                 }
             }
         }

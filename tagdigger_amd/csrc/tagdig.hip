@@ -766,8 +766,11 @@ struct Stager {
     uint64_t first_line = 0;
     uint64_t bytes_submitted = 0;             // every line holds >= 1 byte: bounds the line index from above
     unsigned pieces = 0;
+    unsigned long long *lines_after = nullptr;   // pinned: line terminators counted up to and including buffer i's piece
+    uint64_t lines_seen = 0;                     // ... of the newest piece known to have drained (a lower bound of the cursor)
     int init(td_handle *hh, size_t capacity, uint64_t first) {
         h = hh; cap = capacity; first_line = first;
+        HIPCHK(hipHostMalloc((void **)&lines_after, NB * sizeof(unsigned long long), hipHostMallocDefault));
         for (int i = 0; i < NB; i++) {
             HIPCHK(hipHostMalloc((void **)&pin[i], cap, hipHostMallocDefault));
             HIPCHK(hipMalloc((void **)&dev[i], cap));
@@ -778,6 +781,7 @@ struct Stager {
         return TD_OK;
     }
     ~Stager() {
+        if (lines_after) (void)hipHostFree(lines_after);
         for (int i = 0; i < NB; i++) {
             if (pin[i]) (void)hipHostFree(pin[i]);
             if (dev[i]) (void)hipFree(dev[i]);
@@ -787,7 +791,7 @@ struct Stager {
     }
     // buffer to fill next (waits until its previous use has drained)
     int acquire(uint8_t **p) {
-        if (busy[cur]) { HIPCHK(hipEventSynchronize(done[cur])); busy[cur] = false; }
+        if (busy[cur]) { HIPCHK(hipEventSynchronize(done[cur])); busy[cur] = false; lines_seen = lines_after[cur]; }
         *p = pin[cur];
         return TD_OK;
     }
@@ -803,6 +807,7 @@ struct Stager {
                               first_line + bytes_submitted);
         if (rc) return rc;
         bytes_submitted += n;
+        HIPCHK(hipMemcpyAsync(lines_after + cur, h->d_cursor.p + ((pieces + 1) & 1), 8, hipMemcpyDeviceToHost, h->work_stream));
         HIPCHK(hipEventRecord(done[cur], h->work_stream));
         busy[cur] = true;
         pieces++;
@@ -867,8 +872,12 @@ int pump(td_handle *h, Reader &&reader, uint64_t size_hint, uint64_t first_line,
     int rc = st.init(h, cap, first_line); if (rc) return rc;
     std::vector<uint8_t> carry;
     bool eof = false;
+    // (reference :272: the loop ends at maxreads -- here the input stops being read once a drained piece's line
+    // index shows that the bound has been passed; the kernels ignore reads past it either way)
+    const uint64_t stop_line = max_reads >= (1ull << 60) ? ~0ull : 4 * (std::max<uint64_t>(1, max_reads) - 1) + 2;
     while (!eof) {
         uint8_t *buf; rc = st.acquire(&buf); if (rc) return rc;
+        if (first_line + st.lines_seen >= stop_line) break;
         size_t have = carry.size();
         if (have) memcpy(buf, carry.data(), have);
         carry.clear();

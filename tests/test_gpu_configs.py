@@ -157,6 +157,26 @@ def test_config3_shape_through_the_file_path(eng, tmp_path, kind):
     os.unlink(path)
 
 
+@pytest.mark.parametrize("kind,maxreads", [("plain", 150_001), ("gz", 150_001), ("plain", 1_999_999)])
+def test_file_path_stops_reading_after_maxreads(eng, tmp_path, kind, maxreads):
+    """maxreads inside the first of 14 staged pieces, and one read before the end: the host stops reading the file
+    once a drained piece's line index has passed the bound (reference :272 breaks its loop); same matrix and the
+    same three counters as the reference's loop either way."""
+    cfg, host, _, _ = shape("C3_384x100k")
+    ost = {}
+    want = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(host, maxreads=maxreads, stats=ost)
+    raw = host.tobytes()
+    path = str(tmp_path / ("c3.fq" if kind == "plain" else "c3.fq.gz"))
+    with open(path, "wb") as fh:
+        fh.write(raw if kind == "plain" else gzip.compress(raw, compresslevel=1))
+    del raw
+    eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+    eng.count_file(path, maxreads=maxreads)
+    check(eng, want, ost, (kind, maxreads))
+    assert ost["reads"] == maxreads
+    os.unlink(path)
+
+
 def test_config5_count_and_trim_over_one_buffer(eng):
     """BASELINE config 5 as SURVEY App. B writes it: degenerate cut site, barcodes of 4-10 bp, 5 % tri-allelic markers
     expanded by readTags_Merged, the common cutter's adapter read through in 20 % of the tag-bearing reads -- the
