@@ -2,8 +2,13 @@
 
 `find_tags_fastq` has the reference's signature, defaults, return type and
 exceptions (tagdigger_fun.py:192-277) but its record loop runs on an MI355X.
-The index primitives it is built from are re-exported under their reference
-names so that code written against the reference module keeps working.
+Of the primitives under it, `enumerate_cut_sites` and `combine_barcode_and_cutsite`
+(reference :136-190, :60-69) are exported under their reference names.  The
+reference's nested-list trees (`build_sequence_tree` / `sequence_index_lookup`,
+:71-134) have no counterpart here: their rules live in the flat device index that
+`Engine.set_index` builds (csrc/tagdig.hip, td_set_index) and in the matching
+kernels; a restatement of the two functions exists only as test infrastructure
+(oracle/).
 """
 from .engine import (Engine, default_engine, enumerate_cut_sites,  # noqa: F401
                      combine_barcode_and_cutsite, effective_maxreads)
