@@ -298,6 +298,23 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes},
             "check": check,
         }
+        if world == 1 and not args.debug_ablate:
+            # the same pass with the reference's progress counters kept per window of 50 000 reads (find_tags_fastq's
+            # default here, reference :268-271) -- untimed above, reported beside it
+            eng.set_option("progress", 1)
+            eng.set_option("timing", 1)
+            counts.zero_()
+            eng.reset()
+            for _ in range(3):
+                step()
+            fence()
+            pk = eng.kernel_times_ms()
+            win = eng.progress_windows()
+            pst = eng.stats()
+            out["progress_windows"] = {"kernel_ms": sum(pk) / len(pk) if pk else None, "windows": len(win),
+                                       "sums_equal_counters": (sum(a for a, _ in win), sum(b for _, b in win)) == (pst["barcut"], pst["tag"])}
+            eng.set_option("timing", 0)
+            eng.set_option("progress", 0)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample, my_reads), min(args.cpu_python_sample, my_reads))
         if world == 1 and args.tier_reads > 0 and not args.debug_ablate:

@@ -168,6 +168,14 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
 int td_get_counts(td_handle *h, uint64_t *out_rows_by_cols);   /* barnum*ntags, row-major */
 int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
 
+/* The reference prints its three counters every 50 000 reads (tagdigger_fun.py:268-271).  With
+ * td_set_option(h, "progress", 1) set before counting, the device keeps, per window of 50 000 consecutive reads
+ * (read ordinals of the whole stream, across streamed pieces), how many reads had a barcode + cut site and how
+ * many a tag; this returns them: out[2 w] = barcutcount and out[2 w + 1] = tagcount of the reads in window w,
+ * for w < min(*nwindows, cap), where *nwindows = ceil(reads / 50 000).  Running sums over w give the numbers the
+ * reference prints after read 50 000 (w + 1).  Cumulative since td_reset; synchronises like td_get_stats. */
+int td_get_progress(td_handle *h, uint64_t *out, uint64_t cap, uint64_t *nwindows);
+
 /* K3 of SURVEY 8e: add this library's barcode rows into the run's sample rows on the device --
  * d_dst[row_of_barcode[b]][c] += counts[b][c] for the handle's barnum x ntags uint32 matrix (bound or internal);
  * d_dst is n_dst_rows x ntags uint32 in device memory (e.g. the torch tensor that is all-reduced over RCCL

@@ -44,7 +44,11 @@ struct FParams {
     uint4 *fixlist;          // [fix_cap]
     uint32_t *nfix;
     uint32_t fix_cap;
+    // progress windows (KParams::win): per tile, PROG_SLOTS x {which of the 64 wanted lines of a phase-D pass had a
+    // barcode, which a tag} as the main pass (k_fast2) saw them; k_resolve adds up the tiles whose phase was right
+    uint4 *prog_bits;
 };
+constexpr uint32_t PROG_SLOTS = 8;              // wanted lines per tile the main pass records: 64 x this
 
 // Wave priority per phase (KParams::prio: bits 1:0 phase A and the tile's end, 3:2 phases B-C,
 // 5:4 phase D, 7:6 the end of phase A: pending line, next tile's loads).  The short, serial,
@@ -384,9 +388,9 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
             const bool own_first = t == 0 && tid == 0 && p.nbytes > 0 && r0 == 3u;
             // General enumeration of this thread's q-th wanted line (limit-aware); the common case
             // -- no limit, at most one wanted line in the span -- never calls it.
-            auto nth_wanted = [&](uint32_t q, uint32_t &out) -> bool {
+            auto nth_wanted = [&](uint32_t q, uint32_t &out, uint64_t &line) -> bool {
                 uint32_t seen = 0;
-                if (own_first && (!use_limit || first_line + P <= p.limit_line)) { if (q == 0) { out = 0; return true; } seen = 1; }
+                if (own_first && (!use_limit || first_line + P <= p.limit_line)) { if (q == 0) { out = 0; line = first_line + P; return true; } seen = 1; }
                 uint32_t i = excl;
 #pragma unroll
                 for (int k = 0; k < CPT / 2; k++) {
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
                         const uint32_t sr = span0 + 32u * k + bit + 1u;
                         if ((i & 3u) == r0 && tbase + sr < p.nbytes &&
                             (!use_limit || first_line + P + i + 1 <= p.limit_line)) {
-                            if (seen == q) { out = sr; return true; }
+                            if (seen == q) { out = sr; line = first_line + P + i + 1; return true; }
                             seen++;
                         }
                         i++;
@@ -406,8 +410,9 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
                 return false;
             };
             if (p.dbg & DBG_NO_PHASE2) nw = 0;
-            auto commit = [&](uint64_t res) {
+            auto commit = [&](uint64_t res, uint64_t line) {
                 const uint32_t kind = (uint32_t)(res >> 62);
+                if (FIX && p.win && sign > 0) win_add(p, line >> 2, kind);       // (sequence line L is read L >> 2)
                 st_reads += sign;
                 if (kind >= 1) st_bar += sign;
                 if (kind == 2) {
@@ -460,15 +465,17 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
                     const uint32_t srel = L_list[j];
                     // (a 32-bit status: 1 pending, 0 no barcode, 2 barcode only, 6 raw bytes needed)
                     const uint32_t k = (uint32_t)(match_prepare<W, ML_FAST>(p, cx, tbase + srel, srel, false, pd) >> 61);
+                    const uint64_t line = first_line + P + r0 + 4u * j + 1u;     // (P: fix-up pass only)
                     if (k == 1u) {
                         if (PIPE && j + FBLOCK >= nwant) pd_valid = true;
-                        else { commit(match_finish<W>(p, pd)); vm_settled(); }
+                        else { commit(match_finish<W>(p, pd), line); vm_settled(); }
                     } else if (__builtin_expect(k == 6u, 0)) {
                         // cold: needs its raw bytes (leading blanks to strip, a first byte that is not a
                         // base; a non-blank non-base first byte simply comes back as "no barcode")
-                        commit(match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true));
+                        commit(match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true), line);
                         vm_settled();
                     } else {
+                        if (FIX && p.win && sign > 0 && k == 2u) win_add(p, line >> 2, 1u);
                         st_reads += sign;
                         if (k == 2u) st_bar += sign;
                     }
@@ -481,10 +488,11 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
 #pragma nounroll
                 for (uint32_t q = 0;; q++) {
                     uint32_t srel = 0;
-                    if (!nth_wanted(q, srel)) break;
+                    uint64_t line = 0;
+                    if (!nth_wanted(q, srel, line)) break;
                     const uint32_t c0f = srel >> 4;
                     const bool deferred = c0f + p.nch > win_ch || ((L_conv[c0f].y >> (srel & 15u)) & 1u);
-                    commit(match_line<W, ML_BOTH>(p, cx, tbase + srel, srel, deferred));
+                    commit(match_line<W, ML_BOTH>(p, cx, tbase + srel, srel, deferred), line);
                 }
                 vm_settled();
             }
@@ -591,6 +599,37 @@ __global__ __launch_bounds__(1024) void k_resolve(const FParams fp, const unsign
     if (i == p.ntiles - 1) {
         atomicAdd(p.stats + ST_LINES, P + v);
         if (p.cursor_out) *p.cursor_out = carried + P + v;
+    }
+    // Progress windows: the tiles the main pass counted under the right phase (nothing queued for them above) hand
+    // in what it recorded per wanted line; wanted line j of tile i is read (first_line + P + truth + 1) / 4 + j.
+    // The 64 tiles of a wave are neighbours: their reads fall into one or two windows -- two atomics per wave.
+    if (p.win && fp.prog_bits) {                                    // (uniform)
+        const uint32_t truth = (4u - (uint32_t)((first_line + P) & 3)) & 3u;
+        const bool mine = i < p.ntiles && !(info & TI_SKIP) && ((info >> TI_R0_SHIFT) & 3u) == truth &&
+                          !(finite && first_line + P + v > p.limit_line);
+        const uint64_t rid0 = (first_line + P + truth + 1) >> 2;
+        const uint32_t nwant = mine ? ((uint32_t)v + 3u - truth) >> 2 : 0u;
+        const uint64_t wb = wave_min64(nwant ? rid0 / PROG_WINDOW : ~0ull);
+        unsigned long long a = 0, b = 0;
+        auto add = [&](uint64_t w, uint64_t bar, uint64_t tag) {
+            const unsigned long long pk = (unsigned long long)__builtin_popcountll(bar) | ((unsigned long long)__builtin_popcountll(tag) << 32);
+            if (w == wb) a += pk;
+            else if (w == wb + 1) b += pk;
+            else if (pk && w < p.win_cap) atomicAdd(p.win + w, pk);
+        };
+        for (uint32_t sl = 0; sl * 64u < nwant; sl++) {
+            const uint4 q = fp.prog_bits[(size_t)i * PROG_SLOTS + sl];
+            const uint64_t bar = ((uint64_t)q.y << 32) | q.x, tag = ((uint64_t)q.w << 32) | q.z;
+            const uint64_t r = rid0 + 64u * sl, wl = r / PROG_WINDOW, nlow = (wl + 1) * PROG_WINDOW - r;
+            const uint64_t low = nlow >= 64 ? ~0ull : (1ull << nlow) - 1ull;
+            add(wl, bar & low, tag & low);
+            if (nlow < 64) add(wl + 1, bar & ~low, tag & ~low);
+        }
+        a = wave_sum64(a); b = wave_sum64(b);
+        if (lane == 0 && wb != ~0ull) {
+            if (a && wb < p.win_cap) atomicAdd(p.win + wb, a);
+            if (b && wb + 1 < p.win_cap) atomicAdd(p.win + wb + 1, b);
+        }
     }
 }
 

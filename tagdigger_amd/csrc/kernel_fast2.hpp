@@ -222,7 +222,7 @@ template <int CPT> struct Fast2Waves { static constexpr int value = TD_FAST2_WAV
 // publishes raw bytes, lists, totals and votes; after it wanted line j of the tile -- the line behind the
 // terminator with in-tile ordinal r0 + 4 j -- is found by three compares against the waves' running totals
 // and matched by thread j (full lanes).  Two barriers per tile (that one, and the one that frees the LDS).
-template <int CPT, int W, int NQ>
+template <int CPT, int W, int NQ, bool PROG>
 __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const FParams fp) {
     const KParams &p = fp.k;
     constexpr int TILE_CH = CPT * FBLOCK;
@@ -261,6 +261,14 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
     constexpr bool PIPE = W <= 3;
     Pending<W> pd;
     bool pd_valid = false;
+    // progress windows: what the pass a pending line belongs to has seen so far, and where its record goes
+    constexpr bool prog = PROG;                             // (its own instantiation: the record keeping costs registers)
+    uint64_t pd_bar = 0, pd_tag = 0;
+    uint32_t pd_rec = 0;
+    bool pd_pass = false;                                   // (wave-uniform) a pass's record waits for its pending lines
+    auto prog_store = [&](uint32_t rec, uint64_t bar, uint64_t tag) {
+        if (lane == 0) fp.prog_bits[rec] = make_uint4((uint32_t)bar, (uint32_t)(bar >> 32), (uint32_t)tag, (uint32_t)(tag >> 32));
+    };
     const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
     const uint64_t first_line = p.first_line + carried;
     const uint32_t nwork = p.ntiles;
@@ -292,6 +300,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         }
     };
     // one wanted line finished: statistics, and whether / where to count
+    bool phit_tag = false;                                  // the line finish_pending finished had a tag
     auto finish_pending = [&](bool &hit, uint32_t &cell) {
         vm_settled();
         const uint64_t res = match_finish<W>(p, pd);
@@ -299,6 +308,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         st_reads += 1;
         if (kind >= 1) st_bar += 1;
         if (kind == 2) st_tag += 1;
+        phit_tag = kind == 2;
         hit = kind == 2 && !(p.dbg & DBG_NO_ATOMIC);
         cell = (uint32_t)res;
     };
@@ -475,7 +485,11 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         const uint32_t nit = run_pos + 1u < RUN ? t + 1u : t + 1u + (gridDim.x - 1u) * RUN;      // next tile of this workgroup
         bool phit = false;
         uint32_t pcell = 0;
-        if (PIPE && pd_valid) { finish_pending(phit, pcell); pd_valid = false; }
+        {
+            bool tagged = false;
+            if (PIPE && pd_valid) { finish_pending(phit, pcell); pd_valid = false; tagged = phit_tag; }
+            if (prog && pd_pass) { prog_store(pd_rec, pd_bar, pd_tag | __ballot(tagged)); pd_pass = false; }
+        }
         TD_STAMP(3);   // pending line: wait for its bucket, compares
         if (nit < nwork) fetch_tile(nit);
         if (PIPE) {
@@ -513,7 +527,10 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         }
         const bool tile_has_hi = flg4.y != 0;
         const uint32_t nwant = (total + 3u - r0) >> 2;
-        const bool regular = t != 0 && (flg4.y | flg4.z | flg4.w) == 0 && tbase + TILE + halo <= p.nbytes;
+        // (with progress windows a tile's record holds 64 PROG_SLOTS wanted lines; more -- lines of a few bytes -- and
+        // the tile is left to the fix-up pass, which knows every line's number)
+        const bool regular = t != 0 && (flg4.y | flg4.z | flg4.w) == 0 && tbase + TILE + halo <= p.nbytes &&
+                             (!prog || nwant <= 64u * PROG_SLOTS);
         if (tid == 0)
             fp.tile_info[t] = total | (r0 << TI_R0_SHIFT) | (tile_has_hi ? TI_HI : 0u) | (regular ? 0u : TI_SKIP);
         TD_STAMP(6);   // C: phase
@@ -536,12 +553,15 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                 // k: 0 no barcode, 2 barcode only, 1 pending (bucket in flight), 6 leading blank (rare: raw bytes re-read)
                 st_reads += k != 6u ? 1 : 0;
                 st_bar += k == 2u ? 1 : 0;
+                bool barred = k == 1u || k == 2u, tagged = false;
+                const bool keep = PIPE && j + FBLOCK >= nwant;                   // (the same for every lane of the wave)
                 if (k == 1u) {
-                    if (PIPE && j + FBLOCK >= nwant) { pd_valid = true; st_reads -= 1; }     // (counted when it is finished)
+                    if (keep) { pd_valid = true; st_reads -= 1; }               // (counted when it is finished)
                     else {
                         bool h; uint32_t c;
                         st_reads -= 1;
                         finish_pending(h, c);
+                        tagged = phit_tag;
                         hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
                         vm_settled();
                     }
@@ -551,14 +571,23 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                         const uint64_t res = match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true);
                         const uint32_t kind = (uint32_t)(res >> 62);
                         st_reads += 1;
-                        if (kind >= 1) st_bar += 1;
+                        if (kind >= 1) { st_bar += 1; barred = true; }
                         if (kind == 2) {
                             st_tag += 1;
+                            tagged = true;
                             if (!(p.dbg & DBG_NO_ATOMIC))
                                 __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                     vm_settled();
+                }
+                if (prog) {
+                    // this pass is slot j / 64 of the tile's record (the same for every lane of the wave; the wave's
+                    // first lane holds its smallest j, so it is here whenever any lane is)
+                    const uint64_t bar_bits = __ballot(barred), tag_bits = __ballot(tagged);
+                    const uint32_t rec = t * PROG_SLOTS + (j >> 6);
+                    if (keep && __any(k == 1u)) { pd_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec); pd_bar = bar_bits; pd_tag = tag_bits; pd_pass = true; }
+                    else prog_store(rec, bar_bits, tag_bits);
                 }
             }
         }
@@ -582,10 +611,15 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         run_pos = run_pos + 1u < RUN ? run_pos + 1u : 0u;
         t = nit;
     }
-    if (PIPE && pd_valid) {
-        bool h; uint32_t c;
-        finish_pending(h, c);
-        hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
+    {
+        bool tagged = false;
+        if (PIPE && pd_valid) {
+            bool h; uint32_t c;
+            finish_pending(h, c);
+            tagged = phit_tag;
+            hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
+        }
+        if (prog && pd_pass) prog_store(pd_rec, pd_bar, pd_tag | __ballot(tagged));
     }
     if (p.hot_cache) hc_flush(p.counts, hcS, (uint32_t)lane);
 #ifdef TD_PHASE_PROF

@@ -100,7 +100,13 @@ struct KParams {
     uint32_t dbg;            // timing-only ablations (results wrong when nonzero); see DBG_*
     uint32_t hot_cache;      // k_fast2: count through the per-wave hot-cell cache in LDS
     uint32_t run;            // k_fast2: consecutive tiles per workgroup turn (the line phase is carried inside a run)
+    // progress windows (reference :268-271 prints its three counters every 50 000 reads): win[w] holds, for the
+    // reads with 0-based ordinal in [w, w + 1) * 50 000, how many had a barcode (low word) and a tag (high word);
+    // null = not wanted
+    unsigned long long *win;
+    uint32_t win_cap;
 };
+constexpr uint32_t PROG_WINDOW = 50000;
 
 // ---------------------------------------------------------------- small helpers
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
@@ -194,6 +200,29 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
+}
+__device__ __forceinline__ uint64_t wave_min64(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint64_t o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+    return v;
+}
+// One read (0-based ordinal ridx; kind 0 nothing, 1 barcode, 2 barcode and tag) into its progress window.
+__device__ __forceinline__ void win_add(const KParams &p, uint64_t ridx, uint32_t kind) {
+    const uint64_t w = ridx / PROG_WINDOW;
+    if (kind && w < p.win_cap) atomicAdd(p.win + w, 1ull | ((unsigned long long)(kind == 2) << 32));
+}
+// The same for the reads the lanes of a wave hold (every lane of the wave calls; `have` = this lane holds one): the
+// lanes' reads are neighbours in the file, so one or two windows take them all -- one atomic each.
+__device__ __forceinline__ void win_add_wave(const KParams &p, bool have, uint64_t ridx, uint32_t kind) {
+    uint64_t w = have && kind ? ridx / PROG_WINDOW : ~0ull;
+    for (int round = 0; round < 2; round++) {
+        const uint64_t w0 = wave_min64(w);
+        if (w0 == ~0ull) return;
+        const uint64_t sum = wave_sum64(w == w0 ? (1ull | ((unsigned long long)(kind == 2) << 32)) : 0ull);
+        if ((threadIdx.x & 63) == 0 && w0 < p.win_cap) atomicAdd(p.win + w0, (unsigned long long)sum);
+        if (w == w0) w = ~0ull;
+    }
+    if (w != ~0ull && w < p.win_cap) atomicAdd(p.win + w, 1ull | ((unsigned long long)(kind == 2) << 32));   // (lines of a few bytes)
 }
 
 // In-kernel phase stamps: a separate diagnostic build only (-DTD_PHASE_PROF, libtagdig_prof.so).
@@ -842,6 +871,11 @@ __global__ __launch_bounds__(BLOCK, TD_WAVES_PER_SIMD) void k_count(const KParam
             // ------------ commit the wanted lines of this batch
 #pragma unroll
             for (int k = 0; k < IPL; k++) {
+                if (p.win) {                                         // (uniform; the whole wave goes through it)
+                    const bool have = sr[k] < 0xFFFFFFFEu;
+                    // item e = b0 + IPL * tid + k is line first_line + P + e + 1 - extra; a sequence line L is read L >> 2
+                    win_add_wave(p, have, (first_line + P + b0 + IPL * tid + k + 1 - extra) >> 2, have ? (uint32_t)(res[k] >> 62) : 0u);
+                }
                 if (sr[k] >= 0xFFFFFFFEu) continue;                  // no item, or not a wanted line
                 st_reads++;
                 const uint32_t kind = (uint32_t)(res[k] >> 62);

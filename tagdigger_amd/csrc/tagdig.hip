@@ -157,6 +157,10 @@ struct td_handle {
     uint32_t *bound_counts = nullptr;
     bool used64 = false;
     DevBuf<unsigned long long> d_stats;       // TD_STAT_NSTATS
+    // progress windows (option "progress"): per 50 000 reads, how many had a barcode / a tag (reference :268-271)
+    int progress = 0;
+    DevBuf<unsigned long long> d_win;
+    DevBuf<uint4> d_progbits;                 // k_fast2's per-tile record of what its wanted lines matched
     std::vector<uint64_t> host_acc;           // flushed counts
     uint64_t bytes_since_flush = 0;
     // launch state
@@ -246,15 +250,17 @@ uint32_t fast2_pieces(int W, uint32_t need) {
     for (uint32_t o : opts[W - 1]) if (need <= o) return o;
     return opts[W - 1][2];
 }
-template <int CPT> FFn pick_fast2_c(int W, uint32_t nq) {
+template <int CPT, bool PROG> FFn pick_fast2_c(int W, uint32_t nq) {
     switch (W) {
-    case 1: return nq == 3 ? tdk::k_fast2<CPT, 1, 3> : nq == 4 ? tdk::k_fast2<CPT, 1, 4> : tdk::k_fast2<CPT, 1, 6>;
-    case 2: return nq == 5 ? tdk::k_fast2<CPT, 2, 5> : nq == 6 ? tdk::k_fast2<CPT, 2, 6> : tdk::k_fast2<CPT, 2, 8>;
-    default: return nq == 7 ? tdk::k_fast2<CPT, 3, 7> : nq == 8 ? tdk::k_fast2<CPT, 3, 8> : tdk::k_fast2<CPT, 3, 10>;
+    case 1: return nq == 3 ? tdk::k_fast2<CPT, 1, 3, PROG> : nq == 4 ? tdk::k_fast2<CPT, 1, 4, PROG> : tdk::k_fast2<CPT, 1, 6, PROG>;
+    case 2: return nq == 5 ? tdk::k_fast2<CPT, 2, 5, PROG> : nq == 6 ? tdk::k_fast2<CPT, 2, 6, PROG> : tdk::k_fast2<CPT, 2, 8, PROG>;
+    default: return nq == 7 ? tdk::k_fast2<CPT, 3, 7, PROG> : nq == 8 ? tdk::k_fast2<CPT, 3, 8, PROG> : tdk::k_fast2<CPT, 3, 10, PROG>;
     }
 }
-FFn pick_fast2(int tile_kb, int W, uint32_t nq) {
-    return tile_kb == 32 ? pick_fast2_c<8>(W, nq) : tile_kb == 24 ? pick_fast2_c<6>(W, nq) : pick_fast2_c<4>(W, nq);
+// (PROG: the instantiation that also records, per phase-D pass, which wanted lines matched -- progress windows)
+FFn pick_fast2(int tile_kb, int W, uint32_t nq, bool prog) {
+    if (prog) return tile_kb == 32 ? pick_fast2_c<8, true>(W, nq) : tile_kb == 24 ? pick_fast2_c<6, true>(W, nq) : pick_fast2_c<4, true>(W, nq);
+    return tile_kb == 32 ? pick_fast2_c<8, false>(W, nq) : tile_kb == 24 ? pick_fast2_c<6, false>(W, nq) : pick_fast2_c<4, false>(W, nq);
 }
 FFn pick_fix(int tile_kb, int W) {          // the fix-up pass shares the main pass's tile size
     if (tile_kb == 24) return pick_fast_w<6, true>(W);
@@ -294,6 +300,7 @@ int zero_results(td_handle *h) {
     if (h->d_counts.p) HIPCHK(hipMemsetAsync(h->d_counts.p, 0, (size_t)h->barnum * h->ntags * 4, h->work_stream));
     if (h->d_counts64.p) HIPCHK(hipMemsetAsync(h->d_counts64.p, 0, (size_t)h->barnum * h->ntags * 8, h->work_stream));
     HIPCHK(hipMemsetAsync(h->d_stats.p, 0, STATS_SLOTS * 8, h->work_stream));
+    if (h->d_win.p) HIPCHK(hipMemsetAsync(h->d_win.p, 0, h->d_win.n * 8, h->work_stream));
     HIPCHK(hipStreamSynchronize(h->work_stream));
     std::fill(h->host_acc.begin(), h->host_acc.end(), 0);
     h->bytes_since_flush = 0;
@@ -333,7 +340,9 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     const uint64_t fl_ub = std::max(first_line, first_line_ub);
     const bool limit_far = limit_line >= ~0ull - 16 || limit_line - std::min(limit_line, fl_ub) >= nbytes / 16;
     const bool counts32 = (uint64_t)h->barnum * h->ntags * 4 < h->fast_max_matrix;
-    const bool use_fast = h->fastpath && !tassel && !h->prescan && limit_far && counts32;
+    // progress windows are recorded by k_fast2 (+ k_resolve, fix-up pass) and by the exact kernel; not by k_fast's main pass
+    const bool use_fast = h->fastpath && !tassel && !h->prescan && limit_far && counts32 &&
+                          !(h->progress && (h->kernel_gen != 2 || h->W > 3));
     // its main pass: k_fast2 (raw tile in LDS, lines packed by the lane that matches them) where the tag width has
     // the pipelined probe and the tile fits the LDS budget, else k_fast
     const int tkb2 = h->tile_kb2 ? h->tile_kb2 : fast2_auto_tile(h);
@@ -376,6 +385,21 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
 
     p.hot_cache = (uint32_t)h->hot_cache;
     p.run = (uint32_t)h->run;
+    if (h->progress) {
+        // windows are indexed by the read's ordinal in the whole stream: a line holds a byte at least, a read four lines
+        const uint64_t need = (fl_ub + nbytes) / 4 / tdk::PROG_WINDOW + 2;
+        if (need > h->d_win.n) {
+            const size_t cap = (size_t)std::max<uint64_t>(need * 2, 1u << 16);
+            DevBuf<unsigned long long> bigger;
+            int rc = bigger.ensure(cap); if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipMemset(bigger.p, 0, cap * 8));
+            if (h->d_win.p) HIPCHK(hipMemcpy(bigger.p, h->d_win.p, h->d_win.n * 8, hipMemcpyDeviceToDevice));
+            h->d_win.release();
+            h->d_win = bigger;
+        }
+        p.win = h->d_win.p; p.win_cap = (uint32_t)std::min<size_t>(h->d_win.n, 0xFFFFFFFFu);
+    }
     if (use_fast) {
         int rc = h->d_tileinfo.ensure(ntiles); if (rc) return rc;
         const uint32_t fix_cap = 3u * ntiles + 8u;
@@ -395,8 +419,12 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
         }
         tdk::FParams fp{};
         fp.k = p; fp.tile_info = h->d_tileinfo.p; fp.fixlist = h->d_fixlist.p; fp.nfix = h->d_nfix.p; fp.fix_cap = fix_cap;
+        if (h->progress) {
+            rc = h->d_progbits.ensure((size_t)ntiles * tdk::PROG_SLOTS); if (rc) return rc;
+            fp.prog_bits = h->d_progbits.p;
+        }
         HIPCHK(hipMemsetAsync(h->d_nfix.p, 0, 4, stream));
-        FFn ffn = gen2 ? pick_fast2(tile_kb, h->W, h->nch2) : pick_fast(tile_kb, h->W, false), fixfn = pick_fix(tile_kb, h->W);
+        FFn ffn = gen2 ? pick_fast2(tile_kb, h->W, h->nch2, h->progress != 0) : pick_fast(tile_kb, h->W, false), fixfn = pick_fix(tile_kb, h->W);
         const size_t flds = gen2 ? lds_bytes_fast2(h, tile_kb) : lds_bytes_fast(h, tile_kb), fixlds = lds_bytes_fast(h, tile_kb);
         if (flds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
         if (fixlds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)fixfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fixlds));
@@ -569,6 +597,7 @@ void td_destroy(td_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
+    h->d_win.release(); h->d_progbits.release();
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
     h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release(); h->d_rowmap.release();
     for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -1130,6 +1159,24 @@ int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]) {
     return check_device_errors(h, st);
 }
 
+int td_get_progress(td_handle *h, uint64_t *out, uint64_t cap, uint64_t *nwindows) {
+    if (!h || !nwindows || (cap && !out)) return fail(TD_E_ARG, "NULL argument");
+    uint64_t st[TD_STAT_NSTATS];
+    int rc = td_get_stats(h, st);                         // (synchronises; raises what a kernel flagged)
+    if (rc) return rc;
+    if (!h->progress) return fail(TD_E_STATE, "option progress is off");
+    const uint64_t n = (st[TD_STAT_READS] + tdk::PROG_WINDOW - 1) / tdk::PROG_WINDOW;      // windows that hold a read
+    *nwindows = n;
+    const uint64_t take = std::min<uint64_t>(std::min(n, cap), h->d_win.n);
+    std::vector<unsigned long long> w(take);
+    if (take) HIPCHK(hipMemcpy(w.data(), h->d_win.p, take * 8, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < std::min(n, cap); i++) {
+        const unsigned long long v = i < take ? w[i] : 0ull;
+        out[2 * i] = v & 0xFFFFFFFFull; out[2 * i + 1] = v >> 32;
+    }
+    return TD_OK;
+}
+
 int td_get_counts(td_handle *h, uint64_t *out) {
     if (!h || !out) return fail(TD_E_ARG, "NULL argument");
     if (!h->have_index) return fail(TD_E_STATE, "td_set_index has not been called");
@@ -1182,6 +1229,7 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
         h->tile_kb2 = (int)value;
     } else if (n == "hot_cache") h->hot_cache = value ? 1 : 0;
     else if (n == "run") h->run = (int)std::max<int64_t>(1, std::min<int64_t>(value, 4096));
+    else if (n == "progress") h->progress = value ? 1 : 0;
     else if (n == "gpu_inflate") h->gpu_inflate = value ? 1 : 0;
     else if (n == "gpu_inflate_crc") h->gpu_inflate_crc = value ? 1 : 0;
     else if (n == "stagger") h->stagger = (int)value;

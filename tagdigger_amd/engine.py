@@ -234,6 +234,30 @@ class Engine:
         B.check(self._L.td_get_stats(self._h, st))
         return {"reads": st[0], "barcut": st[1], "tag": st[2], "lines": st[3]}
 
+    def progress_windows(self):
+        """[(reads with barcode + cut site, reads with tag)] per window of 50 000 reads, in read order (option
+        "progress" must have been on while counting); the last window may be partly filled."""
+        n = C.c_uint64(0)
+        B.check(self._L.td_get_progress(self._h, None, 0, C.byref(n)))
+        out = (C.c_uint64 * max(1, 2 * n.value))()
+        B.check(self._L.td_get_progress(self._h, out, n.value, C.byref(n)))
+        return [(out[2 * i], out[2 * i + 1]) for i in range(n.value)]
+
+    def progress_lines(self, fqfile):
+        """The lines the reference's loop prints while it reads (tagdigger_fun.py:268-271): the file name after
+        every 1 000 000 reads, the three counters after every 50 000."""
+        reads = self.stats()["reads"]
+        lines, bar, tag = [], 0, 0
+        for k, (b, t) in enumerate(self.progress_windows()):
+            done = 50000 * (k + 1)
+            if done > reads:
+                break
+            bar, tag = bar + b, tag + t
+            if done % 1000000 == 0:
+                lines.append(fqfile)
+            lines.append("Reads: {0} With barcode and cut site: {1} With tag: {2}".format(done, bar, tag))
+        return lines
+
     def counts_flat(self):
         out = (C.c_uint64 * max(1, self.barnum * self.ntags))()
         B.check(self._L.td_get_counts(self._h, out))

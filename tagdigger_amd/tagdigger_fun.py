@@ -8,7 +8,7 @@ reference's nested-list trees (`build_sequence_tree` / `sequence_index_lookup`,
 :71-134) have no counterpart here: their rules live in the flat device index that
 `Engine.set_index` builds (csrc/tagdig.hip, td_set_index) and in the matching
 kernels; a restatement of the two functions exists only as test infrastructure
-(oracle/).
+(the CPU checker beside the tests).
 """
 from .engine import (Engine, default_engine, enumerate_cut_sites,  # noqa: F401
                      combine_barcode_and_cutsite, effective_maxreads)
@@ -19,19 +19,26 @@ enzymes = {'ApeKI': 'CWGC', 'EcoT22I': 'TGCAT', 'NcoI': 'CATGG',
 
 
 def find_tags_fastq(fqfile, barcodes, tags, cutsite="TGCAG", maxreads=5e9, tassel_tagcount=False,
-                    device=0, as_array=False):
+                    device=0, as_array=False, progress=True):
     """Count barcode x tag combinations in one FASTQ file (plain or .gz by name).
 
     Returns list[list[int]] shaped [len(barcodes)][len(tags)], rows and columns
     in the order given -- exactly what the reference returns (tagdigger_fun.py
-    :237,:277).  Differences, all documented in DESIGN.md: no progress prints;
-    a sequence line holding a byte >= 0x80 raises NonAsciiSequence; an index
+    :237,:277) -- and prints the reference's progress lines (:268-271: the three
+    counters after every 50 000 reads, the file name after every 1 000 000; the
+    numbers are kept on the device per window of reads and printed once the file
+    is through; `progress=False` leaves them out).  Differences, all documented
+    in DESIGN.md: a sequence line holding a byte >= 0x80 raises NonAsciiSequence; an index
     whose first sequence is empty raises IndexError at build time (the
     reference raises at its first lookup).
     """
     eng = default_engine(device)
     eng.set_index(barcodes, tags, cutsite)          # asserts + index, before the file is opened (:198-233)
+    eng.set_option("progress", 1 if progress else 0)
     eng.count_file(fqfile, maxreads, tassel_tagcount)
+    if progress:
+        for line in eng.progress_lines(fqfile):
+            print(line)
     if as_array:                                    # (this build only: the matrix as a numpy array, no Python lists)
         return eng.counts_numpy(signed=bool(tassel_tagcount))
     return eng.counts(signed=bool(tassel_tagcount))
@@ -68,7 +75,8 @@ def find_tags_fastq_many(files, barcodes, tags, cutsite="TGCAG", maxreads=5e9, t
                 k = todo.pop(0)
             try:
                 results[k] = find_tags_fastq(files[k], barcodes[k] if per_file else barcodes, tags, cutsite=cutsite,
-                                             maxreads=maxreads, tassel_tagcount=tassel_tagcount, device=dev)
+                                             maxreads=maxreads, tassel_tagcount=tassel_tagcount, device=dev,
+                                             progress=False)        # (several files at once: no interleaved prints)
             except BaseException as exc:      # noqa: BLE001 -- reported to the caller below
                 errors[k] = exc
     threads = [threading.Thread(target=work, args=(d,)) for d in devs[1:]]

@@ -123,9 +123,12 @@ def test_cli_flag_rules():
 @pytest.mark.gpu
 def test_cli_end_to_end_gpu(tmp_path):
     """The drop-in command line on an MI355X: counts.csv and geno.csv byte-identical to the reference's."""
-    d, _ = _run_cli(tmp_path)
+    d, stdout = _run_cli(tmp_path)
     assert open(os.path.join(d, "counts.csv"), "rb").read() == base64.b64decode(CLI["counts_csv_b64"])
     assert open(os.path.join(d, "geno.csv"), "rb").read() == base64.b64decode(CLI["geno_csv_b64"])
+    # ... and its stdout line for line (a 3 000-read library: the reference prints no progress line here either;
+    # tests/test_progress.py compares those on longer inputs)
+    assert stdout.splitlines() == CLI["stdout"].splitlines()
 
 
 @pytest.mark.gpu

@@ -1,0 +1,169 @@
+"""Progress lines of find_tags_fastq (reference tagdigger_fun.py:268-271): the file name after every 1 000 000
+reads, `Reads: .. With barcode and cut site: .. With tag: ..` after every 50 000.  tests/golden/progress.json
+holds what the REAL reference printed (tests/golden/make_progress_golden.py) on four inputs that seeded
+generators rebuild here; the device keeps the two counters per window of 50 000 reads (td_get_progress)."""
+import contextlib
+import gzip
+import hashlib
+import io
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import DEFAULT_MODE, KERNEL_MODES, apply_mode, mode_id
+from oracle import c_oracle
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "progress.json")))
+_bytes = {}
+
+
+def case_bytes(case):
+    """The input the reference read, rebuilt from its recipe (checked against the recorded SHA-256)."""
+    if case["name"] not in _bytes:
+        r = case["recipe"]
+        if r["kind"] == "synth":
+            from tagdigger_amd.synth import SynthConfig
+            cfg = SynthConfig(**{k: tuple(v) if k == "bclen" else v for k, v in r["config"].items()})
+            assert cfg.barcodes == case["barcodes"] and cfg.tags == case["tags"]
+            raw = helpers.synth_host_bytes(cfg, 0, cfg.nreads).tobytes()
+        else:
+            rnd = random.Random(r["seed"])
+            barcodes, tags, cutsites = helpers.small_index(rnd, r.get("cutsite", "TGCAG"), nbar=r["nbar"], ntag=r["ntag"])
+            assert barcodes == case["barcodes"] and tags == case["tags"]
+            raw = helpers.dirty_fastq(rnd, barcodes, tags, cutsites, r["nrec"], nl_choices=tuple(r["nl_choices"]),
+                                      long_lines=r.get("long_lines", False), permanent_shifts=r.get("permanent_shifts", False))
+        assert hashlib.sha256(raw).hexdigest() == case["sha256"], "the generators drifted from the recorded input"
+        _bytes[case["name"]] = raw
+    return _bytes[case["name"]]
+
+
+def printed_numbers(case):
+    return [tuple(int(x) for x in ln.replace("Reads: ", "").replace(" With barcode and cut site: ", " ").replace(" With tag: ", " ").split())
+            for ln in case["stdout"] if ln.startswith("Reads: ")]
+
+
+@pytest.mark.parametrize("case", GOLD, ids=[c["name"] for c in GOLD])
+def test_oracle_counters_at_the_boundaries_equal_what_the_reference_printed(case):
+    """Pins the checker the other tests use: the C oracle stopped at read 50 000 k has the reference's printed counters."""
+    raw = case_bytes(case)
+    o = c_oracle.COracle(case["barcodes"], case["tags"], case["kwargs"]["cutsite"])
+    nums = printed_numbers(case)
+    for reads, bar, tag in nums[:: max(1, len(nums) // 3)] + nums[-1:]:
+        st = {}
+        o.count_bytes(raw, maxreads=reads, stats=st)
+        assert (st["reads"], st["barcut"], st["tag"]) == (reads, bar, tag)
+    assert [ln for ln in case["stdout"] if not ln.startswith("Reads: ")] == [case["file"]] * (nums[-1][0] // 1000000)
+
+
+MODES = [DEFAULT_MODE, KERNEL_MODES[2], KERNEL_MODES[1], KERNEL_MODES[3], KERNEL_MODES[5]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES, ids=mode_id)
+@pytest.mark.parametrize("case", GOLD, ids=[c["name"] for c in GOLD])
+def test_find_tags_fastq_prints_what_the_reference_prints(case, mode, tmp_path):
+    from tagdigger_amd import tagdigger_fun as tf
+    raw = case_bytes(case)
+    with open(tmp_path / case["file"], "wb") as fh:
+        fh.write(gzip.compress(raw, compresslevel=1) if case["file"].endswith("gz") else raw)
+    eng = tf.default_engine(0)
+    old = os.getcwd()
+    os.chdir(tmp_path)
+    out = io.StringIO()
+    try:
+        apply_mode(eng, mode)
+        with contextlib.redirect_stdout(out):
+            counts = tf.find_tags_fastq(case["file"], case["barcodes"], case["tags"], **case["kwargs"])
+    finally:
+        apply_mode(eng, DEFAULT_MODE)
+        os.chdir(old)
+    assert counts == case["counts"]
+    assert out.getvalue().splitlines() == case["stdout"]
+
+
+def boundary_stats(o, host, nreads):
+    want = []
+    for k in range(1, nreads // 50000 + 1):
+        st = {}
+        o.count_bytes(host, maxreads=50000 * k, stats=st)
+        want.append((st["barcut"], st["tag"]))
+    return want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [DEFAULT_MODE, KERNEL_MODES[1], KERNEL_MODES[5]], ids=mode_id)
+def test_windows_at_config3_shape(mode):
+    """384 barcodes x 100 000 tags, 420 000 reads resident in HBM, then the same bytes as a host buffer in staged
+    pieces: the running sums of the windows are the oracle's counters at every 50 000th read."""
+    import tagdigger_amd
+    from tagdigger_amd.synth import SynthConfig
+    cfg = SynthConfig.from_id(3, nreads=420_000)
+    host = helpers.synth_host_bytes(cfg, 0, cfg.nreads)
+    o = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite)
+    want = boundary_stats(o, host, cfg.nreads)
+    eng = tagdigger_amd.Engine(0)
+    try:
+        apply_mode(eng, mode)
+        eng.set_option("progress", 1)
+        eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        d = eng.dev_alloc(host.nbytes)
+        eng.h2d(d, host.tobytes())
+        for attempt in ("device", "host"):
+            eng.reset()
+            if attempt == "device":
+                eng.count_device(d, host.nbytes)
+            else:
+                eng.count_bytes(host)
+            w = eng.progress_windows()
+            assert len(w) == -(-cfg.nreads // 50000)
+            got = list(zip(np.cumsum([a for a, _ in w]).tolist(), np.cumsum([b for _, b in w]).tolist()))
+            assert got[:len(want)] == want, (attempt, mode)
+            st = eng.stats()
+            assert got[-1] == (st["barcut"], st["tag"])
+        eng.dev_free(d)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_windows_with_short_lines_and_a_bound(tmp_path):
+    """Reads of a dozen bases (more wanted lines in a tile than its record holds: the fix-up pass counts them), and a
+    maxreads bound inside the third staged piece of a larger file."""
+    import tagdigger_amd
+    rnd = random.Random(5)
+    barcodes, tags, cutsites = helpers.small_index(rnd, "TGCAG", nbar=6, ntag=30, taglens=(4, 9))
+    recs = []
+    for i in range(260_000):
+        b, t = rnd.choice(barcodes), rnd.choice(tags)
+        seq = (b + t) if rnd.random() < 0.7 else "".join(rnd.choice("ACGT") for _ in range(rnd.randint(1, 14)))
+        recs.append("@%d\n%s\n+\n%s\n" % (i, seq, "I" * len(seq)))
+    raw = "".join(recs).encode()
+    o = c_oracle.COracle(barcodes, tags, "TGCAG")
+    want = boundary_stats(o, raw, 260_000)
+    eng = tagdigger_amd.Engine(0)
+    try:
+        eng.set_option("progress", 1)
+        eng.set_index(barcodes, tags, "TGCAG")
+        eng.count_bytes(raw)
+        w = eng.progress_windows()
+        got = list(zip(np.cumsum([a for a, _ in w]).tolist(), np.cumsum([b for _, b in w]).tolist()))
+        assert got[:len(want)] == want
+        # a bound in a late piece of a 3-piece file
+        from tagdigger_amd.synth import SynthConfig
+        cfg = SynthConfig.from_id(2, nreads=400_000)
+        host = helpers.synth_host_bytes(cfg, 0, cfg.nreads)
+        path = str(tmp_path / "three_pieces.fq")
+        host.tofile(path)
+        o2 = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite)
+        want2 = boundary_stats(o2, host, 330_000)
+        eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        eng.count_file(path, maxreads=330_000)
+        lines = eng.progress_lines("three_pieces.fq")
+        assert lines == ["Reads: {0} With barcode and cut site: {1} With tag: {2}".format(50000 * (k + 1), a, b)
+                         for k, (a, b) in enumerate(want2)]
+    finally:
+        eng.close()
