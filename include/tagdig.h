@@ -161,6 +161,10 @@ int td_count_and_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes
  * (:1361-1362).  stats = reads, reads with barcode+cut site, reads clipped on the 3' end (:1359). */
 int td_split_file(td_handle *h, const char *in_path, const char *const *out_paths,
                   uint64_t max_reads, uint64_t stats[3]);
+/* What the splitter's loop prints every 50 000 reads (:1357-1360), for the last td_split_file of this handle:
+ * out[2 w] = reads with barcode + cut site, out[2 w + 1] = reads clipped on the 3' end, among the reads of
+ * window w (50 000 consecutive reads); *nwindows = ceil(reads / 50 000).  Running sums are the printed numbers. */
+int td_split_progress(td_handle *h, uint64_t *out, uint64_t cap, uint64_t *nwindows);
 
 /* ---- results ---------------------------------------------------------------
  * Both synchronise with all work enqueued through this handle first and

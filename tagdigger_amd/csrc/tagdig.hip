@@ -159,6 +159,7 @@ struct td_handle {
     DevBuf<unsigned long long> d_stats;       // TD_STAT_NSTATS
     // progress windows (option "progress"): per 50 000 reads, how many had a barcode / a tag (reference :268-271)
     int progress = 0;
+    std::vector<uint64_t> split_win;          // td_split_file's: {with barcode, clipped} per window of 50 000 reads
     DevBuf<unsigned long long> d_win;
     DevBuf<uint4> d_progbits;                 // k_fast2's per-tile record of what its wanted lines matched
     std::vector<uint64_t> host_acc;           // flushed counts
@@ -1177,6 +1178,14 @@ int td_get_progress(td_handle *h, uint64_t *out, uint64_t cap, uint64_t *nwindow
     return TD_OK;
 }
 
+int td_split_progress(td_handle *h, uint64_t *out, uint64_t cap, uint64_t *nwindows) {
+    if (!h || !nwindows || (cap && !out)) return fail(TD_E_ARG, "NULL argument");
+    const uint64_t n = h->split_win.size() / 2;
+    *nwindows = n;
+    for (uint64_t i = 0; i < std::min(n, cap) * 2; i++) out[i] = h->split_win[i];
+    return TD_OK;
+}
+
 int td_get_counts(td_handle *h, uint64_t *out) {
     if (!h || !out) return fail(TD_E_ARG, "NULL argument");
     if (!h->have_index) return fail(TD_E_STATE, "td_set_index has not been called");
@@ -1595,6 +1604,15 @@ struct SplitWriter {
     std::string comment1, sequence, comment2, quality;
     int cur_bar = -1, cur_slice = 999;
     bool stop = false, nonascii = false, io_error = false;
+    // progress windows (reference :1357-1360 prints its counters every 50 000 reads): of the reads this thread looked
+    // at for that purpose, per window of 50 000, how many had a barcode and how many were clipped
+    std::vector<uint64_t> wbar, wclip;
+    void note(uint64_t read0, bool clip) {
+        const size_t w = (size_t)(read0 / 50000);
+        if (w >= wbar.size()) { wbar.resize(w + 1, 0); wclip.resize(w + 1, 0); }
+        wbar[w]++;
+        if (clip) wclip[w]++;
+    }
 
     SplitWriter(SplitFiles &f, uint32_t t, uint32_t n) : files(f), barcodes(f.barcodes), out(f.out), pend(f.pend), tid(t), nthreads(n) {}
     bool mine() const { return cur_bar > -1 && files.owner[(size_t)cur_bar] == tid; }
@@ -1629,6 +1647,7 @@ struct SplitWriter {
         case 2: if (mine()) stripped(p, n, comment2, false); break;
         default: {
             reads++;
+            if (tid == 0 && cur_bar > -1) note(reads - 1, cur_slice != 999);      // (every thread sees this line: one notes it)
             if (mine()) {
                 stripped(p, n, quality, false);
                 barcut++;
@@ -1712,7 +1731,7 @@ struct SplitWriter {
             for (uint32_t o = 0; o < nthreads; o++) ix.bucket[(size_t)tid * nthreads + o].clear();
             for (size_t j = lo; j < hi; j++) {
                 const int b = res[j].x;
-                if (b > -1) ix.bucket[(size_t)tid * nthreads + files.owner[(size_t)b]].push_back((uint32_t)j);
+                if (b > -1) { ix.bucket[(size_t)tid * nthreads + files.owner[(size_t)b]].push_back((uint32_t)j); note(reads + j, res[j].y != 999); }
             }
             ix.barrier();
             for (uint32_t sc = 0; sc < nthreads; sc++)
@@ -2035,6 +2054,9 @@ int td_split_file(td_handle *h, const char *in_path, const char *const *out_path
     for (size_t k = 0; k < files.out.size(); k++) if (!w.flush(k)) io_error = true;
     for (FILE *&f : files.out) { if (f && fclose(f) != 0) io_error = true; f = nullptr; }
     for (auto &wr : writers) { io_error |= wr.io_error; n_barcut += wr.barcut; n_clipped += wr.clipped; }
+    h->split_win.assign(2 * (size_t)((w.reads + 49999) / 50000), 0);
+    for (auto &wr : writers)
+        for (size_t k = 0; k < wr.wbar.size() && 2 * k + 1 < h->split_win.size(); k++) { h->split_win[2 * k] += wr.wbar[k]; h->split_win[2 * k + 1] += wr.wclip[k]; }
     if (io_error && !rc) rc = fail(TD_E_IO, "error writing an output file");
     if (stats) { stats[0] = w.reads; stats[1] = n_barcut; stats[2] = n_clipped; }
     if (timing) fprintf(stderr, "td_split_file: read %.3f s, waiting for the GPU %.3f s, writing %.3f s (thread 0: line index %.3f s, records %.3f s)\n",

@@ -215,6 +215,23 @@ class Engine:
                                       effective_maxreads(maxreads), st))
         return st[0], st[1], st[2]
 
+    def split_progress_lines(self, in_path, reads):
+        """The lines barcodeSplitter's loop prints while it reads (tagdigger_fun.py:1357-1360), for the last split_file."""
+        n = C.c_uint64(0)
+        B.check(self._L.td_split_progress(self._h, None, 0, C.byref(n)))
+        out = (C.c_uint64 * max(1, 2 * n.value))()
+        B.check(self._L.td_split_progress(self._h, out, n.value, C.byref(n)))
+        lines, bar, clip = [], 0, 0
+        for k in range(n.value):
+            done = 50000 * (k + 1)
+            if done > reads:
+                break
+            bar, clip = bar + out[2 * k], clip + out[2 * k + 1]
+            if done % 1000000 == 0:
+                lines.append(in_path)
+            lines.append("Reads: {0} With barcode and cut site: {1} Clipped on 3' end: {2}".format(done, bar, clip))
+        return lines
+
     def count_lines_device(self, d_ptr, nbytes, stream=0):
         out = C.c_uint64(0)
         B.check(self._L.td_count_lines_device(self._h, C.c_void_p(d_ptr), nbytes,

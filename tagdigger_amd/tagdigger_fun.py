@@ -689,7 +689,7 @@ def barcodeSplitter(inputFile, barcodes, outputFiles, cutsite='TGCAG', adapter=a
     """Split one FASTQ file into one file per barcode, removing the barcode and, on the 3' end,
     anything from the first full restriction site or from an adapter that runs off the read
     (reference tagdigger_fun.py:1286-1368).  The per-read decisions are made on the GPU.
-    No progress lines are printed (the reference prints one every 50 000 reads)."""
+    The progress lines of the reference's loop (:1357-1360) are printed once the file is through."""
     assert set(cutsite) <= set('ACGT'), "Only ACGT cut sites allowed."
     assert all([set(bc) <= set('ACGT') for bc in barcodes]), "Found non-ACGT barcodes."
     assert len(adapter) == 2
@@ -714,7 +714,9 @@ def barcodeSplitter(inputFile, barcodes, outputFiles, cutsite='TGCAG', adapter=a
         open(inputFile, 'r').close()
     for name in outputFiles:
         open(name, mode='w').close()
-    eng.split_file(inputFile, outputFiles, maxreads)
+    reads, _, _ = eng.split_file(inputFile, outputFiles, maxreads)
+    for line in eng.split_progress_lines(inputFile, reads):
+        print(line)
     return None
 
 

@@ -54,6 +54,34 @@ def cases():
            dict(kind="dirty", seed=20261, cutsite="CWGC", nbar=10, ntag=40, nrec=110_000, nl_choices=["\n"], permanent_shifts=True))
 
 
+def splitter_case():
+    """barcodeSplitter (:1286-1368) prints its own progress lines (:1357-1360): 130 k reads of the synthetic stream with
+    adapter read-through on a fifth of them; the output files are recorded by their SHA-256."""
+    from tagdigger_amd.synth import SynthConfig
+    shape = dict(nbar=8, nmarkers=50, seed=909, cutsite="TGCAG", bclen=(4, 8), adapter_pct=20)
+    cfg = SynthConfig(nreads=130_000, **shape)
+    raw = helpers.synth_host_bytes(cfg, 0, cfg.nreads).tobytes()
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "lib_s.fq"), "wb") as fh:
+            fh.write(raw)
+        outs = ["split_%d.fq" % k for k in range(len(cfg.barcodes))]
+        old = os.getcwd()
+        os.chdir(d)
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                ref.barcodeSplitter("lib_s.fq", list(cfg.barcodes), outs, cutsite="TGCAG", adapter=ref.adapters["PstI-MspI-Hall"],
+                                    maxreads=120000)
+            sums = [hashlib.sha256(open(o, "rb").read()).hexdigest() for o in outs]
+        finally:
+            os.chdir(old)
+    lines = buf.getvalue().splitlines()
+    print("%-55s %8d bytes  %4d lines printed, last: %s" % ("splitter", len(raw), len(lines), lines[-1]))
+    return dict(name="splitter, 130 k reads, adapter read-through, maxreads 120 000", file="lib_s.fq", sha256=hashlib.sha256(raw).hexdigest(),
+                recipe=dict(kind="synth", config=dict(shape, nreads=cfg.nreads)), splitter=dict(adapter="PstI-MspI-Hall", maxreads=120000),
+                kwargs=dict(cutsite="TGCAG"), barcodes=list(cfg.barcodes), tags=list(cfg.tags), stdout=lines, outputs_sha256=sums)
+
+
 def main():
     out = []
     for name, fname, raw, barcodes, tags, kw, recipe in cases():
@@ -72,6 +100,7 @@ def main():
         print("%-55s %8d bytes  %4d lines printed, last: %s" % (name, len(raw), len(lines), lines[-1] if lines else ""))
         out.append(dict(name=name, file=fname, sha256=hashlib.sha256(raw).hexdigest(), recipe=recipe, kwargs=kw,
                         barcodes=list(barcodes), tags=list(tags), stdout=lines, counts=counts))
+    out.append(splitter_case())
     path = os.path.join(HERE, "progress.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=0, separators=(",", ":"))

@@ -17,7 +17,9 @@ import helpers
 from helpers import DEFAULT_MODE, KERNEL_MODES, apply_mode, mode_id
 from oracle import c_oracle
 
-GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "progress.json")))
+_ALL = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "progress.json")))
+GOLD = [c for c in _ALL if "splitter" not in c]
+SPLIT = [c for c in _ALL if "splitter" in c]
 _bytes = {}
 
 
@@ -167,3 +169,27 @@ def test_windows_with_short_lines_and_a_bound(tmp_path):
                          for k, (a, b) in enumerate(want2)]
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", SPLIT, ids=[c["name"] for c in SPLIT])
+def test_barcode_splitter_prints_what_the_reference_prints(case, tmp_path):
+    """barcodeSplitter's own progress lines (:1357-1360: counted by the writer threads per window of 50 000 reads) and,
+    while there, its output files at 120 000 reads (SHA-256 of what the reference wrote)."""
+    from tagdigger_amd import tagdigger_fun as tf
+    raw = case_bytes(case)
+    with open(tmp_path / case["file"], "wb") as fh:
+        fh.write(raw)
+    outs = ["split_%d.fq" % k for k in range(len(case["barcodes"]))]
+    old = os.getcwd()
+    os.chdir(tmp_path)
+    out = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(out):
+            tf.barcodeSplitter(case["file"], case["barcodes"], outs, cutsite=case["kwargs"]["cutsite"],
+                               adapter=tf.adapters[case["splitter"]["adapter"]], maxreads=case["splitter"]["maxreads"])
+        sums = [hashlib.sha256(open(o, "rb").read()).hexdigest() for o in outs]
+    finally:
+        os.chdir(old)
+    assert sums == case["outputs_sha256"]
+    assert out.getvalue().splitlines() == case["stdout"]
