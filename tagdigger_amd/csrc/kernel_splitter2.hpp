@@ -1,0 +1,315 @@
+// k_split2: the splitter's per-read branch (reference tagdigger_fun.py:1251-1283 and the loop at
+// :1328-1363) on the tile machinery of k_fast2 -- the tile's raw bytes staged in LDS, terminator masks and per-wave
+// lists of line starts built without a workgroup barrier, then ONE lane per sequence line (full lanes: the j-th
+// sequence line of the tile goes to thread j), which reads its line from LDS in unaligned 16-byte pieces:
+//   * barcode + cut site: the first 32 bases packed (pack16_ascii) and looked up in the LDS directory;
+//   * the first full restriction site behind them (str.find, :1263-1268): per piece one 16-bit mask per base
+//     letter, kept with the previous piece's in a 32-bit history word; a site ends where the shifted masks of its
+//     letters all have a bit -- sixteen text positions per handful of instructions instead of one;
+//   * else the adapter that runs off the read's end (:1269-1280), compared backwards from the read's last byte.
+// Line numbers are exact (the caller's prefix of terminators per tile), so no vote and no fix-up pass.  What does
+// not fit the fast form -- the buffer's first and last tiles, tiles holding bytes >= 0x80 or more line starts than a
+// wave's list holds, a line that ends behind the staged window -- goes through k_split's per-thread walk over global
+// memory (split_line), line by line or tile by tile.
+#pragma once
+#include "kernel_fast2.hpp"
+#include "kernel_splitter.hpp"
+
+namespace tdk {
+
+constexpr uint32_t SPLIT2_HALO = 512;       // bytes staged behind the tile (multiple of 64)
+
+// One sequence line whose bytes are raw[s0 .. nx - 1) (nx: start of the next line; all inside the staged window).
+__device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsigned long long *L_bval, const uint32_t *L_bmeta,
+                                               const uint16_t *L_bdir, const uint8_t *raw, uint32_t s0, uint32_t nx) {
+    // the terminator (one byte, or "\r\n") off the end, then line.strip(): blanks off both ends
+    uint32_t s = s0, e = nx - 1u;
+    if (e > s && raw[e] == 0x0Au && raw[e - 1] == 0x0Du) e--;
+    while (s < e && is_blank(raw[s])) s++;
+    while (e > s && is_blank(raw[e - 1])) e--;
+    const uint32_t len = e - s;
+    const uint8_t *src = raw + s;
+
+    // ---- barcode + cut site: the first (up to 32) valid bases, packed like the index
+    const uint4 q0 = lds_read16(src), q1 = lds_read16(src + 16);
+    const uint2 c0 = pack16_ascii(q0.x, q0.y, q0.z, q0.w), c1 = pack16_ascii(q1.x, q1.y, q1.z, q1.w);
+    const unsigned long long Kfull = ((unsigned long long)c0.x << 32) | c1.x;
+    const uint32_t invalid = (c0.y & 0xFFFFu) | (c1.y << 16);
+    uint32_t nvalid = invalid ? (uint32_t)__builtin_ctz(invalid) : 32u;
+    if (nvalid > len) nvalid = len;
+    const unsigned long long K = nvalid >= 32 ? Kfull : nvalid == 0 ? 0ull : Kfull & (~0ull << (64 - 2 * nvalid));
+    uint32_t ci = L_bdir[(uint32_t)(K >> (64 - 2 * BDIR_BASES))];
+    uint32_t meta = 0;
+    bool hit = false;
+    if (ci != 0xFFFFu) {
+        for (;;) {
+            const uint32_t m = L_bmeta[ci];
+            const uint32_t l = m & 63u;
+            if (l <= nvalid && ((K ^ L_bval[ci]) >> (64u - 2u * l)) == 0) { meta = m; hit = true; break; }
+            if (m & BMETA_LAST) break;
+            ci++;
+        }
+    }
+    if (!hit) return make_int2(-1, 999);
+    const uint32_t bar = meta >> 16;
+    const uint32_t start = ((meta >> 6) & 63u) + p.cutlen;           // searchstart = len(barcode) + len(cutsite)
+
+    // ---- first full restriction site at or after `start` (str.find)
+    uint32_t rs0 = 0xFFFFFFFFu, rs1 = 0xFFFFFFFFu;
+    if (start <= len) {
+        if (p.site0_len == 0) rs0 = start;                           // (an empty site is found at `start` itself)
+        if (p.site1_len == 0) rs1 = start;
+        uint32_t H[4] = {0u, 0u, 0u, 0u};                            // per letter A C T G: bits 16-31 this piece, 0-15 the one before
+        const uint32_t k0 = start >> 4;
+        for (uint32_t k = k0; 16u * k < len && (rs0 == 0xFFFFFFFFu || rs1 == 0xFFFFFFFFu); k++) {
+            uint4 v = lds_read16(src + 16u * k);
+            v.x &= 0xDFDFDFDFu; v.y &= 0xDFDFDFDFu; v.z &= 0xDFDFDFDFu; v.w &= 0xDFDFDFDFu;      // (a == A for the four letters)
+            // text positions of this piece that take part: start <= position < len
+            const uint32_t left = len - 16u * k, from = start > 16u * k ? start - 16u * k : 0u;
+            const uint32_t pm = (left >= 16u ? 0xFFFFu : (1u << left) - 1u) & (0xFFFFu << from);
+            const uint32_t m[4] = {eq_mask16_ascii(v, 0x41414141u, 0x7F7F7F7Fu), eq_mask16_ascii(v, 0x43434343u, 0x7F7F7F7Fu),
+                                   eq_mask16_ascii(v, 0x54545454u, 0x7F7F7F7Fu), eq_mask16_ascii(v, 0x47474747u, 0x7F7F7F7Fu)};
+#pragma unroll
+            for (int c = 0; c < 4; c++) H[c] = (H[c] >> 16) | ((m[c] & pm) << 16);
+#pragma unroll
+            for (int which = 0; which < 2; which++) {
+                const uint32_t L = which ? p.site1_len : p.site0_len;
+                const unsigned long long site = which ? p.site1 : p.site0;      // last character in the low byte
+                if (L == 0) continue;
+                uint32_t M = 0xFFFF0000u;
+                for (uint32_t back = 0; back < L; back++) {                       // (uniform: the sites are the launch's)
+                    const uint32_t ch = (uint32_t)(site >> (8u * back)) & 0xFFu; // the site's character `back` places before its last
+                    const uint32_t code = (ch >> 1) & 3u;                         // A C T G = 0 1 2 3
+                    const uint32_t h = code == 0 ? H[0] : code == 1 ? H[1] : code == 2 ? H[2] : H[3];
+                    M &= h << back;
+                }
+                const uint32_t ends = M >> 16;
+                if (ends) {
+                    const uint32_t at = 16u * k + (uint32_t)__builtin_ctz(ends) + 1u - L;     // where that site starts
+                    if (which) { if (rs1 == 0xFFFFFFFFu) rs1 = at; } else { if (rs0 == 0xFFFFFFFFu) rs0 = at; }
+                }
+            }
+        }
+    }
+    if (rs0 != 0xFFFFFFFFu || rs1 != 0xFFFFFFFFu) {
+        uint32_t cut;
+        if (rs1 == 0xFFFFFFFFu) cut = rs0 + p.site0_len;
+        else if (rs0 == 0xFFFFFFFFu) cut = rs1 + p.site1_len;
+        else if (rs0 < rs1) cut = rs0 + p.site0_len;
+        else cut = rs1 + p.site1_len;
+        return make_int2((int)bar, (int)cut);
+    }
+    // ---- no full site: does the read END with the start of an adapter?  Only the entries whose last base is the
+    // read's last base can match: they are stored together.
+    if (len == 0) return make_int2((int)bar, 999);
+    const uint32_t lastc = upper_ascii(raw[e - 1]);
+    const uint32_t lcode = (lastc >> 1) & 3u;
+    if (lastc != ((0x47544341u >> (8 * lcode)) & 0xFFu)) return make_int2((int)bar, 999);     // not a base: no entry ends with it
+    const uint32_t e0 = p.ent_group[4 * bar + lcode];
+    const uint32_t e1 = lcode == 3 ? p.ent_begin[bar + 1] : p.ent_group[4 * bar + lcode + 1];
+    int found = 999;
+    for (uint32_t k = e0; k < e1 && found == 999; k++) {
+        const uint4 ent = reinterpret_cast<const uint4 *>(p.entries)[k];     // {off, len, slice, -}
+        const uint32_t elen = ent.y;
+        if (elen > len || elen == 0) continue;
+        const uint8_t *a = p.pool + ent.x;
+        bool same = true;
+        for (uint32_t q = 1; q < elen && same; q++)                   // from the read's second-last character backwards
+            same = upper_ascii(raw[e - 1 - q]) == a[elen - 1 - q];
+        if (same) found = (int)ent.z;
+    }
+    return make_int2((int)bar, found);
+}
+
+template <int CPT>
+__global__ __launch_bounds__(FBLOCK, 4) void k_split2(const SplitParams p) {
+    constexpr int TILE_CH = CPT * FBLOCK;
+    constexpr uint32_t TILE = TILE_CH * 16;
+    constexpr uint32_t WCH = CPT * 64;
+    constexpr uint32_t WBYTES = WCH * 16;
+    constexpr uint32_t HALO = SPLIT2_HALO;
+    static_assert(FBLOCK == 256 && (CPT % 2) == 0, "256 threads, an even number of chunks per thread");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *L_raw = lds;
+    uint16_t *L_mask = reinterpret_cast<uint16_t *>(lds + TILE + HALO + 64);      // (64 spare bytes: a piece read past the window's end)
+    uint32_t *L_misc = reinterpret_cast<uint32_t *>(lds + TILE + HALO + 64 + TILE_CH * 2u);   // 64 dwords
+    uint8_t *L_bidx = reinterpret_cast<uint8_t *>(L_misc + 64);
+    const unsigned long long *L_bval = reinterpret_cast<const unsigned long long *>(L_bidx);
+    const uint32_t *L_bmeta = reinterpret_cast<const uint32_t *>(L_bidx + p.off_bmeta);
+    const uint16_t *L_bdir = reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir);
+    // L_misc: [1] a byte >= 0x80 in tile or halo, [2] a wave has more terminators than its list holds, [4..7] wave totals
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t i = tid; i < p.bblob_bytes / 4; i += FBLOCK) reinterpret_cast<uint32_t *>(L_bidx)[i] = p.bblob[i];
+    if (tid < 16) L_misc[tid] = 0;
+    // the buffer's r-th sequence line has global index seq0 + 4 r
+    const uint64_t seq0 = p.first_line + ((1 - (p.first_line & 3)) & 3);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t voff = (uint32_t)wave * WBYTES + (uint32_t)lane * 16u;
+    __syncthreads();
+
+    for (uint32_t t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        const uint64_t tbase = (uint64_t)t * TILE;
+        // ---------------- A: this wave's quarter: raw bytes and terminator masks -> LDS (bytes past the buffer read as zero)
+        const uint64_t rem = p.nbytes - tbase;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.buf + tbase), 0,
+                                                                           (int)(rem < (uint64_t)(TILE + HALO) ? rem : (uint64_t)(TILE + HALO)), 0x00020000);
+        uint4 v[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * 1024, 0);
+            v[j] = make_uint4(q.x, q.y, q.z, q.w);
+        }
+        uint4 vh = make_uint4(0u, 0u, 0u, 0u);
+        const bool has_halo = (uint32_t)tid < HALO / 16u;
+        if (has_halo) {
+            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)tid * 16u, (int)TILE, 0);
+            vh = make_uint4(q.x, q.y, q.z, q.w);
+        }
+        bool wave_crb = false;
+        {
+            uint32_t hiacc = vh.x | vh.y | vh.z | vh.w;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) hiacc |= v[j].x | v[j].y | v[j].z | v[j].w;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) *reinterpret_cast<uint4 *>(L_raw + voff + j * 1024) = v[j];
+            if (has_halo) *reinterpret_cast<uint4 *>(L_raw + TILE + (size_t)tid * 16u) = vh;
+            uint16_t *Lm = L_mask + wave * WCH + lane;
+            const bool general = __any((hiacc & 0x80808080u) != 0);
+            uint32_t crs = 0;
+            if (__builtin_expect(!general, 1)) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    const uint32_t nl = eq_mask16_ascii(v[j], 0x0A0A0A0Au, 0x7F7F7F7Fu), cr = eq_mask16_ascii(v[j], 0x0D0D0D0Du, 0x7F7F7F7Fu);
+                    Lm[j * 64] = (uint16_t)(nl | (cr & ~(nl >> 1)));      // (a '\r' in the chunk's last byte: settled in phase B)
+                    crs |= cr;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    const uint32_t nl = eq_mask16(v[j], 0x0A0A0A0Au), cr = eq_mask16(v[j], 0x0D0D0D0Du);
+                    Lm[j * 64] = (uint16_t)(nl | (cr & ~(nl >> 1)));
+                    crs |= cr;
+                }
+                if (hiacc & 0x80808080u) L_misc[1] = 1;
+            }
+            wave_crb = __any((crs & 0x8000u) != 0);
+        }
+        wave_lds_fence();
+
+        // ---------------- B: terminators of this thread's CPT consecutive chunks, wave scan, list of line starts
+        uint32_t mm[CPT / 2];
+#pragma unroll
+        for (int i = 0; i < CPT / 2; i++) mm[i] = reinterpret_cast<const uint32_t *>(L_mask)[tid * (CPT / 2) + i];
+        const uint32_t span0 = tid * CPT * 16u;
+        const uint32_t wend = ((uint32_t)wave + 1u) * WBYTES;
+        if (__builtin_expect(wave_crb, 0)) {
+            // a chunk whose last byte is '\r': one terminator with the '\n' that opens the next chunk, if there is one
+#pragma unroll
+            for (int i = 0; i < CPT / 2; i++) {
+#pragma unroll
+                for (int hbit = 15; hbit < 32; hbit += 16) {
+                    if ((mm[i] >> hbit) & 1u) {
+                        const uint32_t at = span0 + 32u * i + (uint32_t)hbit;
+                        if (L_raw[at] == 0x0Du) {
+                            // (the next byte may belong to another wave's quarter, or to the halo: not in LDS yet)
+                            const uint64_t g = tbase + at + 1u;
+                            const uint32_t nxb = at + 1u < wend ? (uint32_t)L_raw[at + 1u] : g < p.nbytes ? (uint32_t)p.buf[g] : 0u;
+                            if (nxb == 0x0Au) mm[i] &= ~(1u << hbit);
+                        }
+                    }
+                }
+            }
+            vm_settled();
+        }
+        // (bytes past the buffer's end were read as zeros: no terminators there)
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < CPT / 2; i++) cnt += __builtin_popcount(mm[i]);
+        const uint32_t incl = wave_incl_scan(cnt, lane);
+        {
+            uint16_t *Ll = L_mask + wave * WCH;
+            const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (__builtin_expect(wtot <= WCH, 1)) {
+                uint32_t k = incl - cnt;
+#pragma unroll
+                for (int i = 0; i < CPT / 2; i++) {
+                    uint32_t m = mm[i];
+                    while (m) {
+                        const uint32_t bit = __builtin_ctz(m);
+                        m &= m - 1;
+                        Ll[k] = (uint16_t)(span0 + 32u * i + bit + 1u);
+                        k++;
+                    }
+                }
+            }
+            if (lane == 63) {
+                L_misc[4 + wave] = incl;
+                if (incl > WCH) L_misc[2] = 1;
+            }
+        }
+        lds_barrier();
+
+        // ---------------- C: running totals, the tile's first line number
+        const uint4 tot4 = *reinterpret_cast<const uint4 *>(L_misc + 4);
+        const uint4 flg4 = *reinterpret_cast<const uint4 *>(L_misc);
+        const uint32_t wb1 = tot4.x, wb2 = wb1 + tot4.y, wb3 = wb2 + tot4.z, total = wb3 + tot4.w;
+        const uint64_t P = t ? (p.prefix[t - 1] & ~FLAG_INC) : 0ull;            // terminators before this tile
+        const uint32_t r0 = (4u - (uint32_t)((p.first_line + P) & 3)) & 3u;      // ordinals == r0 (mod 4) precede sequence lines
+        const uint32_t nwant = (total + 3u - r0) >> 2;
+        const bool regular = t != 0 && (flg4.y | flg4.z) == 0 && tbase + TILE + HALO <= p.nbytes;
+
+        if (__builtin_expect(regular, 1)) {
+            // ---------------- D: sequence line j of the tile -> thread j
+            const uint32_t j0 = ((uint32_t)tid + 64u * (t & 3u)) & (uint32_t)(FBLOCK - 1);
+#pragma nounroll
+            for (uint32_t j = j0; j < nwant; j += FBLOCK) {
+                const uint32_t o = r0 + 4u * j;
+                auto at = [&](uint32_t ord) -> uint32_t {
+                    uint32_t sel = 0u;
+                    sel = ord >= wb1 ? 1u * WCH - wb1 : sel;
+                    sel = ord >= wb2 ? 2u * WCH - wb2 : sel;
+                    sel = ord >= wb3 ? 3u * WCH - wb3 : sel;
+                    return L_mask[ord + sel];
+                };
+                const uint32_t srel = at(o);
+                uint32_t nx = 0;                                               // start of the next line (0: not inside the window)
+                if (o + 1u < total) nx = at(o + 1u);
+                else {
+                    // the tile's last line: its terminator lies in the halo, if the line is not longer than that
+                    for (uint32_t q = srel > TILE ? srel : TILE; q < TILE + HALO && nx == 0; q++) {
+                        const uint32_t ch = L_raw[q];
+                        if (ch == 0x0Au || ch == 0x0Du) nx = q + 1u;
+                    }
+                }
+                const uint64_t line = p.first_line + P + o + 1u;
+                int2 r;
+                if (nx != 0) r = split_line_lds(p, L_bval, L_bmeta, L_bdir, L_raw, srel, nx);
+                else r = split_line(p, L_bval, L_bmeta, L_bdir, tbase + srel);
+                p.out[(line - seq0) >> 2] = r;
+            }
+        } else {
+            // ---------------- cold: every thread walks the sequence lines that start in its own span (global memory)
+            uint32_t wbase = wave == 0 ? 0u : wave == 1 ? wb1 : wave == 2 ? wb2 : wb3;
+            uint64_t ord = P + wbase + incl - cnt;
+            if (t == 0 && tid == 0 && p.nbytes > 0 && (p.first_line & 3) == 1)
+                p.out[0] = split_line(p, L_bval, L_bmeta, L_bdir, 0);
+#pragma unroll
+            for (int k = 0; k < CPT / 2; k++) {
+                uint32_t m = mm[k];
+                while (m) {
+                    const uint32_t bit = __builtin_ctz(m);
+                    m &= m - 1;
+                    const uint64_t line = p.first_line + ord + 1;
+                    const uint64_t gpos = tbase + span0 + 32u * k + bit + 1u;
+                    ord++;
+                    if ((line & 3) == 1 && gpos < p.nbytes)
+                        p.out[(line - seq0) >> 2] = split_line(p, L_bval, L_bmeta, L_bdir, gpos);
+                }
+            }
+        }
+        if (tid == 0) { L_misc[1] = 0; L_misc[2] = 0; }
+        lds_barrier();                                    // LDS is reused by the next tile
+    }
+}
+
+}  // namespace tdk

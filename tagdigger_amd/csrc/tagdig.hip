@@ -23,6 +23,7 @@
 #include "kernel_fast.hpp"
 #include "kernel_fast2.hpp"
 #include "kernel_splitter.hpp"
+#include "kernel_splitter2.hpp"
 #include "gz_source.hpp"
 #include "gpu_inflate.hpp"
 
@@ -159,6 +160,8 @@ struct td_handle {
     DevBuf<unsigned long long> d_stats;       // TD_STAT_NSTATS
     // progress windows (option "progress"): per 50 000 reads, how many had a barcode / a tag (reference :268-271)
     int progress = 0;
+    int split_kernel = 2;                     // 2: k_split2 (tile in LDS), 1: k_split
+    bool sp_sites_acgt = false;
     std::vector<uint64_t> split_win;          // td_split_file's: {with barcode, clipped} per window of 50 000 reads
     DevBuf<unsigned long long> d_win;
     DevBuf<uint4> d_progbits;                 // k_fast2's per-tile record of what its wanted lines matched
@@ -1239,6 +1242,7 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     } else if (n == "hot_cache") h->hot_cache = value ? 1 : 0;
     else if (n == "run") h->run = (int)std::max<int64_t>(1, std::min<int64_t>(value, 4096));
     else if (n == "progress") h->progress = value ? 1 : 0;
+    else if (n == "split_kernel") h->split_kernel = value == 1 ? 1 : 2;
     else if (n == "gpu_inflate") h->gpu_inflate = value ? 1 : 0;
     else if (n == "gpu_inflate_crc") h->gpu_inflate_crc = value ? 1 : 0;
     else if (n == "stagger") h->stagger = (int)value;
@@ -1496,14 +1500,24 @@ int td_synth_expected_device(td_handle *h, const void *params, uint64_t first_re
 namespace {
 
 // line terminators before the end of every 16 KB tile -> d_state, their total -> d_cursor[0] (async on `s`)
+// k_split2 (24 KiB tiles staged in LDS) where the two restriction sites are spelled in ACGT and the index fits beside
+// the tile; k_split (16 KiB tiles, lines walked in global memory) otherwise, or on request (option split_kernel = 1)
+size_t lds_bytes_split2(const td_handle *h) {
+    return (size_t)24 * 1024 + tdk::SPLIT2_HALO + 64 + (size_t)6 * tdk::FBLOCK * 2 + 256 + h->sp_bblob_bytes;
+}
+bool use_split2(const td_handle *h) {
+    return h->split_kernel == 2 && h->sp_sites_acgt && lds_bytes_split2(h) <= (size_t)40 * 1024;
+}
+
 int launch_split_prefix(td_handle *h, const void *d_fastq, uint64_t nbytes, hipStream_t s) {
-    const uint64_t tile = 16 * 1024;
+    const uint64_t tile = use_split2(h) ? 24 * 1024 : 16 * 1024;
     const uint64_t nt = (nbytes + tile - 1) / tile;
     if (nt > 0x7FFFFFFFull) return fail(TD_E_LIMIT, "buffer too large for one launch; split it");
     int rc = h->d_tilecounts.ensure(nt); if (rc) return rc;
     rc = h->d_state.ensure(nt); if (rc) return rc;
     const uint32_t g = (uint32_t)std::min<uint64_t>(nt, (uint64_t)h->num_cu * 8);
-    hipLaunchKernelGGL((tdk::k_count_lines<4>), dim3(g), dim3(tdk::BLOCK), 0, s, (const uint8_t *)d_fastq, nbytes, (uint32_t)nt, h->d_tilecounts.p);
+    if (use_split2(h)) hipLaunchKernelGGL((tdk::k_count_lines<6>), dim3(g), dim3(tdk::BLOCK), 0, s, (const uint8_t *)d_fastq, nbytes, (uint32_t)nt, h->d_tilecounts.p);
+    else hipLaunchKernelGGL((tdk::k_count_lines<4>), dim3(g), dim3(tdk::BLOCK), 0, s, (const uint8_t *)d_fastq, nbytes, (uint32_t)nt, h->d_tilecounts.p);
     hipLaunchKernelGGL(tdk::k_scan_tiles, dim3(1), dim3(1024), 0, s, h->d_tilecounts.p, (uint32_t)nt, h->d_state.p, h->d_cursor.p);
     HIPCHK(hipGetLastError());
     return TD_OK;
@@ -1511,9 +1525,10 @@ int launch_split_prefix(td_handle *h, const void *d_fastq, uint64_t nbytes, hipS
 
 // k_split on `s` (after launch_split_prefix); out must hold one int2 per sequence line of the buffer
 int launch_split(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, int2 *d_out, hipStream_t s) {
-    const uint64_t tile = 16 * 1024;
+    const bool two = use_split2(h);
+    const uint64_t tile = two ? 24 * 1024 : 16 * 1024;
     const uint64_t nt = (nbytes + tile - 1) / tile;
-    const uint32_t g = (uint32_t)std::min<uint64_t>(nt, (uint64_t)h->num_cu * 8);
+    const uint32_t g = (uint32_t)std::min<uint64_t>(nt, (uint64_t)h->num_cu * (two ? 4 : 8));
     tdk::SplitParams sp{};
     sp.buf = (const uint8_t *)d_fastq; sp.nbytes = nbytes; sp.first_line = first_line;
     sp.prefix = h->d_state.p; sp.ntiles = (uint32_t)nt;
@@ -1522,6 +1537,11 @@ int launch_split(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     sp.site0 = h->sp_site[0]; sp.site1 = h->sp_site[1]; sp.site0_len = h->sp_site_len[0]; sp.site1_len = h->sp_site_len[1];
     sp.ent_begin = h->d_sp_ent_begin.p; sp.ent_group = h->d_sp_ent_group.p; sp.entries = h->d_sp_entries.p; sp.pool = h->d_sp_pool.p;
     sp.out = d_out; sp.stats = h->d_stats.p;
+    if (two) {
+        hipLaunchKernelGGL((tdk::k_split2<6>), dim3(g), dim3(tdk::FBLOCK), lds_bytes_split2(h), s, sp);
+        HIPCHK(hipGetLastError());
+        return TD_OK;
+    }
     const size_t lds = (size_t)4 * tdk::BLOCK * 2 + 64 + h->sp_bblob_bytes;
     hipLaunchKernelGGL((tdk::k_split<4>), dim3(g), dim3(tdk::BLOCK), lds, s, sp);
     HIPCHK(hipGetLastError());
@@ -1787,12 +1807,14 @@ int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, co
     if ((size_t)4 * tdk::BLOCK * 2 + 64 + blob.size() > LDS_BUDGET) return fail(TD_E_LIMIT, "barcode index does not fit the LDS budget");
     h->sp_cutlen = (uint32_t)cs.size();
     const char *sites[2] = {fullsite0, fullsite1};
+    h->sp_sites_acgt = true;
     for (int k = 0; k < 2; k++) {
         const size_t L = strlen(sites[k]);
         if (L > 8) return fail(TD_E_LIMIT, "restriction site longer than 8 bases");
         unsigned long long v = 0;
         for (size_t q = 0; q < L; q++) v = (v << 8) | (uint8_t)sites[k][q];
         h->sp_site[k] = v; h->sp_site_len[k] = (uint32_t)L;
+        for (size_t q = 0; q < L; q++) if (!strchr("ACGT", sites[k][q])) h->sp_sites_acgt = false;
     }
     if (ent_begin[nbar] != nent) return fail(TD_E_ARG, "ent_begin[nbar] must equal nent");
     // per barcode the entries are stored by the code of their LAST base (A C T G = (byte >> 1) & 3): only

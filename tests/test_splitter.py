@@ -218,12 +218,13 @@ def test_gpu_split_fuzz_campaign():
                 b = "".join(rng.choice("ACGT") for _ in range(rng.randint(3, 9)))
                 if not any((b + cutsite).startswith(o + cutsite) or (o + cutsite).startswith(b + cutsite) for o in barcodes):
                     barcodes.append(b)
-            data = synth_reads(rng, barcodes, cutsite, ad, rng.randint(1, 1500))
+            data = synth_reads(rng, barcodes, cutsite, ad, rng.randint(1, 4000))
             nl = rng.choice([b"\n", b"\n", b"\r\n", b"\r"])
             data = data.replace(b"\n", nl)
             with contextlib.redirect_stdout(io.StringIO()):
                 ends = tf._adapter_ends(ad, barcodes)
             eng.set_splitter(barcodes, cutsite, ad[0][0].replace("^", ""), ad[1][0].replace("^", ""), ends)
+            eng.set_option("split_kernel", 2 if ncase % 3 else 1)          # k_split2 (tile in LDS) twice, k_split once
             d = eng.dev_alloc(len(data))
             try:
                 eng.h2d(d, data)
@@ -231,7 +232,7 @@ def test_gpu_split_fuzz_campaign():
                 want = []
                 po.barcode_splitter_bytes(data, barcodes, cutsite, ad, decisions=want)
                 got = [(int(a), int(b)) for a, b in res[:len(want)]]
-                assert got == [(b, 999 if b < 0 else c) for b, c in want], ("seed", seed0 + ncase, name, nl)
+                assert got == [(b, 999 if b < 0 else c) for b, c in want], ("seed", seed0 + ncase, name, nl, "split_kernel", 2 if ncase % 3 else 1)
             finally:
                 eng.dev_free(d)
             ncase += 1
