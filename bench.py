@@ -315,6 +315,8 @@ def main():
                                        "sums_equal_counters": (sum(a for a, _ in win), sum(b for _, b in win)) == (pst["barcut"], pst["tag"])}
             eng.set_option("timing", 0)
             eng.set_option("progress", 0)
+        if world == 1 and args.config == 5 and not args.debug_ablate:
+            out["count_and_trim"] = count_and_trim(eng, cfg, fastq, nbytes, first_line, my_reads, stream)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample, my_reads), min(args.cpu_python_sample, my_reads))
         if world == 1 and args.tier_reads > 0 and not args.debug_ablate:
@@ -327,6 +329,39 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def count_and_trim(eng, cfg, fastq, nbytes, first_line, reads, stream):
+    """BASELINE config 5's other half: counting AND the splitter's per-read branch (barcode, first full restriction
+    site, adapter run-off: reference :1251-1283, :1328-1363) over the same resident buffer -- td_count_and_split_device,
+    wall time of the call (count pass, line prefix, decisions; two synchronisations inside), three repetitions."""
+    import contextlib
+    import ctypes as C
+    import io
+    import torch
+    from tagdigger_amd import tagdigger_fun as tf
+    adapter = [tuple(x) for x in tf.adapters["PstI-MspI-Hall"]]
+    with contextlib.redirect_stdout(io.StringIO()):
+        ends = tf._adapter_ends(adapter, cfg.barcodes)
+    eng.set_splitter(cfg.barcodes, cfg.cutsites[0], adapter[0][0].replace("^", ""), adapter[1][0].replace("^", ""), ends)
+    cap = reads + 8
+    d_out = torch.empty((cap, 2), dtype=torch.int32, device=fastq.device)
+    terms = C.c_uint64(0)
+    times = []
+    for _ in range(4):
+        eng.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = eng._L.td_count_and_split_device(eng._h, C.c_void_p(fastq.data_ptr()), nbytes, first_line, 1 << 62,
+                                              C.c_void_p(d_out.data_ptr()), cap, C.c_void_p(stream) if stream else None, C.byref(terms))
+        times.append(time.perf_counter() - t0)
+        if rc:
+            return {"error": rc}
+    ms = sorted(times[1:])[1] * 1e3
+    with_bar = int((d_out[:reads, 0] >= 0).sum())
+    clipped = int(((d_out[:reads, 0] >= 0) & (d_out[:reads, 1] != 999)).sum())
+    return {"ms": ms, "reads_per_s": reads / (ms * 1e-3), "terminators": int(terms.value), "with_barcode": with_bar, "clipped": clipped,
+            "what": "count pass + line prefix + k_split2 decisions (8 B per read, left in HBM) over one resident buffer; median of 3"}
 
 
 def oracle_check(cfg, sample, first_line, got_flat):

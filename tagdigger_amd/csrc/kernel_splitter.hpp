@@ -18,7 +18,7 @@ struct SplitEntry {            // one adapter prefix to look for at the end of a
     uint32_t off;              // its characters: pool[off .. off + len)
     uint32_t len;
     int32_t slice;             // the (negative) index the reference slices with when it is found
-    uint32_t pad;
+    uint32_t key;              // its last four characters (fewer: the top bytes), the last one in the top byte
 };
 
 struct SplitParams {
@@ -38,6 +38,7 @@ struct SplitParams {
     const uint8_t *pool;
     int2 *out;
     unsigned long long *stats; // ST_ERR
+    uint32_t dbg;              // timing-only ablations (results wrong when nonzero): 64 no site search, 128 no adapter search
 };
 
 __device__ __forceinline__ uint32_t upper_ascii(uint32_t c) { return (c >= 0x61u && c <= 0x7Au) ? c - 0x20u : c; }

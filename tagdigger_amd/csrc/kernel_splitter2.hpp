@@ -56,7 +56,7 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
 
     // ---- first full restriction site at or after `start` (str.find)
     uint32_t rs0 = 0xFFFFFFFFu, rs1 = 0xFFFFFFFFu;
-    if (start <= len) {
+    if (start <= len && !(p.dbg & 64u)) {
         if (p.site0_len == 0) rs0 = start;                           // (an empty site is found at `start` itself)
         if (p.site1_len == 0) rs1 = start;
         uint32_t H[4] = {0u, 0u, 0u, 0u};                            // per letter A C T G: bits 16-31 this piece, 0-15 the one before
@@ -101,22 +101,46 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
     }
     // ---- no full site: does the read END with the start of an adapter?  Only the entries whose last base is the
     // read's last base can match: they are stored together.
-    if (len == 0) return make_int2((int)bar, 999);
+    if (len == 0 || (p.dbg & 128u)) return make_int2((int)bar, 999);
     const uint32_t lastc = upper_ascii(raw[e - 1]);
     const uint32_t lcode = (lastc >> 1) & 3u;
     if (lastc != ((0x47544341u >> (8 * lcode)) & 0xFFu)) return make_int2((int)bar, 999);     // not a base: no entry ends with it
     const uint32_t e0 = p.ent_group[4 * bar + lcode];
     const uint32_t e1 = lcode == 3 ? p.ent_begin[bar + 1] : p.ent_group[4 * bar + lcode + 1];
+    // The read's last four characters (case folded) against every entry's: an entry whose tail differs is dropped on
+    // one compare of registers; the few that agree are compared eight bytes at a time, read against pool.
+    uint32_t t4 = 0;
+    {
+        const uint32_t n4 = len < 4u ? len : 4u;
+        uint32_t w;
+        __builtin_memcpy(&w, raw + e - n4, 4);                           // bytes e - n4 .. e - n4 + 3
+        t4 = (w << (8u * (4u - n4))) & 0xDFDFDFDFu;                      // the last character in the top byte
+    }
+    // (no `continue` / `return` inside these nested divergent loops: see the note in k_split's split_line)
     int found = 999;
-    for (uint32_t k = e0; k < e1 && found == 999; k++) {
-        const uint4 ent = reinterpret_cast<const uint4 *>(p.entries)[k];     // {off, len, slice, -}
-        const uint32_t elen = ent.y;
-        if (elen > len || elen == 0) continue;
-        const uint8_t *a = p.pool + ent.x;
-        bool same = true;
-        for (uint32_t q = 1; q < elen && same; q++)                   // from the read's second-last character backwards
-            same = upper_ascii(raw[e - 1 - q]) == a[elen - 1 - q];
-        if (same) found = (int)ent.z;
+    for (uint32_t k = e0; k < e1 && found == 999; k += 4) {
+        uint4 ent[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) ent[u] = reinterpret_cast<const uint4 *>(p.entries)[k + u < e1 ? k + u : e1 - 1];     // {off, len, slice, key}
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t elen = ent[u].y;
+            const uint32_t kmask = elen >= 4u ? 0xFFFFFFFFu : elen == 0u ? 0u : 0xFFFFFFFFu << (8u * (4u - elen));
+            bool same = k + u < e1 && found == 999 && elen <= len && elen != 0 && ((t4 ^ ent[u].w) & kmask) == 0;
+            if (same && elen > 4u) {
+                const uint32_t rest = elen - 4u;                          // characters e - elen .. e - 4 against pool[off .. off + rest)
+                const uint8_t *a = p.pool + ent[u].x, *r = raw + e - elen;
+                for (uint32_t i = 0; i < rest; i += 8) {
+                    unsigned long long x, y;
+                    __builtin_memcpy(&x, r + i, 8);
+                    __builtin_memcpy(&y, a + i, 8);
+                    const uint32_t n = rest - i;
+                    const unsigned long long m = n >= 8u ? ~0ull : (1ull << (8u * n)) - 1ull;
+                    if (((x & 0xDFDFDFDFDFDFDFDFull) ^ y) & m) same = false;
+                }
+            }
+            found = same ? (int)ent[u].z : found;
+        }
     }
     return make_int2((int)bar, found);
 }

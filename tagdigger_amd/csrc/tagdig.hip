@@ -1536,7 +1536,7 @@ int launch_split(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     sp.cutlen = h->sp_cutlen;
     sp.site0 = h->sp_site[0]; sp.site1 = h->sp_site[1]; sp.site0_len = h->sp_site_len[0]; sp.site1_len = h->sp_site_len[1];
     sp.ent_begin = h->d_sp_ent_begin.p; sp.ent_group = h->d_sp_ent_group.p; sp.entries = h->d_sp_entries.p; sp.pool = h->d_sp_pool.p;
-    sp.out = d_out; sp.stats = h->d_stats.p;
+    sp.out = d_out; sp.stats = h->d_stats.p; sp.dbg = (uint32_t)h->debug_ablate;
     if (two) {
         hipLaunchKernelGGL((tdk::k_split2<6>), dim3(g), dim3(tdk::FBLOCK), lds_bytes_split2(h), s, sp);
         HIPCHK(hipGetLastError());
@@ -1834,7 +1834,11 @@ int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, co
                 for (size_t q = 0; q < L; q++)
                     if (!strchr("ACGT", ent_seq[e][q])) return fail(TD_E_ALPHABET, "adapter entries must be upper-case ACGT");
                 tdk::SplitEntry en;
-                en.off = (uint32_t)pool.size(); en.len = (uint32_t)L; en.slice = ent_slice[e]; en.pad = 0;
+                en.off = (uint32_t)pool.size(); en.len = (uint32_t)L; en.slice = ent_slice[e];
+                // its last (up to) four characters as the word read from a read's last four bytes holds them: the last
+                // character in the top byte (k_split2 looks at the rest only when these agree)
+                en.key = 0;
+                for (size_t q = 0; q < std::min<size_t>(L, 4); q++) en.key |= (uint32_t)(uint8_t)ent_seq[e][L - 1 - q] << (8 * (3 - q));
                 ents.push_back(en);
                 pool.insert(pool.end(), (const uint8_t *)ent_seq[e], (const uint8_t *)ent_seq[e] + L);
             }
@@ -1848,6 +1852,7 @@ int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, co
     HIPCHK(hipMemcpy(h->d_sp_ent_group.p, groups.data(), groups.size() * 4, hipMemcpyHostToDevice));
     rc = h->d_sp_entries.ensure(std::max<size_t>(1, nent)); if (rc) return rc;
     if (nent) HIPCHK(hipMemcpy(h->d_sp_entries.p, ents.data(), (size_t)nent * sizeof(tdk::SplitEntry), hipMemcpyHostToDevice));
+    pool.insert(pool.end(), 8, 0);                        // (k_split2 compares eight bytes at a time: may read past the last string)
     rc = h->d_sp_pool.ensure(std::max<size_t>(1, pool.size())); if (rc) return rc;
     if (!pool.empty()) HIPCHK(hipMemcpy(h->d_sp_pool.p, pool.data(), pool.size(), hipMemcpyHostToDevice));
     rc = h->d_cursor.ensure(2); if (rc) return rc;
