@@ -36,6 +36,9 @@ struct SplitParams {
     const uint32_t *ent_group; // [barnum][4] within those, where the entries whose LAST base has code c begin (sorted by it)
     const SplitEntry *entries;
     const uint8_t *pool;
+    // k_split2: group (16 bar + 4 code(last) + code(second last)) of gcap entries each (unused ones: len 0)
+    const SplitEntry *entries16;
+    uint32_t gcap;
     int2 *out;
     unsigned long long *stats; // ST_ERR
     uint32_t dbg;              // timing-only ablations (results wrong when nonzero): 64 no site search, 128 no adapter search

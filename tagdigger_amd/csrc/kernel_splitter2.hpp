@@ -53,6 +53,18 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
     if (!hit) return make_int2(-1, 999);
     const uint32_t bar = meta >> 16;
     const uint32_t start = ((meta >> 6) & 63u) + p.cutlen;           // searchstart = len(barcode) + len(cutsite)
+    // The adapter entries this read could end with -- those of its barcode that end with its last two characters: a
+    // group of p.gcap entries found by address alone, so its first four are requested NOW and arrive under the
+    // search for the restriction sites.  (A second-last byte that is no base leaves the one-character entries,
+    // which every group of their character holds.)
+    const uint32_t lastc = len ? (uint32_t)raw[e - 1] & 0xDFu : 0u;
+    const uint32_t lcode = (lastc >> 1) & 3u;
+    const bool tail_is_base = len != 0 && lastc == ((0x47544341u >> (8 * lcode)) & 0xFFu) && !(p.dbg & 128u);
+    const uint32_t prevc = len >= 2u ? (uint32_t)raw[e - 2] & 0xDFu : 0x41u;
+    const uint4 *grp = reinterpret_cast<const uint4 *>(p.entries16) + (size_t)(16u * bar + 4u * lcode + ((prevc >> 1) & 3u)) * p.gcap;
+    uint4 ent[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) ent[u] = tail_is_base ? grp[u] : make_uint4(0u, 0u, 999u, 0u);      // {off, len, slice, key}
 
     // ---- first full restriction site at or after `start` (str.find)
     uint32_t rs0 = 0xFFFFFFFFu, rs1 = 0xFFFFFFFFu;
@@ -99,16 +111,12 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
         else cut = rs1 + p.site1_len;
         return make_int2((int)bar, (int)cut);
     }
-    // ---- no full site: does the read END with the start of an adapter?  Only the entries whose last base is the
-    // read's last base can match: they are stored together.
-    if (len == 0 || (p.dbg & 128u)) return make_int2((int)bar, 999);
-    const uint32_t lastc = upper_ascii(raw[e - 1]);
-    const uint32_t lcode = (lastc >> 1) & 3u;
-    if (lastc != ((0x47544341u >> (8 * lcode)) & 0xFFu)) return make_int2((int)bar, 999);     // not a base: no entry ends with it
-    const uint32_t e0 = p.ent_group[4 * bar + lcode];
-    const uint32_t e1 = lcode == 3 ? p.ent_begin[bar + 1] : p.ent_group[4 * bar + lcode + 1];
-    // The read's last four characters (case folded) against every entry's: an entry whose tail differs is dropped on
-    // one compare of registers; the few that agree are compared eight bytes at a time, read against pool.
+    // ---- no full site: does the read END with the start of an adapter?  (the reference walks a trie over the reversed
+    // read; its stored set is prefix-free, so at most one entry matches.)  The read's last four characters (case
+    // folded) against every entry's: an entry whose tail differs is dropped on one compare of registers; one that
+    // agrees is compared eight bytes at a time, read against pool, all of its pool words requested together.
+    // (no `continue` / `return` inside these nested divergent loops: hipcc 7.2 -O3 miscompiled that, see split_line)
+    if (!tail_is_base) return make_int2((int)bar, 999);
     uint32_t t4 = 0;
     {
         const uint32_t n4 = len < 4u ? len : 4u;
@@ -116,30 +124,47 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
         __builtin_memcpy(&w, raw + e - n4, 4);                           // bytes e - n4 .. e - n4 + 3
         t4 = (w << (8u * (4u - n4))) & 0xDFDFDFDFu;                      // the last character in the top byte
     }
-    // (no `continue` / `return` inside these nested divergent loops: see the note in k_split's split_line)
     int found = 999;
-    for (uint32_t k = e0; k < e1 && found == 999; k += 4) {
-        uint4 ent[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) ent[u] = reinterpret_cast<const uint4 *>(p.entries)[k + u < e1 ? k + u : e1 - 1];     // {off, len, slice, key}
+    bool more = true;
+    for (uint32_t k = 0; more; k += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t elen = ent[u].y;
             const uint32_t kmask = elen >= 4u ? 0xFFFFFFFFu : elen == 0u ? 0u : 0xFFFFFFFFu << (8u * (4u - elen));
-            bool same = k + u < e1 && found == 999 && elen <= len && elen != 0 && ((t4 ^ ent[u].w) & kmask) == 0;
+            bool same = found == 999 && elen <= len && elen != 0 && ((t4 ^ ent[u].w) & kmask) == 0;
             if (same && elen > 4u) {
                 const uint32_t rest = elen - 4u;                          // characters e - elen .. e - 4 against pool[off .. off + rest)
                 const uint8_t *a = p.pool + ent[u].x, *r = raw + e - elen;
-                for (uint32_t i = 0; i < rest; i += 8) {
-                    unsigned long long x, y;
+                constexpr int NB = 10;                                    // (entries of up to 84 characters in one go; longer: the loop below)
+                unsigned long long y[NB];
+#pragma unroll
+                for (int b = 0; b < NB; b++) { y[b] = 0; if (8u * b < rest) __builtin_memcpy(&y[b], a + 8 * b, 8); }
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    if (8u * b < rest) {
+                        unsigned long long x;
+                        __builtin_memcpy(&x, r + 8 * b, 8);
+                        const uint32_t n = rest - 8u * b;
+                        const unsigned long long m = n >= 8u ? ~0ull : (1ull << (8u * n)) - 1ull;
+                        if (((x & 0xDFDFDFDFDFDFDFDFull) ^ y[b]) & m) same = false;
+                    }
+                }
+                for (uint32_t i = 8u * NB; i < rest; i += 8) {
+                    unsigned long long x, yy;
                     __builtin_memcpy(&x, r + i, 8);
-                    __builtin_memcpy(&y, a + i, 8);
+                    __builtin_memcpy(&yy, a + i, 8);
                     const uint32_t n = rest - i;
                     const unsigned long long m = n >= 8u ? ~0ull : (1ull << (8u * n)) - 1ull;
-                    if (((x & 0xDFDFDFDFDFDFDFDFull) ^ y) & m) same = false;
+                    if (((x & 0xDFDFDFDFDFDFDFDFull) ^ yy) & m) same = false;
                 }
             }
             found = same ? (int)ent[u].z : found;
+        }
+        // the group's next four entries, if it has any (unused entries close a group: len 0)
+        more = found == 999 && ent[3].y != 0 && k + 4 < p.gcap;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) ent[u] = grp[k + 4 + u];
         }
     }
     return make_int2((int)bar, found);

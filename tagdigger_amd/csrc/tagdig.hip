@@ -162,6 +162,7 @@ struct td_handle {
     int progress = 0;
     int split_kernel = 2;                     // 2: k_split2 (tile in LDS), 1: k_split
     bool sp_sites_acgt = false;
+    uint32_t sp_gcap = 4;                     // entries per (barcode, last two bases) group of entries16
     std::vector<uint64_t> split_win;          // td_split_file's: {with barcode, clipped} per window of 50 000 reads
     DevBuf<unsigned long long> d_win;
     DevBuf<uint4> d_progbits;                 // k_fast2's per-tile record of what its wanted lines matched
@@ -182,7 +183,8 @@ struct td_handle {
     uint32_t sp_bblob_bytes = 0, sp_off_bmeta = 0, sp_off_bdir = 0, sp_cutlen = 0;
     unsigned long long sp_site[2] = {0, 0};
     uint32_t sp_site_len[2] = {0, 0};
-    DevBuf<uint32_t> d_sp_bblob, d_sp_ent_begin, d_sp_ent_group;
+    DevBuf<uint32_t> d_sp_bblob, d_sp_ent_begin, d_sp_ent_group, d_sp_group16;
+    DevBuf<tdk::SplitEntry> d_sp_entries16;
     DevBuf<tdk::SplitEntry> d_sp_entries;
     DevBuf<uint8_t> d_sp_pool;
     DevBuf<uint4> d_fixlist;
@@ -601,7 +603,7 @@ void td_destroy(td_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
-    h->d_win.release(); h->d_progbits.release();
+    h->d_win.release(); h->d_progbits.release(); h->d_sp_group16.release(); h->d_sp_entries16.release();
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
     h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release(); h->d_rowmap.release();
     for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -1536,6 +1538,7 @@ int launch_split(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     sp.cutlen = h->sp_cutlen;
     sp.site0 = h->sp_site[0]; sp.site1 = h->sp_site[1]; sp.site0_len = h->sp_site_len[0]; sp.site1_len = h->sp_site_len[1];
     sp.ent_begin = h->d_sp_ent_begin.p; sp.ent_group = h->d_sp_ent_group.p; sp.entries = h->d_sp_entries.p; sp.pool = h->d_sp_pool.p;
+    sp.gcap = h->sp_gcap; sp.entries16 = h->d_sp_entries16.p;
     sp.out = d_out; sp.stats = h->d_stats.p; sp.dbg = (uint32_t)h->debug_ablate;
     if (two) {
         hipLaunchKernelGGL((tdk::k_split2<6>), dim3(g), dim3(tdk::FBLOCK), lds_bytes_split2(h), s, sp);
@@ -1848,6 +1851,33 @@ int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, co
     HIPCHK(hipMemcpy(h->d_sp_bblob.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     rc = h->d_sp_ent_begin.ensure(nbar + 1); if (rc) return rc;
     HIPCHK(hipMemcpy(h->d_sp_ent_begin.p, ent_begin, (size_t)(nbar + 1) * 4, hipMemcpyHostToDevice));
+    {   // k_split2's view of the same entries: per barcode 16 groups by the codes of the LAST TWO characters (a one-character
+        // entry sits in all four groups of its character), every group padded to the same capacity (empty entries: len 0),
+        // so a read finds its group by address alone -- the loads can be issued before the group is needed -- and looks
+        // at a sixteenth of its barcode's entries
+        std::vector<std::vector<tdk::SplitEntry>> grp((size_t)nbar * 16);
+        size_t cap = 4;
+        for (uint32_t b = 0; b < nbar; b++) {
+            const uint32_t lo = groups[(size_t)b * 4], hi = b + 1 < nbar ? groups[(size_t)(b + 1) * 4] : (uint32_t)ents.size();
+            for (uint32_t g = 0; g < 16; g++) {
+                auto &v = grp[(size_t)b * 16 + g];
+                for (uint32_t k = lo; k < hi; k++) {
+                    const tdk::SplitEntry &en = ents[k];
+                    if (en.len == 0) continue;
+                    const uint32_t last = ((en.key >> 24) >> 1) & 3u, prev = ((en.key >> 16) >> 1) & 3u;
+                    if (last == (g >> 2) && (en.len == 1 || prev == (g & 3u))) v.push_back(en);
+                }
+                // longest first: a read that ran into the adapter usually carries a long piece of it
+                std::stable_sort(v.begin(), v.end(), [](const tdk::SplitEntry &a, const tdk::SplitEntry &c) { return a.len > c.len; });
+                cap = std::max(cap, (v.size() + 3) / 4 * 4);
+            }
+        }
+        std::vector<tdk::SplitEntry> e16((size_t)nbar * 16 * cap, tdk::SplitEntry{0u, 0u, 999, 0u});
+        for (size_t g = 0; g < grp.size(); g++) std::copy(grp[g].begin(), grp[g].end(), e16.begin() + g * cap);
+        h->sp_gcap = (uint32_t)cap;
+        rc = h->d_sp_entries16.ensure(std::max<size_t>(1, e16.size())); if (rc) return rc;
+        HIPCHK(hipMemcpy(h->d_sp_entries16.p, e16.data(), e16.size() * sizeof(tdk::SplitEntry), hipMemcpyHostToDevice));
+    }
     rc = h->d_sp_ent_group.ensure((size_t)nbar * 4); if (rc) return rc;
     HIPCHK(hipMemcpy(h->d_sp_ent_group.p, groups.data(), groups.size() * 4, hipMemcpyHostToDevice));
     rc = h->d_sp_entries.ensure(std::max<size_t>(1, nent)); if (rc) return rc;
