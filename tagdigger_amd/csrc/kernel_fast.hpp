@@ -633,4 +633,11 @@ __global__ __launch_bounds__(1024) void k_resolve(const FParams fp, const unsign
     }
 }
 
+// the main pass's per-tile terminator counts as k_scan_tiles reads them (td_count_and_split_device: the splitter's line
+// prefix without a second pass over the bytes)
+__global__ __launch_bounds__(256) void k_info_counts(const uint32_t *tile_info, uint32_t ntiles, uint64_t *tile_counts) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < ntiles) tile_counts[i] = tile_info[i] & TI_COUNT_MASK;
+}
+
 }  // namespace tdk

@@ -162,6 +162,8 @@ struct td_handle {
     int progress = 0;
     int split_kernel = 2;                     // 2: k_split2 (tile in LDS), 1: k_split
     bool sp_sites_acgt = false;
+    int last_fast_tile_kb = 0;                // tile size of the last free-running count launch (0: it took another path)
+    uint32_t last_fast_ntiles = 0;
     uint32_t sp_gcap = 4;                     // entries per (barcode, last two bases) group of entries16
     std::vector<uint64_t> split_win;          // td_split_file's: {with barcode, clipped} per window of 50 000 reads
     DevBuf<unsigned long long> d_win;
@@ -406,6 +408,8 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
         }
         p.win = h->d_win.p; p.win_cap = (uint32_t)std::min<size_t>(h->d_win.n, 0xFFFFFFFFu);
     }
+    h->last_fast_tile_kb = use_fast ? tile_kb : 0;        // (td_count_and_split_device: are d_tileinfo's counts the splitter's tiles?)
+    h->last_fast_ntiles = use_fast ? ntiles : 0;
     if (use_fast) {
         int rc = h->d_tileinfo.ensure(ntiles); if (rc) return rc;
         const uint32_t fix_cap = 3u * ntiles + 8u;
@@ -1511,14 +1515,18 @@ bool use_split2(const td_handle *h) {
     return h->split_kernel == 2 && h->sp_sites_acgt && lds_bytes_split2(h) <= (size_t)40 * 1024;
 }
 
-int launch_split_prefix(td_handle *h, const void *d_fastq, uint64_t nbytes, hipStream_t s) {
+int launch_split_prefix(td_handle *h, const void *d_fastq, uint64_t nbytes, hipStream_t s, bool counted = false) {
     const uint64_t tile = use_split2(h) ? 24 * 1024 : 16 * 1024;
     const uint64_t nt = (nbytes + tile - 1) / tile;
     if (nt > 0x7FFFFFFFull) return fail(TD_E_LIMIT, "buffer too large for one launch; split it");
     int rc = h->d_tilecounts.ensure(nt); if (rc) return rc;
     rc = h->d_state.ensure(nt); if (rc) return rc;
     const uint32_t g = (uint32_t)std::min<uint64_t>(nt, (uint64_t)h->num_cu * 8);
-    if (use_split2(h)) hipLaunchKernelGGL((tdk::k_count_lines<6>), dim3(g), dim3(tdk::BLOCK), 0, s, (const uint8_t *)d_fastq, nbytes, (uint32_t)nt, h->d_tilecounts.p);
+    // `counted`: the count pass just enqueued on this stream ran over the same bytes in tiles of this size and left
+    // every tile's terminator count in d_tileinfo
+    if (counted && use_split2(h) && h->last_fast_tile_kb == 24 && h->last_fast_ntiles == (uint32_t)nt)
+        hipLaunchKernelGGL(tdk::k_info_counts, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, s, h->d_tileinfo.p, (uint32_t)nt, h->d_tilecounts.p);
+    else if (use_split2(h)) hipLaunchKernelGGL((tdk::k_count_lines<6>), dim3(g), dim3(tdk::BLOCK), 0, s, (const uint8_t *)d_fastq, nbytes, (uint32_t)nt, h->d_tilecounts.p);
     else hipLaunchKernelGGL((tdk::k_count_lines<4>), dim3(g), dim3(tdk::BLOCK), 0, s, (const uint8_t *)d_fastq, nbytes, (uint32_t)nt, h->d_tilecounts.p);
     hipLaunchKernelGGL(tdk::k_scan_tiles, dim3(1), dim3(1024), 0, s, h->d_tilecounts.p, (uint32_t)nt, h->d_state.p, h->d_cursor.p);
     HIPCHK(hipGetLastError());
@@ -1890,8 +1898,17 @@ int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, co
     return TD_OK;
 }
 
+static int split_device_impl(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, int32_t *d_out,
+                             uint64_t out_capacity, void *stream, uint64_t *n_terminators, bool counted);
+
 int td_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, int32_t *d_out,
                     uint64_t out_capacity, void *stream, uint64_t *n_terminators) {
+    return split_device_impl(h, d_fastq, nbytes, first_line, d_out, out_capacity, stream, n_terminators, false);
+}
+
+// (counted: a count pass over the same bytes was just enqueued on `stream` -- its per-tile terminator counts serve)
+static int split_device_impl(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t first_line, int32_t *d_out,
+                             uint64_t out_capacity, void *stream, uint64_t *n_terminators, bool counted) {
     if (!h || !d_out) return fail(TD_E_ARG, "NULL argument");
     if (!h->have_splitter) return fail(TD_E_STATE, "td_set_splitter has not been called");
     if (((uintptr_t)d_fastq & 15) != 0) return fail(TD_E_ARG, "device FASTQ pointer must be 16-byte aligned");
@@ -1899,7 +1916,7 @@ int td_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t
     if (n_terminators) *n_terminators = 0;
     if (nbytes == 0) return TD_OK;
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_split_prefix(h, d_fastq, nbytes, s); if (rc) return rc;
+    int rc = launch_split_prefix(h, d_fastq, nbytes, s, counted); if (rc) return rc;
     unsigned long long v = 0;
     HIPCHK(hipMemcpyAsync(&v, h->d_cursor.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1922,7 +1939,7 @@ int td_count_and_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes
     HIPCHK(hipSetDevice(h->device));
     int rc = launch_count(h, d_fastq, nbytes, first_line, max_reads, 0, (hipStream_t)stream);
     if (rc) return rc;
-    return td_split_device(h, d_fastq, nbytes, first_line, d_out, out_capacity, stream, n_terminators);
+    return split_device_impl(h, d_fastq, nbytes, first_line, d_out, out_capacity, stream, n_terminators, true);
 }
 
 int td_split_file(td_handle *h, const char *in_path, const char *const *out_paths, uint64_t max_reads, uint64_t stats[3]) {
