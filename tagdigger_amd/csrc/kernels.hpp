@@ -965,17 +965,23 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint64_t *tile_counts
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < ntiles; base += 1024) {
-        const uint32_t i = base + tid;
-        unsigned long long v = i < ntiles ? tile_counts[i] : 0ull;
-        unsigned long long inc = v;
+    // (eight consecutive tiles per thread and round: a round of 8192 tiles costs the same three barriers as one of 1024)
+    constexpr uint32_t PER = 8;
+    for (uint32_t base = 0; base < ntiles; base += 1024 * PER) {
+        const uint32_t i0 = base + (uint32_t)tid * PER;
+        unsigned long long v[PER], sum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) { v[q] = i0 + q < ntiles ? tile_counts[i0 + q] : 0ull; sum += v[q]; }
+        unsigned long long inc = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { unsigned long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
         unsigned long long off = carry;
         for (int w = 0; w < wave; w++) off += wsum[w];
-        if (i < ntiles) state[i] = FLAG_INC | (off + inc);
+        unsigned long long run = off + inc - sum;                 // terminators before this thread's first tile
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) { run += v[q]; if (i0 + q < ntiles) state[i0 + q] = FLAG_INC | run; }
         __syncthreads();
         if (tid == 1023) carry = off + inc;
         __syncthreads();
