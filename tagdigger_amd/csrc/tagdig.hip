@@ -185,7 +185,7 @@ struct td_handle {
     uint32_t sp_bblob_bytes = 0, sp_off_bmeta = 0, sp_off_bdir = 0, sp_cutlen = 0;
     unsigned long long sp_site[2] = {0, 0};
     uint32_t sp_site_len[2] = {0, 0};
-    DevBuf<uint32_t> d_sp_bblob, d_sp_ent_begin, d_sp_ent_group, d_sp_group16;
+    DevBuf<uint32_t> d_sp_bblob, d_sp_ent_begin, d_sp_ent_group;
     DevBuf<tdk::SplitEntry> d_sp_entries16;
     DevBuf<tdk::SplitEntry> d_sp_entries;
     DevBuf<uint8_t> d_sp_pool;
@@ -607,7 +607,7 @@ void td_destroy(td_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
-    h->d_win.release(); h->d_progbits.release(); h->d_sp_group16.release(); h->d_sp_entries16.release();
+    h->d_win.release(); h->d_progbits.release(); h->d_sp_entries16.release();
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
     h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release(); h->d_rowmap.release();
     for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
