@@ -160,6 +160,8 @@ struct td_handle {
     DevBuf<unsigned long long> d_stats;       // TD_STAT_NSTATS
     // progress windows (option "progress"): per 50 000 reads, how many had a barcode / a tag (reference :268-271)
     int progress = 0;
+    uint32_t zb_members = 1u << 30;           // (tests: BGZF members per GPU batch, below the built-in 49 152)
+    unsigned long long *pin_cursor = nullptr; // pinned: the line index after the newest counted BGZF batch
     int split_kernel = 2;                     // 2: k_split2 (tile in LDS), 1: k_split
     bool sp_sites_acgt = false;
     int last_fast_tile_kb = 0;                // tile size of the last free-running count launch (0: it took another path)
@@ -607,6 +609,7 @@ void td_destroy(td_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
+    if (h->pin_cursor) (void)hipHostFree(h->pin_cursor);
     h->d_win.release(); h->d_progbits.release(); h->d_sp_entries16.release();
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
     h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release(); h->d_rowmap.release();
@@ -993,7 +996,7 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
         td_handle::ZSlot &z = h->zslot[slot];
         b = Batch();
         const size_t first = pos;
-        while (pos < src.bsize && b.n < ZB_MEMBERS) {
+        while (pos < src.bsize && b.n < std::min<uint32_t>(ZB_MEMBERS, h->zb_members)) {
             uint32_t bs = 0, hs = 0;
             if (!tdhost::GzSource::bgzf_header(src.map + pos, src.bsize - pos, &bs, &hs) || bs < hs + 8 || pos + bs > src.bsize)
                 return fail(TD_E_IO, "damaged BGZF member header");
@@ -1026,6 +1029,11 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
     };
     Batch cur, nxt;
     int slot = 0;
+    // (reference :272: the loop ends at maxreads -- no further batch is inflated once a counted batch's line index shows
+    // that the bound has been passed; the kernels ignore reads past it either way)
+    if (!h->pin_cursor) HIPCHK(hipHostMalloc((void **)&h->pin_cursor, 16, hipHostMallocDefault));
+    h->pin_cursor[0] = 0;
+    const uint64_t stop_line = max_reads >= (1ull << 60) ? ~0ull : 4 * (std::max<uint64_t>(1, max_reads) - 1) + 2;
     int rc = prepare(0, cur); if (rc) return rc;
     size_t carry = 0;                                       // bytes of an unfinished line at the front of this slot's output
     uint64_t bytes_submitted = 0;
@@ -1045,6 +1053,7 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
         // the next batch is read and sent while this one inflates
         if (!cur.last) { rc = prepare(slot ^ 1, nxt); if (rc) return rc; }
         HIPCHK(hipStreamSynchronize(h->work_stream));
+        if (h->pin_cursor[0] >= stop_line) break;               // (the batches counted so far already hold read number max_reads)
         for (uint32_t i = 0; i < cur.n; i++)
             if (z.pin_status[i]) return fail(TD_E_IO, z.pin_status[i] == 100 ? "BGZF member fails its CRC-32" : "inflate error in a BGZF member");
         size_t cut = total;
@@ -1058,6 +1067,7 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
                               h->d_cursor.p + ((pieces + 1) & 1), bytes_submitted);
             if (rc) return rc;
             bytes_submitted += cut; pieces++;
+            HIPCHK(hipMemcpyAsync(h->pin_cursor, h->d_cursor.p + (pieces & 1), 8, hipMemcpyDeviceToHost, h->work_stream));
         }
         if (cur.last) break;
         carry = total - cut;
@@ -1248,6 +1258,7 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     } else if (n == "hot_cache") h->hot_cache = value ? 1 : 0;
     else if (n == "run") h->run = (int)std::max<int64_t>(1, std::min<int64_t>(value, 4096));
     else if (n == "progress") h->progress = value ? 1 : 0;
+    else if (n == "zb_members") h->zb_members = (uint32_t)std::max<int64_t>(64, value);
     else if (n == "split_kernel") h->split_kernel = value == 1 ? 1 : 2;
     else if (n == "gpu_inflate") h->gpu_inflate = value ? 1 : 0;
     else if (n == "gpu_inflate_crc") h->gpu_inflate_crc = value ? 1 : 0;
