@@ -24,7 +24,7 @@ def _rank_world():
     return 0, 1
 
 
-def count_libraries(bckeys, tags, cutsite, counter=None, device=None, maxreads=5e9, as_array=False):
+def count_libraries(bckeys, tags, cutsite, counter=None, device=None, maxreads=5e9, as_array=False, progress=False):
     """Every rank calls this with the same arguments.  Returns [sample names, samples x tags counts]
     on every rank (counts: list of lists like the reference's, or an int64 numpy array with `as_array`).
 
@@ -33,7 +33,9 @@ def count_libraries(bckeys, tags, cutsite, counter=None, device=None, maxreads=5
     device tensor is all-reduced in place -- no host lists anywhere.
     counter(file, barcodes, tags, cutsite) -> matrix: a stand-in for the per-file counter (the CPU rehearsal
     of the sharding and the reduction in tests/test_multi_gloo.py passes the oracle); the matrices are folded
-    with numpy and reduced as an int64 host tensor."""
+    with numpy and reduced as an int64 host tensor.
+    progress=True: rank 0 prints, file by file in the reference's order, the progress lines its find_tags_fastq
+    prints (:268-271) -- every rank keeps the per-window counters of its libraries on its GPU, the lines are gathered."""
     rank, world = _rank_world()
     order, rows = sample_rows(bckeys)
     files = sorted(bckeys.keys())
@@ -47,10 +49,25 @@ def count_libraries(bckeys, tags, cutsite, counter=None, device=None, maxreads=5
         eng = tagdigger_fun.default_engine(dev.index)
         total = torch.zeros((len(order), len(tags)), dtype=torch.int32, device=dev)     # uint32 counts: bit pattern == int32's
         torch.cuda.synchronize(dev)
+        printed = {}
+        eng.set_option("progress", 1 if progress else 0)
         for f in mine:
             eng.set_index(bckeys[f][0], tags, cutsite)          # (kept when the barcode set repeats: only the counts are zeroed)
             eng.count_file(f, maxreads)
+            if progress:
+                printed[f] = eng.progress_lines(f)
             eng.fold_rows(rows[f], total.data_ptr(), len(order))
+        eng.set_option("progress", 0)
+        if progress:
+            every = [printed]
+            if world > 1:
+                every = [None] * world
+                dist.all_gather_object(every, printed)
+            if rank == 0:
+                for f in files:
+                    for part in every:
+                        for line in part.get(f, ()):
+                            print(line)
         if world > 1:
             dist.all_reduce(total, op=dist.ReduceOp.SUM)        # the path's one exchange: RCCL over xGMI
         out = total.cpu().numpy().view(np.uint32).astype(np.int64)

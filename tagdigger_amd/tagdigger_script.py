@@ -185,7 +185,7 @@ def _rank_main(rank, devices, keys, sequences, site, names, outputcounts, output
     else:
         dist.init_process_group("gloo", rank=rank, world_size=len(devices))
     try:
-        samples, counts = multi.count_libraries(keys, sequences, site, device=dev, as_array=True)
+        samples, counts = multi.count_libraries(keys, sequences, site, device=dev, as_array=True, progress=True)
         if rank == 0:
             tf.writeCounts(outputcounts, counts, samples, names)
             if outputgen is not None:

@@ -193,3 +193,41 @@ def test_barcode_splitter_prints_what_the_reference_prints(case, tmp_path):
         os.chdir(old)
     assert sums == case["outputs_sha256"]
     assert out.getvalue().splitlines() == case["stdout"]
+
+
+@pytest.mark.gpu
+def test_cli_on_several_devices_prints_the_progress_lines_in_file_order(tmp_path, capfd):
+    """--td-devices (one process per GPU; the same GPU twice here: the rehearsal form): two libraries counted on two
+    ranks, their progress lines gathered and printed by rank 0 in the reference's order -- sorted file names, each
+    file's lines together -- with the counters the C oracle has at every 50 000th read of that file."""
+    import csv
+    from tagdigger_amd import tagdigger_script
+    from tagdigger_amd.synth import SynthConfig, merged_rows
+    cfg = SynthConfig(nreads=290_000, nbar=8, nmarkers=50, seed=4321, cutsite="TGCAG", bclen=(4, 8))
+    host = helpers.synth_host_bytes(cfg, 0, cfg.nreads)
+    parts = {"lib_1.fq": host[:160_000 * cfg.record_bytes], "lib_2.fq": host[160_000 * cfg.record_bytes:]}
+    o = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite)
+    want = []
+    for name in sorted(parts):
+        parts[name].tofile(str(tmp_path / name))
+        n = len(parts[name]) // cfg.record_bytes
+        for k, (bar, tag) in enumerate(boundary_stats(o, parts[name], n)):
+            want.append("Reads: {0} With barcode and cut site: {1} With tag: {2}".format(50000 * (k + 1), bar, tag))
+    with open(tmp_path / "key.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["File", "Barcode", "Sample"])
+        for name in sorted(parts):
+            for k, b in enumerate(cfg.barcodes):
+                w.writerow([name, b, "S%d" % k])
+    with open(tmp_path / "tags.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Marker name", "Tag sequence"])
+        w.writerows(merged_rows(cfg.tags, len(cfg.tags) // 2, np.random.default_rng(1), 0))
+    old = os.getcwd()
+    try:
+        tagdigger_script.main(["-c", cfg.cutsite, "--MergedTags", "tags.csv", "-b", "key.csv", "-o", "counts.csv", "-w", str(tmp_path),
+                               "--td-devices", "0,0"])
+    finally:
+        os.chdir(old)
+    got = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("Reads: ")]
+    assert got == want and len(want) == 5
