@@ -120,25 +120,7 @@ def small_index(rnd, cutsite, nbar=10, ntag=40, taglens=(20, 70)):
     return barcodes, tags, cutsites
 
 
-def bgzf_bytes(data, block=0xFF00, level=6, threads=0):
-    """`data` as a BGZF file (what bgzip writes): gzip members of at most 64 KiB, each with the
-    'BC' extra field holding its compressed size, closed by the empty end-of-file member.
-    `threads` > 1: the members are compressed on a thread pool (zlib releases the GIL)."""
-    import struct
-    import zlib
-
-    def member(i):
-        chunk = data[i:i + block]
-        co = zlib.compressobj(level, zlib.DEFLATED, -15)
-        comp = co.compress(chunk) + co.flush()
-        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp
-                + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
-    starts = range(0, len(data), block)
-    if threads > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(threads) as ex:
-            out = list(ex.map(member, starts, chunksize=64))
-    else:
-        out = [member(i) for i in starts]
-    out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
-    return b"".join(out)
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools"))
+from compress_formats import bgzf_bytes, gzip_one_member  # noqa: E402,F401  (tools/compress_formats.py: shared with the bench's tiers)

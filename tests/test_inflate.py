@@ -7,7 +7,7 @@ import random
 
 import pytest
 
-from helpers import bgzf_bytes
+from helpers import bgzf_bytes, gzip_one_member
 
 
 def gunzip(path, capacity, chunk=0):
@@ -40,13 +40,16 @@ def fastq():
                     for i in range(20000))
 
 
-@pytest.mark.parametrize("kind", ["bgzf", "bgzf-small-blocks", "gzip", "two-members", "bgzf-empty"])
+@pytest.mark.parametrize("kind", ["bgzf", "bgzf-small-blocks", "gzip", "two-members", "bgzf-empty", "pigz-like", "pigz-like-small-pieces"])
 @pytest.mark.parametrize("chunk", [0, 97, 70000, 1 << 22])
 def test_gunzip_file(tmp_path, fastq, kind, chunk):
     data = b"" if kind == "bgzf-empty" else fastq
     blob = {"bgzf": lambda: bgzf_bytes(data), "bgzf-small-blocks": lambda: bgzf_bytes(data, block=777, level=1),
             "gzip": lambda: gzip.compress(data), "two-members": lambda: gzip.compress(data[:999]) + gzip.compress(data[999:]),
-            "bgzf-empty": lambda: bgzf_bytes(b"")}[kind]()
+            "bgzf-empty": lambda: bgzf_bytes(b""),
+            # one member whose DEFLATE stream was compressed in independent pieces closed by full flushes (pigz)
+            "pigz-like": lambda: gzip_one_member(data, level=1, threads=4, piece=1 << 17),
+            "pigz-like-small-pieces": lambda: gzip_one_member(data, level=6, threads=2, piece=5000)}[kind]()
     p = tmp_path / "x.fq.gz"
     p.write_bytes(blob)
     rc, got = gunzip(p, len(data), chunk)
