@@ -87,8 +87,7 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
             for (int which = 0; which < 2; which++) {
                 const uint32_t L = which ? p.site1_len : p.site0_len;
                 const unsigned long long site = which ? p.site1 : p.site0;      // last character in the low byte
-                if (L == 0) continue;
-                uint32_t M = 0xFFFF0000u;
+                uint32_t M = L ? 0xFFFF0000u : 0u;                                // (an empty site was settled above)
                 for (uint32_t back = 0; back < L; back++) {                       // (uniform: the sites are the launch's)
                     const uint32_t ch = (uint32_t)(site >> (8u * back)) & 0xFFu; // the site's character `back` places before its last
                     const uint32_t code = (ch >> 1) & 3u;                         // A C T G = 0 1 2 3

@@ -145,6 +145,11 @@ def synth_reads(rng, barcodes, cutsite, ad, n, first_line_shift=0):
             seq = (bc + cutsite + body).lower()
         else:
             seq = bc + cutsite + body
+        r = rng.random()
+        if r < 0.01:                       # a read far longer than the window k_split2 stages behind a tile (its global-memory path)
+            seq = seq[:len(seq) // 2] + "".join(rng.choice("AT") for _ in range(rng.randrange(400, 3000))) + seq[len(seq) // 2:]
+        elif r < 0.03:                     # blanks str.strip() takes off, and a read of a few bases
+            seq = rng.choice([" ", "\t", "  "]) + seq[:rng.randrange(0, 12)] + rng.choice(["", " ", "\t "])
         recs.append("@r%d\n%s\n+\n%s\n" % (i, seq, "I" * len(seq)))
     return ("\n" * first_line_shift + "".join(recs)).encode("ascii")
 
