@@ -210,6 +210,16 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
     return 1u;
 }
 
+// wave priority per phase (s_setprio): the pending line + next tile's loads, phases C-D, phases A-B of the next tile
+#ifndef TD_P_PEND
+#define TD_P_PEND 3
+#endif
+#ifndef TD_P_D
+#define TD_P_D 2
+#endif
+#ifndef TD_P_A
+#define TD_P_A 0
+#endif
 #ifndef TD_FAST2_WAVES
 #define TD_FAST2_WAVES 0        // 0: derived from the tile size (LDS decides how many workgroups share a CU)
 #endif
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         }
         TD_STAMP(2);   // B: masks, scan, vote, list
         // ---------------- the pending line of the previous tile, the next tile's loads, the pending count
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(TD_P_PEND);
         const uint32_t nit = run_pos + 1u < RUN ? t + 1u : t + 1u + (gridDim.x - 1u) * RUN;      // next tile of this workgroup
         bool phit = false;
         uint32_t pcell = 0;
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         TD_STAMP(4);   // next tile's loads issued, pending count committed
         lds_barrier();
         TD_STAMP(5);   // barrier 1
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(TD_P_D);
 
         // ---------------- C: the tile's phase and the waves' running totals
         const uint4 tot4 = *reinterpret_cast<const uint4 *>(L_misc + 4), pk4 = *reinterpret_cast<const uint4 *>(L_misc + 8);
@@ -591,7 +601,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                 }
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(TD_P_A);
         TD_STAMP(7);   // D: lines packed and matched up to the bucket loads (thread 0's share)
         if (tid == 0) { L_misc[1] = 0; L_misc[2] = 0; L_misc[3] = 0; }
         if (p.hot_cache && ++aged == HC_AGE_TILES) {
