@@ -57,7 +57,7 @@ def main():
                     help="reads for the pure-Python restatement's timing (cpu_baseline.value; 0 = skip)")
     ap.add_argument("--oracle-sample", type=int, default=2_000_000,
                     help="reads of the resident stream counted by the C oracle and compared with a GPU pass over the same bytes (0 = skip)")
-    ap.add_argument("--tier-reads", type=int, default=8_000_000, help="reads in the T2/T3 tier measurements (0 = skip)")
+    ap.add_argument("--tier-reads", type=int, default=16_000_000, help="reads in the T2/T3 tier measurements (0 = skip)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--stagger", type=int, default=-1)
     ap.add_argument("--table-load", type=int, default=0)

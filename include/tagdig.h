@@ -229,6 +229,13 @@ int64_t td_format_csv_row(const int64_t *vals, uint64_t n, char *out, uint64_t c
  *   "timing"         1: record HIP events around every launch for td_kernel_time_ms
  *   "fast_max_matrix_bytes"  count matrices of this many bytes and more go to the exact kernel (the
  *                    free-running one addresses cells as base + 32-bit offset); 0 = the built-in 4 GiB
+ *   "progress"       1: keep the reference's progress counters per window of 50 000 reads (td_get_progress); the main pass
+ *                    is then k_fast2's recording instantiation (+6 % kernel time) or the exact kernel
+ *   "split_kernel"   the splitter's per-read branch: 2 (default) k_split2 -- tile in LDS, one lane per read
+ *                    (kernel_splitter2.hpp); 1 k_split (kernel_splitter.hpp)
+ *   "gpu_inflate"    1 (default): BGZF members are inflated on the GPU; 0: on host threads
+ *   "gpu_inflate_crc" 1 (default): every member's CRC-32 is checked on the device
+ *   "zb_members"     BGZF members per GPU batch (tests; the built-in 49 152 is also the maximum)
  *   "debug_ablate"   timing-only ablation bits -- the counts are WRONG when non-zero
  * Returns TD_E_ARG for unknown names. */
 int td_set_option(td_handle *h, const char *name, int64_t value);
