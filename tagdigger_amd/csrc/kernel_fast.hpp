@@ -530,6 +530,7 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
 // counts into super[block] first, and each k_resolve block adds up the super sums before its own.
 constexpr uint32_t RESOLVE_SPAN = 1024;
 
+#ifndef TD_INST_ONLY      // (defined once, in tagdig.hip's translation unit)
 __global__ __launch_bounds__(256) void k_resolve_sums(const FParams fp, unsigned long long *super) {
     __shared__ unsigned long long wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -544,7 +545,9 @@ __global__ __launch_bounds__(256) void k_resolve_sums(const FParams fp, unsigned
     __syncthreads();
     if (tid == 0) super[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
+#endif
 
+#ifndef TD_INST_ONLY      // (defined once, in tagdig.hip's translation unit)
 __global__ __launch_bounds__(1024) void k_resolve(const FParams fp, const unsigned long long *super) {
     const KParams &p = fp.k;
     __shared__ unsigned long long wsum[16];
@@ -632,12 +635,15 @@ __global__ __launch_bounds__(1024) void k_resolve(const FParams fp, const unsign
         }
     }
 }
+#endif
 
 // the main pass's per-tile terminator counts as k_scan_tiles reads them (td_count_and_split_device: the splitter's line
 // prefix without a second pass over the bytes)
+#ifndef TD_INST_ONLY      // (defined once, in tagdig.hip's translation unit)
 __global__ __launch_bounds__(256) void k_info_counts(const uint32_t *tile_info, uint32_t ntiles, uint64_t *tile_counts) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < ntiles) tile_counts[i] = tile_info[i] & TI_COUNT_MASK;
 }
+#endif
 
 }  // namespace tdk

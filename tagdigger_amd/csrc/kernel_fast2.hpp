@@ -647,3 +647,22 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
 }
 
 }  // namespace tdk
+
+// (tag width in 64-bit words, 16-byte pieces packed per line) the host picks from: see pick_fast2_c in tagdig.hip
+#define TD_FAST2_COMBOS(X) X(1, 3) X(1, 4) X(1, 6) X(2, 5) X(2, 6) X(2, 8) X(3, 7) X(3, 8) X(3, 10)
+#ifdef TD_FAST2_EXTERN
+// instantiated in inst_fast2.hip's translation units
+#define TD_X4F(W, NQ) extern template __global__ void tdk::k_fast2<4, W, NQ, false>(const tdk::FParams);
+#define TD_X6F(W, NQ) extern template __global__ void tdk::k_fast2<6, W, NQ, false>(const tdk::FParams);
+#define TD_X8F(W, NQ) extern template __global__ void tdk::k_fast2<8, W, NQ, false>(const tdk::FParams);
+#define TD_X4T(W, NQ) extern template __global__ void tdk::k_fast2<4, W, NQ, true>(const tdk::FParams);
+#define TD_X6T(W, NQ) extern template __global__ void tdk::k_fast2<6, W, NQ, true>(const tdk::FParams);
+#define TD_X8T(W, NQ) extern template __global__ void tdk::k_fast2<8, W, NQ, true>(const tdk::FParams);
+TD_FAST2_COMBOS(TD_X4F) TD_FAST2_COMBOS(TD_X6F) TD_FAST2_COMBOS(TD_X8F) TD_FAST2_COMBOS(TD_X4T) TD_FAST2_COMBOS(TD_X6T) TD_FAST2_COMBOS(TD_X8T)
+#undef TD_X4F
+#undef TD_X6F
+#undef TD_X8F
+#undef TD_X4T
+#undef TD_X6T
+#undef TD_X8T
+#endif

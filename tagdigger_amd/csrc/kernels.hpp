@@ -958,6 +958,7 @@ __global__ __launch_bounds__(BLOCK) void k_count_lines(const uint8_t *buf, uint6
 }
 
 // single block: state[i] = FLAG_INC | inclusive prefix of tile_counts; total -> *total_out
+#ifndef TD_INST_ONLY      // (defined once, in tagdig.hip's translation unit)
 __global__ __launch_bounds__(1024) void k_scan_tiles(const uint64_t *tile_counts, uint32_t ntiles, uint64_t *state,
                                                      unsigned long long *total_out) {
     __shared__ unsigned long long wsum[16];
@@ -988,5 +989,6 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint64_t *tile_counts
     }
     if (tid == 0 && total_out) *total_out = carry;
 }
+#endif
 
 }  // namespace tdk

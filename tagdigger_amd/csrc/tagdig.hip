@@ -21,6 +21,7 @@
 #include "../../include/td_synth_spec.h"
 #include "kernels.hpp"
 #include "kernel_fast.hpp"
+#define TD_FAST2_EXTERN 1           // the instantiations of k_fast2 live in inst_fast2.hip (six translation units)
 #include "kernel_fast2.hpp"
 #include "kernel_splitter.hpp"
 #include "kernel_splitter2.hpp"
