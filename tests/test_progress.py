@@ -231,3 +231,36 @@ def test_cli_on_several_devices_prints_the_progress_lines_in_file_order(tmp_path
         os.chdir(old)
     got = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("Reads: ")]
     assert got == want and len(want) == 5
+
+
+@pytest.mark.gpu
+def test_progress_lines_with_tassel_tagcount(tmp_path, capsys):
+    """tassel_tagcount=True (the exact kernel with the header's count=N as the weight, :251-253,:264-265): tagcount in
+    the progress line still counts READS (:263), the matrix counts weights."""
+    from tagdigger_amd import tagdigger_fun as tf
+    rnd = random.Random(99)
+    barcodes, tags, cutsites = helpers.small_index(rnd, "TGCAG", nbar=6, ntag=30)
+    recs = []
+    for i in range(120_000):
+        b, t = rnd.choice(barcodes), rnd.choice(tags)
+        u = rnd.random()
+        seq = b + t + "ACGT" if u < 0.6 else b + "TGCAG" + "".join(rnd.choice("ACGT") for _ in range(30)) if u < 0.8 else \
+            "".join(rnd.choice("ACGTN") for _ in range(50))
+        recs.append("@t%d count=%d\n%s\n+\n%s\n" % (i, rnd.randint(1, 40), seq, "I" * len(seq)))
+    raw = "".join(recs).encode()
+    (tmp_path / "tassel.fq").write_bytes(raw)
+    o = c_oracle.COracle(barcodes, tags, "TGCAG")
+    want_lines = []
+    for k in (1, 2):
+        st = {}
+        o.count_bytes(raw, maxreads=50000 * k, tassel_tagcount=True, stats=st)
+        want_lines.append("Reads: {0} With barcode and cut site: {1} With tag: {2}".format(50000 * k, st["barcut"], st["tag"]))
+    want = o.count_bytes(raw, tassel_tagcount=True)
+    old = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        got = tf.find_tags_fastq("tassel.fq", barcodes, tags, tassel_tagcount=True)
+    finally:
+        os.chdir(old)
+    assert capsys.readouterr().out.splitlines() == want_lines
+    assert got == [[int(v) for v in row] for row in want.astype("int64")]
