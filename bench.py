@@ -479,7 +479,7 @@ def tiers(eng, cfg, reads):
         eng.dev_free(dw)
         return w
     want = expected(reads)
-    out = {"reads": reads, "stage_threads": int(os.environ.get("TAGDIG_STAGE_THREADS", "8")),
+    out = {"reads": reads, "stage_threads": int(os.environ.get("TAGDIG_STAGE_THREADS", "16" if (os.cpu_count() or 1) >= 32 else "8")),
            "inflate_threads": os.environ.get("TAGDIG_INFLATE_THREADS", "default (host cores, at most %s)" % os.environ.get("TAGDIG_INFLATE_MAX", "16"))}
 
     def timed(fn, n, w):

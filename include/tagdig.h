@@ -198,7 +198,7 @@ int td_inflate_raw_host(const void *in, uint32_t in_len, void *out, uint32_t out
 int64_t td_format_csv_row(const int64_t *vals, uint64_t n, char *out, uint64_t capacity);
 
 /* ---- environment ------------------------------------------------------------
- * TAGDIG_STAGE_THREADS    host threads that copy / pread a piece into pinned memory (default 8, 1..16)
+ * TAGDIG_STAGE_THREADS    host threads that copy / pread a piece into pinned memory (default 16 on hosts with 32 cores or more, else 8; 1..16)
  * TAGDIG_INFLATE_THREADS  host threads for BGZF member-parallel and gzip chunk-parallel inflate (default: cores, at most 16)
  * TAGDIG_PAR_INFLATE      0: ordinary gzip always on one thread; 1: always chunk-parallel (default: from 8 MiB compressed)
  * TAGDIG_INFLATE_CHUNK    compressed bytes per chunk of the chunk-parallel decoder (default 1 MiB; two chunks per thread and batch)

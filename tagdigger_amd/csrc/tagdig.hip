@@ -884,7 +884,9 @@ size_t cut_at_line_end(const uint8_t *p, size_t n) {
 inline int stage_threads() {
     static const int n = []() {
         const char *env = getenv("TAGDIG_STAGE_THREADS");
-        const long v = env ? atol(env) : 8;
+        // (default: 16 where the host has the cores -- measured 46 vs 45 GB/s from a host buffer, 36 vs 32 GB/s from a
+        // plain file against 8 -- else 8)
+        const long v = env ? atol(env) : (std::thread::hardware_concurrency() >= 32 ? 16 : 8);
         return (int)std::max<long>(1, std::min<long>(v, 16));
     }();
     return n;
