@@ -176,8 +176,10 @@ int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]);
  * td_set_option(h, "progress", 1) set before counting, the device keeps, per window of 50 000 consecutive reads
  * (read ordinals of the whole stream, across streamed pieces), how many reads had a barcode + cut site and how
  * many a tag; this returns them: out[2 w] = barcutcount and out[2 w + 1] = tagcount of the reads in window w,
- * for w < min(*nwindows, cap), where *nwindows = ceil(reads / 50 000).  Running sums over w give the numbers the
- * reference prints after read 50 000 (w + 1).  Cumulative since td_reset; synchronises like td_get_stats. */
+ * for w < cap (windows without reads are zero), and *nwindows = ceil(reads / 50 000) for the reads THIS handle
+ * counted -- a handle that counted from read 0 on needs no more than that many; the shard of a byte-sharded file
+ * (first_line > 0) asks for the windows of the whole file.  Running sums over w give the numbers the reference
+ * prints after read 50 000 (w + 1).  Cumulative since td_reset; synchronises like td_get_stats. */
 int td_get_progress(td_handle *h, uint64_t *out, uint64_t cap, uint64_t *nwindows);
 
 /* K3 of SURVEY 8e: add this library's barcode rows into the run's sample rows on the device --

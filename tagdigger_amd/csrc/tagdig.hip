@@ -1190,10 +1190,12 @@ int td_get_progress(td_handle *h, uint64_t *out, uint64_t cap, uint64_t *nwindow
     if (!h->progress) return fail(TD_E_STATE, "option progress is off");
     const uint64_t n = (st[TD_STAT_READS] + tdk::PROG_WINDOW - 1) / tdk::PROG_WINDOW;      // windows that hold a read
     *nwindows = n;
-    const uint64_t take = std::min<uint64_t>(std::min(n, cap), h->d_win.n);
+    // every window the caller has room for, whatever this handle's own read count says: a byte-sharded file's later
+    // shards hold reads of high ordinals only (windows the handle never touched read as zero)
+    const uint64_t take = std::min<uint64_t>(cap, h->d_win.n);
     std::vector<unsigned long long> w(take);
     if (take) HIPCHK(hipMemcpy(w.data(), h->d_win.p, take * 8, hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < std::min(n, cap); i++) {
+    for (uint64_t i = 0; i < cap; i++) {
         const unsigned long long v = i < take ? w[i] : 0ull;
         out[2 * i] = v & 0xFFFFFFFFull; out[2 * i + 1] = v >> 32;
     }

@@ -251,14 +251,17 @@ class Engine:
         B.check(self._L.td_get_stats(self._h, st))
         return {"reads": st[0], "barcut": st[1], "tag": st[2], "lines": st[3]}
 
-    def progress_windows(self):
+    def progress_windows(self, nwindows=None):
         """[(reads with barcode + cut site, reads with tag)] per window of 50 000 reads, in read order (option
-        "progress" must have been on while counting); the last window may be partly filled."""
+        "progress" must have been on while counting); the last window may be partly filled.  nwindows: that many
+        windows from read 0 on (a shard of a byte-sharded file holds reads of high ordinals only); default: the
+        windows of the reads this engine counted."""
         n = C.c_uint64(0)
         B.check(self._L.td_get_progress(self._h, None, 0, C.byref(n)))
-        out = (C.c_uint64 * max(1, 2 * n.value))()
-        B.check(self._L.td_get_progress(self._h, out, n.value, C.byref(n)))
-        return [(out[2 * i], out[2 * i + 1]) for i in range(n.value)]
+        want = n.value if nwindows is None else int(nwindows)
+        out = (C.c_uint64 * max(1, 2 * want))()
+        B.check(self._L.td_get_progress(self._h, out, want, C.byref(n)))
+        return [(out[2 * i], out[2 * i + 1]) for i in range(want)]
 
     def progress_lines(self, fqfile):
         """The lines the reference's loop prints while it reads (tagdigger_fun.py:268-271): the file name after

@@ -131,7 +131,8 @@ def count_terminators(data):
     return n
 
 
-def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, counter=None, device=None, as_array=False):
+def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, counter=None, device=None, as_array=False,
+                       progress=False):
     """find_tags_fastq on one plain FASTQ file, byte-sharded over the ranks of the default process
     group (every rank calls this with the same arguments; backend "nccl" = RCCL for GPUs).
     Returns the whole file's matrix on every rank, bit-identical to the single-GPU result for any
@@ -142,7 +143,9 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
     (-> this shard's first line index), the shard is counted in place with the global maxreads bound, and the
     device matrix is all-reduced.
     counter(data, barcodes, tags, cutsite, first_line, maxreads) -> matrix stands in for the GPU in the CPU
-    rehearsal."""
+    rehearsal.
+    progress=True (device path): rank 0 prints the reference's progress lines (:268-271) -- every shard keeps its
+    per-window counters by GLOBAL read ordinal, so the windows of all ranks simply add up (one more small all-reduce)."""
     import math
     rank, world = _rank_world()
     if path[-2:].lower() == 'gz':
@@ -170,6 +173,7 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
             dev = torch.device("cuda", int(device or 0))
         eng = tagdigger_fun.default_engine(dev.index)
         eng.set_index(barcodes, tags, cutsite)
+        eng.set_option("progress", 1 if progress else 0)
         total = torch.zeros(len(barcodes) * len(tags), dtype=torch.int32, device=dev)
         shard = torch.empty(max(16, data.size), dtype=torch.uint8, device=dev)         # (torch allocations are 256-byte aligned)
         if data.size:
@@ -181,11 +185,32 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
         try:
             if data.size and (first_line + 2) // 4 < bound:
                 eng.count_device(shard.data_ptr(), int(data.size), first_line=first_line, maxreads=bound)
-            eng.stats()                                        # (synchronises; raises what a kernel flagged)
+            st = eng.stats()                                   # (synchronises; raises what a kernel flagged)
+            if progress:
+                # reads of the whole file, then every rank's windows laid over the same axis and summed
+                # (before the matrix is unbound: unbinding resets the handle's results, the windows with them)
+                reads = torch.tensor([st["reads"]], dtype=torch.int64, device=dev)
+                if world > 1:
+                    dist.all_reduce(reads)
+                nwin = int(reads[0]) // 50000
+                win = torch.zeros((max(1, nwin), 2), dtype=torch.int64, device=dev)
+                mine = eng.progress_windows(nwin)
+                if mine:
+                    win[:len(mine)] = torch.tensor(mine, dtype=torch.int64, device=dev)
+                if world > 1:
+                    dist.all_reduce(win)
         finally:
             eng.bind_counts(0)
+            eng.set_option("progress", 0)
         if world > 1:
             dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        if progress and rank == 0:
+            bar = tag = 0
+            for k in range(nwin):
+                bar, tag = bar + int(win[k, 0]), tag + int(win[k, 1])
+                if 50000 * (k + 1) % 1000000 == 0:
+                    print(path)
+                print("Reads: {0} With barcode and cut site: {1} With tag: {2}".format(50000 * (k + 1), bar, tag))
         out = total.cpu().numpy().view(np.uint32).astype(np.int64).reshape(len(barcodes), len(tags))
     else:
         first_line = first_line_of(count_terminators(data), "cpu")

@@ -264,3 +264,39 @@ def test_progress_lines_with_tassel_tagcount(tmp_path, capsys):
         os.chdir(old)
     assert capsys.readouterr().out.splitlines() == want_lines
     assert got == [[int(v) for v in row] for row in want.astype("int64")]
+
+
+def _sharded_worker(rank, world, port, path, barcodes, tags, cutsite, maxreads):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tagdigger_amd import multi
+    multi.count_file_sharded(path, barcodes, tags, cutsite, maxreads=maxreads, device=torch.device("cuda", 0), progress=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maxreads", [5e9, 170_000])
+def test_byte_sharded_file_prints_the_progress_lines(tmp_path, capfd, maxreads):
+    """One file over two ranks (gloo rehearsal on one GPU): each shard keeps its windows by global read ordinal, the
+    windows are summed, rank 0 prints what one process would have printed."""
+    import socket
+    import torch.multiprocessing as mp
+    from tagdigger_amd.synth import SynthConfig
+    cfg = SynthConfig(nreads=260_000, nbar=8, nmarkers=50, seed=2468, cutsite="TGCAG", bclen=(4, 8))
+    host = helpers.synth_host_bytes(cfg, 0, cfg.nreads)
+    path = str(tmp_path / "one_file.fq")
+    host.tofile(path)
+    o = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite)
+    n = int(min(maxreads, cfg.nreads))
+    want = ["Reads: {0} With barcode and cut site: {1} With tag: {2}".format(50000 * (k + 1), a, b)
+            for k, (a, b) in enumerate(boundary_stats(o, host, n))]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_sharded_worker, args=(2, port, path, cfg.barcodes, cfg.tags, cfg.cutsite, maxreads), nprocs=2, join=True)
+    got = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("Reads: ")]
+    assert got == want and len(want) == n // 50000
