@@ -2,7 +2,7 @@
 """Re-create one case of tests/test_gpu_parity.py::test_fuzz_campaign by seed and find the shortest
 prefix (in lines) on which the GPU and the C oracle disagree.  usage: fuzz_repro.py SEED [opt=value ...]"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import tagdigger_amd

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One case of tests/test_splitter.py::test_gpu_split_fuzz_campaign by seed: where the decisions differ, with the record's place in the buffer."""
 import contextlib, io, os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_splitter as ts
 import tagdigger_amd

@@ -1,10 +1,10 @@
 import os, sys, time
 ROOT=os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import tagdigger_amd
 from tagdigger_amd.synth import SynthConfig
-from helpers import bgzf_bytes
+from compress_formats import bgzf_bytes
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 cfg = SynthConfig(nreads=reads, nbar=384, nmarkers=50_000, seed=3)
 eng = tagdigger_amd.Engine(0)

@@ -4,12 +4,12 @@
 H2D -> count), TAGDIG_INFLATE_THREADS = 8 .. 64.   usage: inflate_scale.py [reads] [gzip level]"""
 import ctypes as C, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import tagdigger_amd
 from tagdigger_amd import _binding as B
 from tagdigger_amd.synth import SynthConfig
-from helpers import bgzf_bytes
+from compress_formats import bgzf_bytes
 
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
