@@ -72,6 +72,18 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
         if (p.site0_len == 0) rs0 = start;                           // (an empty site is found at `start` itself)
         if (p.site1_len == 0) rs1 = start;
         uint32_t H[4] = {0u, 0u, 0u, 0u};                            // per letter A C T G: bits 16-31 this piece, 0-15 the one before
+        // SP[site][letter]: bit `back` set where the site's character `back` places before its last is that letter (uniform)
+        uint32_t SP[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+        for (int which = 0; which < 2; which++) {
+            const uint32_t L = which ? p.site1_len : p.site0_len;
+            const unsigned long long site = which ? p.site1 : p.site0;          // last character in the low byte
+            for (uint32_t back = 0; back < L; back++) {
+                const uint32_t code = ((uint32_t)(site >> (8u * back)) >> 1) & 3u;   // A C T G = 0 1 2 3
+#pragma unroll
+                for (int c = 0; c < 4; c++) SP[which][c] |= code == (uint32_t)c ? 1u << back : 0u;
+            }
+        }
         const uint32_t k0 = start >> 4;
         for (uint32_t k = k0; 16u * k < len && (rs0 == 0xFFFFFFFFu || rs1 == 0xFFFFFFFFu); k++) {
             uint4 v = lds_read16(src + 16u * k);
@@ -86,13 +98,19 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
 #pragma unroll
             for (int which = 0; which < 2; which++) {
                 const uint32_t L = which ? p.site1_len : p.site0_len;
-                const unsigned long long site = which ? p.site1 : p.site0;      // last character in the low byte
+                // a site ends at bit b of the current piece where, for each of its characters `back` places before its
+                // last, that letter's history has bit b - back: per letter, the places it takes in the site (uniform
+                // masks, made once per line below) -- a shift and an AND per character, no selects
                 uint32_t M = L ? 0xFFFF0000u : 0u;                                // (an empty site was settled above)
-                for (uint32_t back = 0; back < L; back++) {                       // (uniform: the sites are the launch's)
-                    const uint32_t ch = (uint32_t)(site >> (8u * back)) & 0xFFu; // the site's character `back` places before its last
-                    const uint32_t code = (ch >> 1) & 3u;                         // A C T G = 0 1 2 3
-                    const uint32_t h = code == 0 ? H[0] : code == 1 ? H[1] : code == 2 ? H[2] : H[3];
-                    M &= h << back;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    uint32_t places = SP[which][c];
+                    const uint32_t h = H[c];
+                    while (places) {
+                        const uint32_t back = (uint32_t)__builtin_ctz(places);
+                        places &= places - 1u;
+                        M &= h << back;
+                    }
                 }
                 const uint32_t ends = M >> 16;
                 if (ends) {
