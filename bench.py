@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -58,6 +58,14 @@ def main():
     ap.add_argument("--oracle-sample", type=int, default=2_000_000,
                     help="reads of the resident stream counted by the C oracle and compared with a GPU pass over the same bytes (0 = skip)")
     ap.add_argument("--tier-reads", type=int, default=16_000_000, help="reads in the T2/T3 tier measurements (0 = skip)")
+    ap.add_argument("--other-configs", default="auto",
+                    help="BASELINE configs measured after the headline at N=1 (3 steps each, full read count, bit-exact check); "
+                         "auto = 2,4,5 with the default workload, none otherwise; '' = skip")
+    ap.add_argument("--other-reads", type=int, default=0, help="reads of those passes (0 = each config's own count)")
+    ap.add_argument("--traffic", default="auto", choices=("auto", "off"),
+                    help="roofline.traffic: 'auto' = two rocprofv3 --pmc child runs of this script (FETCH_SIZE, WRITE_SIZE) when "
+                         "rocprofv3 is on PATH, else null")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # (the counter passes' run: launches only)
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--stagger", type=int, default=-1)
     ap.add_argument("--table-load", type=int, default=0)
@@ -65,20 +73,125 @@ def main():
     ap.add_argument("--prio", type=lambda v: int(v, 0), default=-1)
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to td_set_option (repeatable)")
     ap.add_argument("--debug-ablate", type=int, default=0, help="timing-only kernel ablation bits (implies --no-check)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
 
+def self_launch(args):
+    """`bench.py --gpus N` from a bare shell: N fresh ranks under torch.distributed.run, started BEFORE this
+    process has touched the GPU (it never does); rank 0's JSON line and the launcher's exit code are relayed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def is_default_workload(args):
+    return (args.config == 3 and not (args.reads or args.barcodes or args.markers or args.cutsite or args.bclen_max
+                                      or args.skew or args.seed >= 0 or args.tile_kb or args.blocks_per_cu or args.opt
+                                      or args.debug_ablate or args.stagger >= 0 or args.table_load or args.nt >= 0 or args.prio >= 0))
+
+
+def measure_traffic(args):
+    """roofline.traffic, live: this script again as a child of `rocprofv3 --pmc <counter>` (one pass per counter:
+    the TCC slots do not hold both), launches only, before this process touches the GPU.  Returns the dict that
+    goes into the line, or None (no rocprofv3, a failed pass)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if not prof:
+        return None
+    got = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="tdpmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--steps", "2", "--warmup", "1"]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=300)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                return None
+            vals = {}
+            for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and "k_fast2" in row.get("Kernel_Name", ""):
+                            vals.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            name, v = max(vals.items(), key=lambda kv: max(kv[1]))
+            got[counter] = (name, sum(v) / len(v) * 1024.0, len(v))           # (reported in KiB per dispatch)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]
+    return {"fabric_bytes_per_launch": 2 * fetch + write, "FETCH_SIZE_bytes_raw": fetch, "WRITE_SIZE_bytes": write,
+            "kernel": got["FETCH_SIZE"][0], "dispatches": got["FETCH_SIZE"][2], "seconds": time.perf_counter() - t0,
+            "what": "2 x FETCH_SIZE + WRITE_SIZE of the main pass, two rocprofv3 --pmc child runs of this script in this run "
+                    "(gfx950 tallies a wide coalesced read stream at half its bytes: MI355X_MICROARCH.md, HBM); requests at the "
+                    "L2's memory side, Infinity-Cache hits included: fabric traffic, an upper bound of the HBM bytes"}
+
+
+def make_config(args, cid, reads=0):
+    from tagdigger_amd.synth import CONFIGS, SynthConfig
+    base = dict(CONFIGS[cid])
+    if cid in (4, 5):
+        base["nreads"] = 200_000_000                    # (one library; config 5's 1 B reads are five of them)
+    if reads:
+        base["nreads"] = reads
+    if cid == args.config:
+        if args.barcodes:
+            base["nbar"] = args.barcodes
+        if args.markers:
+            base["nmarkers"] = args.markers
+        if args.seed >= 0:
+            base["seed"] = args.seed
+        if args.cutsite:
+            base["cutsite"] = args.cutsite
+        if args.bclen_max:
+            base["bclen"] = (4, args.bclen_max)
+        if args.skew:
+            base["skew"] = args.skew
+    return SynthConfig(**base)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
-                  file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    if args.debug_ablate or args.pmc_child:
+        args.no_check = True
+    default_workload = is_default_workload(args)
+    # the counter passes come first: their children must be started by a process that has not initialised HIP
+    traffic = None
+    if world == 1 and default_workload and args.traffic == "auto" and not args.pmc_child:
+        traffic = measure_traffic(args)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     # TD_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- a correctness rehearsal of the N > 1 code
     # path on a one-GPU box (never a measurement)
     rehearsal = os.environ.get("TD_BENCH_REHEARSAL") == "1"
@@ -86,36 +199,18 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
     import tagdigger_amd
-    from tagdigger_amd.synth import CONFIGS, SynthConfig
 
-    base = dict(CONFIGS[args.config])
-    if args.config in (4, 5):
-        base["nreads"] = 200_000_000                    # (one library; config 5's 1 B reads are five of them)
-    if args.reads:
-        base["nreads"] = args.reads
-    if args.barcodes:
-        base["nbar"] = args.barcodes
-    if args.markers:
-        base["nmarkers"] = args.markers
-    if args.seed >= 0:
-        base["seed"] = args.seed
-    if args.cutsite:
-        base["cutsite"] = args.cutsite
-    if args.bclen_max:
-        base["bclen"] = (4, args.bclen_max)
-    if args.skew:
-        base["skew"] = args.skew
-    cfg = SynthConfig(**base)
-    default_workload = (args.config == 3 and not (args.reads or args.barcodes or args.markers or args.cutsite or args.bclen_max
-                                                   or args.skew or args.seed >= 0))
+    cfg = make_config(args, args.config, args.reads)
     eng = tagdigger_amd.Engine(local_rank)
     if args.tile_kb:
         eng.set_option("tile_kb", args.tile_kb)
@@ -134,21 +229,7 @@ def main():
         eng.set_option(k, int(v, 0))
     if args.debug_ablate:
         eng.set_option("debug_ablate", args.debug_ablate)
-        args.no_check = True
 
-    # ---- this rank's share of the stream
-    if args.scaling == "weak":
-        my_reads, first_read = cfg.nreads, rank * cfg.nreads         # its own library = its own slice of the stream
-        first_line = 0                                               # ... a file of its own: line 0
-        job_reads = cfg.nreads * world
-    else:
-        lo, hi = cfg.nreads * rank // world, cfg.nreads * (rank + 1) // world
-        my_reads, first_read = hi - lo, lo                           # a byte range of ONE file, cut at line starts
-        first_line = 4 * lo                                          # ... counted with its true line index
-        job_reads = cfg.nreads
-    nbytes = my_reads * cfg.record_bytes
-    fastq = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    cfg.fill_device(eng, fastq.data_ptr(), first_read, my_reads)
     # The matrix lives in torch tensors so that RCCL can reduce it in place.  With several GPUs there are
     # two: the all-reduce of one pass (the path's one exchange: an integer sum over xGMI) runs on RCCL's
     # stream while the next pass counts into the other matrix.
@@ -159,20 +240,11 @@ def main():
     eng.bind_counts(counts.data_ptr())
     eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
     stream = torch.cuda.current_stream().cuda_stream
-    passes = [0]
-
-    def step():
-        b = passes[0] % nmat
-        passes[0] += 1
-        if reducing[b] is not None:       # this matrix's previous all-reduce (two passes ago)
-            reducing[b].wait()
-            reducing[b] = None
-        mats[b].zero_()
-        eng.bind_counts(mats[b].data_ptr())
-        eng.count_device(fastq.data_ptr(), nbytes, first_line=first_line, stream=stream)
-        if world > 1:
-            reducing[b] = dist.all_reduce(mats[b], async_op=True)
-        return mats[b]
+    # this rank's share of the stream: weak = its own library (a file of its own: line 0), strong = a byte range of
+    # ONE file, cut at line starts and counted with its true line index
+    weak_reads = cfg.nreads
+    lo, hi = cfg.nreads * rank // world, cfg.nreads * (rank + 1) // world
+    fastq = torch.empty(max(weak_reads, hi - lo) * cfg.record_bytes, dtype=torch.uint8, device=dev)
 
     def fence():
         for b in range(nmat):
@@ -184,89 +256,132 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
+    def run_scaling(scaling):
+        """warm-up, the check of what is timed, the timed region; returns this rank's view (rank 0's is printed)"""
+        if scaling == "weak":
+            my_reads, first_read, first_line, job_reads = weak_reads, rank * weak_reads, 0, weak_reads * world
+        else:
+            my_reads, first_read, first_line, job_reads = hi - lo, lo, 4 * lo, cfg.nreads
+        nbytes = my_reads * cfg.record_bytes
+        cfg.fill_device(eng, fastq.data_ptr(), first_read, my_reads)
+        passes = [0]
 
-    # ---- correctness of what is being timed (rank-local shard, before any all-reduce)
-    check = None
-    if not args.no_check:
-        # (1) the whole matrix against the one the generator's own choices imply (built on the device from
-        # the shared spec include/td_synth_spec.h; nothing is parsed, nothing of oracle/ is involved)
-        counts.zero_()
-        eng.reset()
-        eng.bind_counts(counts.data_ptr())
-        eng.count_device(fastq.data_ptr(), nbytes, first_line=first_line, stream=stream)
-        torch.cuda.synchronize()
-        want = torch.zeros_like(counts)
-        hits = cfg.expected_device(eng, want.data_ptr(), first_read, my_reads)
-        st = eng.stats()
-        ok = bool(torch.equal(counts, want)) and st["tag"] == hits and st["reads"] == my_reads
-        check = {"bit_exact_vs_expected": ok, "reads": int(st["reads"]), "barcut": int(st["barcut"]), "tag": int(st["tag"])}
-        del want
-        if not ok:
-            print("bench.py: rank %d COUNT MISMATCH against the generator's expected matrix" % rank, file=sys.stderr)
-            sys.exit(3)
-        # (2) an independent checker on a sample: the first reads of the RESIDENT bytes, copied back and
-        # counted by the C oracle, against a GPU pass over exactly that prefix
-        if rank == 0 and args.oracle_sample > 0:
-            n = min(args.oracle_sample, my_reads)
+        def step():
+            b = passes[0] % nmat
+            passes[0] += 1
+            if reducing[b] is not None:       # this matrix's previous all-reduce (two passes ago)
+                reducing[b].wait()
+                reducing[b] = None
+            mats[b].zero_()
+            eng.bind_counts(mats[b].data_ptr())
+            eng.count_device(fastq.data_ptr(), nbytes, first_line=first_line, stream=stream)
+            if world > 1:
+                reducing[b] = dist.all_reduce(mats[b], async_op=True)
+            return mats[b]
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+
+        # ---- correctness of what is being timed (rank-local shard, before any all-reduce)
+        check = None
+        if not args.no_check:
+            # (1) the whole matrix against the one the generator's own choices imply (built on the device from
+            # the shared spec include/td_synth_spec.h; nothing is parsed, nothing of oracle/ is involved)
             counts.zero_()
             eng.reset()
-            eng.count_device(fastq.data_ptr(), n * cfg.record_bytes, first_line=first_line, stream=stream)
+            eng.bind_counts(counts.data_ptr())
+            eng.count_device(fastq.data_ptr(), nbytes, first_line=first_line, stream=stream)
             torch.cuda.synchronize()
-            gst = eng.stats()
-            sample = fastq[:n * cfg.record_bytes].cpu().numpy()
-            okc, ost = oracle_check(cfg, sample, first_line, counts.cpu().numpy().view(np.uint32))
-            okc = okc and (gst["reads"], gst["barcut"], gst["tag"]) == (ost["reads"], ost["barcut"], ost["tag"])
-            check["oracle_sample"] = {"reads": n, "bit_exact_vs_c_oracle": bool(okc), "tag": int(ost["tag"])}
-            del sample
-            if not okc:
-                print("bench.py: GPU counts differ from the C oracle on the first %d reads" % n, file=sys.stderr)
+            want = torch.zeros_like(counts)
+            hits = cfg.expected_device(eng, want.data_ptr(), first_read, my_reads)
+            st = eng.stats()
+            ok = bool(torch.equal(counts, want)) and st["tag"] == hits and st["reads"] == my_reads
+            check = {"bit_exact_vs_expected": ok, "reads": int(st["reads"]), "barcut": int(st["barcut"]), "tag": int(st["tag"]),
+                     "what": "whole matrix + counters against the generator's expected matrix (product code sharing include/td_synth_spec.h "
+                             "with the generator); the independent C-oracle parse is oracle_sample"}
+            del want
+            if not ok:
+                print("bench.py: rank %d COUNT MISMATCH against the generator's expected matrix" % rank, file=sys.stderr)
                 sys.exit(3)
-        counts.zero_()
-        eng.reset()
+            # (2) an independent checker on a sample: the first reads of the RESIDENT bytes, copied back and
+            # counted by the C oracle, against a GPU pass over exactly that prefix
+            if rank == 0 and args.oracle_sample > 0:
+                n = min(args.oracle_sample, my_reads)
+                counts.zero_()
+                eng.reset()
+                eng.count_device(fastq.data_ptr(), n * cfg.record_bytes, first_line=first_line, stream=stream)
+                torch.cuda.synchronize()
+                gst = eng.stats()
+                sample = fastq[:n * cfg.record_bytes].cpu().numpy()
+                okc, ost = oracle_check(cfg, sample, first_line, counts.cpu().numpy().view(np.uint32))
+                okc = okc and (gst["reads"], gst["barcut"], gst["tag"]) == (ost["reads"], ost["barcut"], ost["tag"])
+                check["oracle_sample"] = {"reads": n, "bit_exact_vs_c_oracle": bool(okc), "tag": int(ost["tag"])}
+                del sample
+                if not okc:
+                    print("bench.py: GPU counts differ from the C oracle on the first %d reads" % n, file=sys.stderr)
+                    sys.exit(3)
+            counts.zero_()
+            eng.reset()
 
-    eng.set_option("timing", 1)
-    eng.kernel_times_ms()                 # (drop what the check launched)
-    fence()
-    t0 = time.perf_counter()
-    last = counts
-    for _ in range(args.steps):
-        last = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ktimes = eng.kernel_times_ms()
-    kms = sum(ktimes) / len(ktimes) if ktimes else 0.0
-    fixups = eng.debug_counters()[11]
-    eng.set_option("timing", 0)
+        eng.set_option("timing", 1)
+        eng.kernel_times_ms()                 # (drop what the check launched)
+        fence()
+        t0 = time.perf_counter()
+        last = counts
+        for _ in range(args.steps):
+            last = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        ktimes = eng.kernel_times_ms()
+        kms = sum(ktimes) / len(ktimes) if ktimes else 0.0
+        fixups = eng.debug_counters()[11]
+        eng.set_option("timing", 0)
 
-    if world > 1:
-        t = torch.tensor([elapsed, kms], dtype=torch.float64, device=dev)
+        if world > 1:
+            t = torch.tensor([elapsed, kms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, kms = float(t[0]), float(t[1])
+            # every rank now holds the same summed matrix: its total must equal the sum of all shards' hits
+            tot = torch.tensor([int(last.to(torch.int64).sum())], dtype=torch.int64, device=dev)
+            mine = torch.tensor([check["tag"] if check else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(mine)
+            if check:
+                check["reduced_total_equals_sum_of_shard_hits"] = int(tot[0]) == int(mine[0])
+                if int(tot[0]) != int(mine[0]):
+                    print("bench.py: all-reduced matrix total %d != sum of shard hits %d" % (int(tot[0]), int(mine[0])),
+                          file=sys.stderr)
+                    sys.exit(3)
+        return {"scaling": scaling, "my_reads": my_reads, "nbytes": nbytes, "first_line": first_line, "job_reads": job_reads,
+                "elapsed": elapsed, "kms": kms, "ktimes": ktimes, "fixups": fixups, "check": check, "step": step}
+
+    def allreduce_alone():
+        """the path's one exchange by itself: the int32 [barcodes x tags] matrix, in place, median of 5 (max over ranks)"""
+        ts = []
+        for _ in range(6):
+            fence()
+            t0 = time.perf_counter()
+            dist.all_reduce(mats[0])
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        t = torch.tensor([sorted(ts[1:])[2]], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kms = float(t[0]), float(t[1])
-        # every rank now holds the same summed matrix: its total must equal the sum of all shards' hits
-        tot = torch.tensor([int(last.to(torch.int64).sum())], dtype=torch.int64, device=dev)
-        mine = torch.tensor([check["tag"] if check else 0], dtype=torch.int64, device=dev)
-        dist.all_reduce(mine)
-        if check and int(tot[0]) != int(mine[0]):
-            print("bench.py: all-reduced matrix total %d != sum of shard hits %d" % (int(tot[0]), int(mine[0])),
-                  file=sys.stderr)
-            sys.exit(3)
+        mats[0].zero_()
+        return float(t[0]) * 1e3
 
-    if rank == 0:
-        value = job_reads * args.steps / elapsed
+    main_run = run_scaling(args.scaling)
+    strong_run = None
+    if world > 1 and args.scaling == "weak" and not args.pmc_child:
+        strong_run = run_scaling("strong")                 # (the metric's literal reading: ONE library over the N GPUs)
+    allreduce_ms = allreduce_alone() if world > 1 else None
+    R = main_run
+    my_reads, nbytes, first_line, kms, ktimes = R["my_reads"], R["nbytes"], R["first_line"], R["kms"], R["ktimes"]
+    step = R["step"]
+
+    if rank == 0 and not args.pmc_child:
+        value = R["job_reads"] * args.steps / R["elapsed"]
         algo_bytes = cfg.record_bytes * my_reads
         achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        # HBM traffic from the PMC passes (profiles/pmc_traffic.json, tools/profile_round.sh): a property of the
-        # DEFAULT workload -- any other shape or option set reports null rather than a number it did not measure
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if default_workload and world == 1 and not (args.tile_kb or args.blocks_per_cu or args.opt) and os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         metric = "FASTQ reads/sec (whole node), 200M-read × 100k-tag synthetic, 1/2/4/8 MI355X"
         try:                                              # (verbatim from BASELINE.json when it is there)
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
@@ -281,7 +396,7 @@ def main():
         out = {
             "metric": metric,
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": R["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d] shape, device-resident (tier T1): %d reads x %d barcodes x %d tags "
                                    "per GPU, 100 bp reads, %d B/record, cut site %s%s, %s"
@@ -291,13 +406,28 @@ def main():
                        "reads_per_gpu": my_reads, "barcodes": len(cfg.barcodes), "tags": len(cfg.tags),
                        "fastq_bytes_per_gpu": nbytes, "sharding": sharding},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic["fabric_bytes_per_launch"] if traffic else None,
+                         "traffic_kind": "fabric_bytes_per_launch", "traffic_detail": traffic,
                          "kernel": "tdk::k_fast2 main pass + k_resolve + k_fast fix-up pass (HIP events around the three)", "kernel_ms": kms,
                          "kernel_ms_min": min(ktimes) if ktimes else None, "kernel_ms_max": max(ktimes) if ktimes else None,
-                         "fixup_queue": fixups, "kernel_launches": len(ktimes),
+                         "fixup_queue": R["fixups"], "kernel_launches": len(ktimes),
                          "algorithmic_bytes_per_launch": algo_bytes},
-            "check": check,
+            "check": R["check"],
         }
+        if world > 1:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["collective_backend"] = backend + (" (RCCL over xGMI)" if backend == "nccl" else " (REHEARSAL on one GPU: not a measurement)")
+            out["allreduce_ms"] = allreduce_ms
+            out["allreduce_bytes"] = int(mats[0].numel()) * 4
+        if strong_run is not None:
+            S = strong_run
+            out["strong"] = {"value": S["job_reads"] * args.steps / S["elapsed"], "unit": "reads/s",
+                             "ms_per_step": S["elapsed"] / args.steps * 1e3, "library_reads": S["job_reads"],
+                             "reads_per_gpu": S["my_reads"], "kernel_ms": S["kms"], "fixup_queue": S["fixups"], "check": S["check"],
+                             "allreduce_ms": allreduce_ms,
+                             "what": "ONE library byte-sharded over the GPUs, each shard counted with its true first line index, "
+                                     "the same all-reduce per pass (overlapped with the next pass)"}
         if world == 1 and not args.debug_ablate:
             # the same pass with the reference's progress counters kept per window of 50 000 reads (find_tags_fastq's
             # default here, reference :268-271) -- untimed above, reported beside it
@@ -319,16 +449,75 @@ def main():
             out["count_and_trim"] = count_and_trim(eng, cfg, fastq, nbytes, first_line, my_reads, stream)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample, my_reads), min(args.cpu_python_sample, my_reads))
-        if world == 1 and args.tier_reads > 0 and not args.debug_ablate:
+        others = ("2,4,5" if default_workload else "") if args.other_configs == "auto" else args.other_configs
+        if world == 1 and others and not args.debug_ablate:
             del fastq
+            R = main_run = None
+            eng.bind_counts(0)
+            del mats, counts
+            torch.cuda.empty_cache()
+            out["other_configs"] = {}
+            for cid in [int(c) for c in others.split(",") if c]:
+                out["other_configs"]["c%d" % cid] = other_config(eng, args, cid, dev, stream)
+            fastq = None
+        if world == 1 and args.tier_reads > 0 and not args.debug_ablate:
+            fastq = None
+            R = main_run = None
             torch.cuda.empty_cache()
             eng.bind_counts(0)
             out["tiers"] = tiers(eng, cfg, min(args.tier_reads, my_reads))
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def other_config(eng, args, cid, dev, stream, steps=3):
+    """One of the other BASELINE index shapes at its full read count: bit-exact check against the generator's
+    expected matrix, then `steps` timed passes (HIP events around the kernels); config 5 also runs the trim branch."""
+    import torch
+    t_all = time.perf_counter()
+    cfg = make_config(args, cid, args.other_reads)
+    reads = cfg.nreads
+    nbytes = reads * cfg.record_bytes
+    fastq = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    cfg.fill_device(eng, fastq.data_ptr(), 0, reads)
+    counts = torch.zeros(len(cfg.barcodes) * len(cfg.tags), dtype=torch.int32, device=dev)
+    eng.bind_counts(counts.data_ptr())
+    eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+    eng.count_device(fastq.data_ptr(), nbytes, stream=stream)              # (warm; also the pass that is checked)
+    torch.cuda.synchronize()
+    want = torch.zeros_like(counts)
+    hits = cfg.expected_device(eng, want.data_ptr(), 0, reads)
+    st = eng.stats()
+    ok = bool(torch.equal(counts, want)) and st["tag"] == hits and st["reads"] == reads
+    del want
+    eng.set_option("timing", 1)
+    eng.kernel_times_ms()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        counts.zero_()
+        eng.count_device(fastq.data_ptr(), nbytes, stream=stream)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    kt = eng.kernel_times_ms()
+    eng.set_option("timing", 0)
+    kms = sum(kt) / len(kt) if kt else 0.0
+    res = {"reads": reads, "barcodes": len(cfg.barcodes), "tags": len(cfg.tags), "cutsite": cfg.cutsite,
+           "ms": kms, "ms_per_step": wall * 1e3, "reads_per_s": reads / wall,
+           "frac": cfg.record_bytes * reads / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms else None,
+           "bit_exact": ok, "tag": int(st["tag"]), "steps": steps}
+    if cid == 5:
+        eng.reset()
+        res["count_and_trim"] = count_and_trim(eng, cfg, fastq, nbytes, 0, reads, stream)
+    eng.bind_counts(0)
+    del fastq, counts
+    torch.cuda.empty_cache()
+    res["seconds"] = time.perf_counter() - t_all
+    return res
 
 
 def count_and_trim(eng, cfg, fastq, nbytes, first_line, reads, stream):
@@ -405,7 +594,11 @@ def cpu_baseline(cfg, sample_reads, python_reads=0):
                         "trie build %.2f s timed separately; scalar C restatement oracle/oracle.c"
                         % (sample_reads, data.nbytes / 1e9, build_s),
               "index_build_s": build_s, "loop_s": loop_s}
-    out = {"value": None, "unit": "reads/s", "cores": 1, "kind": "port", "cpu": host_cpu_model(), "c_port": c_port}
+    # kind: "restatement" = `value` is the pure-Python restatement of the reference's loop (the closest thing to the
+    # reference that can travel); "port" when only the scalar C port was timed
+    out = {"value": None, "unit": "reads/s", "cores": 1, "kind": "restatement" if python_reads > 0 else "port",
+           "cpu": host_cpu_model(), "c_port": c_port}
+    c_port["kind"] = "port"
     # the same C restatement on every core this process may use (at most 16: the GPU box's share per GPU),
     # one shard of whole records per thread, matrices summed
     try:

@@ -57,12 +57,19 @@ TDI_FN uint64_t load64(const uint8_t *p) {
     return v;
 }
 TDI_FN void store64(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
-// ipos = the input consumed into the bit buffer; `ahead` holds in[ipos .. ipos + 4)
+// ipos = the input consumed into the bit buffer; `ahead` holds in[ipos .. ipos + 4).  No load ever reaches beyond
+// in[in_len + 8): a position past the payload's end (a truncated or hostile stream: a dynamic block's header alone
+// consumes up to ~570 bytes between two of step()'s checks) re-reads the last allowed word, and step() then fails
+// the stream with ERR_INPUT.
+TDI_FN uint32_t load_ahead(const Stream &s) {
+    const uint32_t lim = s.in_len + 4u;
+    return load32(s.in + (s.ipos < lim ? s.ipos : lim));
+}
 TDI_FN void refill(Stream &s) {
     if (s.bc <= 32) {
         s.bb |= (uint64_t)s.ahead << s.bc;
         s.ipos += 4; s.bc += 32;
-        s.ahead = load32(s.in + s.ipos);
+        s.ahead = load_ahead(s);
     }
 }
 TDI_FN uint32_t peek(const Stream &s, uint32_t n) { return (uint32_t)s.bb & ((1u << n) - 1u); }
@@ -138,7 +145,7 @@ TDI_FN void header(Stream &s) {
         if ((len ^ nlen) != 0xFFFFu) { s.state = ST_ERROR; s.err = ERR_STORED; return; }
         // the bytes still in the bit buffer go back to the input
         s.ipos -= s.bc >> 3; s.bb = 0; s.bc = 0;
-        s.ahead = load32(s.in + s.ipos);
+        s.ahead = load_ahead(s);
         s.copy_len = len;
         s.state = len ? ST_STORED : (s.last_block ? ST_DONE : ST_HEADER);
         return;
@@ -261,7 +268,7 @@ TDI_FN void step(Stream &s) {
         if (s.opos + n > s.out_len || s.ipos + n > s.in_len) { s.state = ST_ERROR; s.err = ERR_OVERRUN; return; }
         s.copy_len -= n;
         while (n--) s.out[s.opos++] = s.in[s.ipos++];
-        if (s.copy_len == 0) { s.ahead = load32(s.in + s.ipos); s.state = s.last_block ? ST_DONE : ST_HEADER; }
+        if (s.copy_len == 0) { s.ahead = load_ahead(s); s.state = s.last_block ? ST_DONE : ST_HEADER; }
         break;
     }
     default: break;

@@ -173,6 +173,7 @@ struct td_handle {
     DevBuf<uint4> d_progbits;                 // k_fast2's per-tile record of what its wanted lines matched
     std::vector<uint64_t> host_acc;           // flushed counts
     uint64_t bytes_since_flush = 0;
+    uint64_t flush_limit = 0xFFFFFFFFull;     // hits a uint32 cell may have taken before the matrix is flushed (tests lower it)
     // launch state
     DevBuf<uint64_t> d_state, d_tilecounts;
     DevBuf<uint32_t> d_ticket;
@@ -199,6 +200,7 @@ struct td_handle {
                    uint32_t *d_status = nullptr, *pin_status = nullptr; uint8_t *pin_tail = nullptr; hipEvent_t copied = nullptr; } zslot[2];
     struct ZPiece { uint8_t *pin = nullptr; hipEvent_t sent = nullptr; bool busy = false; } zpiece[2];     // pinned staging of the compressed bytes
     uint8_t *d_zscratch = nullptr; uint32_t *d_crctab = nullptr;
+    uint32_t zcap_members = 0; size_t zcap_in = 0;   // what the batch buffers above were allocated for
     int gpu_inflate = 1;                      // BGZF input: inflate on the GPU (0: member-parallel on the host)
     int gpu_inflate_crc = 1;                  // ... and check every member's CRC-32 there
     uint32_t max_need = 0;                    // bases from a read's start that the matcher may look at
@@ -220,6 +222,29 @@ struct td_handle {
 };
 
 namespace {
+
+// count_bgzf_gpu's batch buffers (sized from the file, kept on the handle between files)
+void release_bgzf_buffers(td_handle *h) {
+    for (auto &zp : h->zpiece) {
+        if (zp.pin) (void)hipHostFree(zp.pin);
+        if (zp.sent) (void)hipEventDestroy(zp.sent);
+        zp = td_handle::ZPiece();
+    }
+    for (auto &z : h->zslot) {
+        if (z.d_in) (void)hipFree(z.d_in);
+        if (z.d_out) (void)hipFree(z.d_out);
+        if (z.pin_mem) (void)hipHostFree(z.pin_mem);
+        if (z.d_mem) (void)hipFree(z.d_mem);
+        if (z.d_status) (void)hipFree(z.d_status);
+        if (z.pin_status) (void)hipHostFree(z.pin_status);
+        if (z.pin_tail) (void)hipHostFree(z.pin_tail);
+        if (z.copied) (void)hipEventDestroy(z.copied);
+        z = td_handle::ZSlot();
+    }
+    if (h->d_zscratch) (void)hipFree(h->d_zscratch);
+    h->d_zscratch = nullptr;
+    h->zcap_members = 0; h->zcap_in = 0;
+}
 
 using KFn = void (*)(const tdk::KParams);
 template <int CPT, bool TASSEL> KFn pick_w(int W) {
@@ -352,12 +377,13 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     const bool limit_far = limit_line >= ~0ull - 16 || limit_line - std::min(limit_line, fl_ub) >= nbytes / 16;
     const bool counts32 = (uint64_t)h->barnum * h->ntags * 4 < h->fast_max_matrix;
     // progress windows are recorded by k_fast2 (+ k_resolve, fix-up pass) and by the exact kernel; not by k_fast's main pass
-    const bool use_fast = h->fastpath && !tassel && !h->prescan && limit_far && counts32 &&
-                          !(h->progress && (h->kernel_gen != 2 || h->W > 3));
     // its main pass: k_fast2 (raw tile in LDS, lines packed by the lane that matches them) where the tag width has
-    // the pipelined probe and the tile fits the LDS budget, else k_fast
+    // the pipelined probe and the tile fits the LDS budget, else k_fast -- which keeps no progress records: with
+    // progress on and no k_fast2 (wide tags, or a barcode index too large for its LDS layout) the exact kernel counts
     const int tkb2 = h->tile_kb2 ? h->tile_kb2 : fast2_auto_tile(h);
-    const bool gen2 = use_fast && h->kernel_gen == 2 && h->W <= 3 && lds_bytes_fast2(h, tkb2) <= LDS_BUDGET;
+    const bool gen2_fits = h->kernel_gen == 2 && h->W <= 3 && lds_bytes_fast2(h, tkb2) <= LDS_BUDGET;
+    const bool use_fast = h->fastpath && !tassel && !h->prescan && limit_far && counts32 && !(h->progress && !gen2_fits);
+    const bool gen2 = use_fast && gen2_fits;
     const int tile_kb = tassel ? 16 : gen2 ? tkb2 : h->tile_kb;
     const uint64_t tile = (uint64_t)tile_kb * 1024;
     const uint64_t ntiles64 = (nbytes + tile - 1) / tile;
@@ -365,7 +391,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     const uint32_t ntiles = (uint32_t)ntiles64;
 
     if (!h->bound_counts && !tassel) {       // uint32 cells: a hit needs > 4 bytes of input
-        if ((h->bytes_since_flush + nbytes) / 4 >= 0xFFFFFFFFull) { int rc = flush_counts(h); if (rc) return rc; }
+        if ((h->bytes_since_flush + nbytes) / 4 >= h->flush_limit) { int rc = flush_counts(h); if (rc) return rc; }
         h->bytes_since_flush += nbytes;
     }
     if (tassel) {
@@ -622,21 +648,7 @@ void td_destroy(td_handle *h) {
         if (sl.res_pin) (void)hipHostFree(sl.res_pin);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
-    for (auto &zp : h->zpiece) {
-        if (zp.pin) (void)hipHostFree(zp.pin);
-        if (zp.sent) (void)hipEventDestroy(zp.sent);
-    }
-    for (auto &z : h->zslot) {
-        if (z.d_in) (void)hipFree(z.d_in);
-        if (z.d_out) (void)hipFree(z.d_out);
-        if (z.pin_mem) (void)hipHostFree(z.pin_mem);
-        if (z.d_mem) (void)hipFree(z.d_mem);
-        if (z.d_status) (void)hipFree(z.d_status);
-        if (z.pin_status) (void)hipHostFree(z.pin_status);
-        if (z.pin_tail) (void)hipHostFree(z.pin_tail);
-        if (z.copied) (void)hipEventDestroy(z.copied);
-    }
-    if (h->d_zscratch) (void)hipFree(h->d_zscratch);
+    release_bgzf_buffers(h);
     if (h->d_crctab) (void)hipFree(h->d_crctab);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->work_stream) (void)hipStreamDestroy(h->work_stream);
@@ -964,24 +976,56 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
     if (!src.map_only(path)) { *not_bgzf = true; return TD_OK; }           // (empty or unreadable: the host path reports it)
     uint32_t bs0 = 0, hs0 = 0;
     if (!tdhost::GzSource::bgzf_header(src.map, src.bsize, &bs0, &hs0)) { *not_bgzf = true; return TD_OK; }
-    const size_t out_cap = (size_t)ZB_MEMBERS * 65536 + ZB_CARRY + 4096;
-    for (auto &zp : h->zpiece) {
-        if (zp.pin) continue;
-        HIPCHK(hipHostMalloc((void **)&zp.pin, ZB_PIECE + 64, hipHostMallocDefault));
-        HIPCHK(hipEventCreateWithFlags(&zp.sent, hipEventDisableTiming));
+    // Batch buffers sized from the file: a small file is walked first (headers only), which also tells whether EVERY
+    // member is BGZF -- gzip.open (reference :240-241) reads a file whose later members are plain gzip, so such a file
+    // goes to the host inflater; a file beyond 1 GiB compressed takes the full batch (49 152 members, ~9.5 GB of HBM).
+    uint32_t need_members = ZB_MEMBERS;
+    size_t need_in = ZB_IN;
+    if (src.bsize <= ((size_t)1 << 30)) {
+        size_t at = 0;
+        uint32_t n = 0;
+        while (at < src.bsize) {
+            uint32_t bs = 0, hs = 0;
+            if (!tdhost::GzSource::bgzf_header(src.map + at, src.bsize - at, &bs, &hs) || bs < hs + 8 || at + bs > src.bsize) {
+                *not_bgzf = true;                                  // (a damaged file too: the host path reports it)
+                return TD_OK;
+            }
+            at += bs; n++;
+        }
+        need_members = std::min<uint32_t>(ZB_MEMBERS, std::max<uint32_t>(64, (n + 63) / 64 * 64));
+        need_in = std::min<size_t>(ZB_IN, (src.bsize + 4095) / 4096 * 4096);
     }
-    for (auto &z : h->zslot) {
-        if (z.d_in) continue;
-        HIPCHK(hipMalloc((void **)&z.d_in, ZB_IN + 64));
-        HIPCHK(hipMalloc((void **)&z.d_out, out_cap));
-        HIPCHK(hipHostMalloc((void **)&z.pin_mem, (size_t)ZB_MEMBERS * sizeof(tdinf::Member), hipHostMallocDefault));
-        HIPCHK(hipMalloc((void **)&z.d_mem, (size_t)ZB_MEMBERS * sizeof(tdinf::Member)));
-        HIPCHK(hipMalloc((void **)&z.d_status, (size_t)ZB_MEMBERS * 4));
-        HIPCHK(hipHostMalloc((void **)&z.pin_status, (size_t)ZB_MEMBERS * 4, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&z.pin_tail, ZB_TAIL, hipHostMallocDefault));
-        HIPCHK(hipEventCreateWithFlags(&z.copied, hipEventDisableTiming));
+    if (need_members > h->zcap_members || need_in > h->zcap_in) {
+        // (kept on the handle between files; grown when a larger file comes)
+        release_bgzf_buffers(h);
+        const size_t out_cap = (size_t)need_members * 65536 + ZB_CARRY + 4096;
+        bool ok = true;
+        auto dev = [&](void **p, size_t n) { if (ok && hipMalloc(p, n) != hipSuccess) { ok = false; (void)hipGetLastError(); } };
+        auto pin = [&](void **p, size_t n) { if (ok && hipHostMalloc(p, n, hipHostMallocDefault) != hipSuccess) { ok = false; (void)hipGetLastError(); } };
+        for (auto &zp : h->zpiece) {
+            pin((void **)&zp.pin, std::min(ZB_PIECE, need_in + 64) + 64);
+            if (ok && hipEventCreateWithFlags(&zp.sent, hipEventDisableTiming) != hipSuccess) ok = false;
+        }
+        for (auto &z : h->zslot) {
+            dev((void **)&z.d_in, need_in + 1024);
+            dev((void **)&z.d_out, out_cap);
+            pin((void **)&z.pin_mem, (size_t)need_members * sizeof(tdinf::Member));
+            dev((void **)&z.d_mem, (size_t)need_members * sizeof(tdinf::Member));
+            dev((void **)&z.d_status, (size_t)need_members * 4);
+            pin((void **)&z.pin_status, (size_t)need_members * 4);
+            pin((void **)&z.pin_tail, ZB_TAIL);
+            if (ok && hipEventCreateWithFlags(&z.copied, hipEventDisableTiming) != hipSuccess) ok = false;
+        }
+        dev((void **)&h->d_zscratch, (size_t)need_members * tdinf::SCRATCH_BYTES);
+        if (!ok) {                                                 // no room on the device: the host inflater takes the file
+            release_bgzf_buffers(h);
+            *not_bgzf = true;
+            return TD_OK;
+        }
+        h->zcap_members = need_members; h->zcap_in = need_in;
     }
-    if (!h->d_zscratch) HIPCHK(hipMalloc((void **)&h->d_zscratch, (size_t)ZB_MEMBERS * tdinf::SCRATCH_BYTES));
+    const uint32_t batch_members = std::min<uint32_t>(h->zcap_members, h->zb_members);
+    const size_t batch_in = h->zcap_in, piece_cap = std::min(ZB_PIECE, h->zcap_in + 64);
     if (!h->d_crctab) {
         uint32_t T[1024];                                        // slicing-by-4: T[256 k + b] = CRC of byte b followed by k zero bytes
         for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; T[i] = c; }
@@ -999,11 +1043,11 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
         td_handle::ZSlot &z = h->zslot[slot];
         b = Batch();
         const size_t first = pos;
-        while (pos < src.bsize && b.n < std::min<uint32_t>(ZB_MEMBERS, h->zb_members)) {
+        while (pos < src.bsize && b.n < batch_members) {
             uint32_t bs = 0, hs = 0;
             if (!tdhost::GzSource::bgzf_header(src.map + pos, src.bsize - pos, &bs, &hs) || bs < hs + 8 || pos + bs > src.bsize)
-                return fail(TD_E_IO, "damaged BGZF member header");
-            if (pos + bs - first > ZB_IN) break;
+                return fail(TD_E_IO, "damaged BGZF member header (or a member that is not BGZF) in a file that began as BGZF");
+            if (pos + bs - first > batch_in) break;
             const uint8_t *tail = src.map + pos + bs - 8;
             const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
             const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
@@ -1016,10 +1060,10 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
         const size_t nin = pos - first;
         // the compressed bytes, through the two pinned pieces in turn (+ 64 zero bytes: the decoder reads a little ahead)
         int k = 0;
-        for (size_t off = 0; off < nin + 64; off += ZB_PIECE, k ^= 1) {
+        for (size_t off = 0; off < nin + 64; off += piece_cap, k ^= 1) {
             td_handle::ZPiece &zp = h->zpiece[k];
             if (zp.busy) { HIPCHK(hipEventSynchronize(zp.sent)); zp.busy = false; }
-            const size_t want = std::min(ZB_PIECE, nin + 64 - off), have = off < nin ? std::min(want, nin - off) : 0;
+            const size_t want = std::min(piece_cap, nin + 64 - off), have = off < nin ? std::min(want, nin - off) : 0;
             if (have) stage_parallel(have, [&](size_t o2, size_t len) { memcpy(zp.pin + o2, src.map + first + off + o2, len); return true; });
             if (want > have) memset(zp.pin + have, 0, want - have);
             HIPCHK(hipMemcpyAsync(z.d_in + off, zp.pin, want, hipMemcpyHostToDevice, h->copy_stream));
@@ -1273,6 +1317,8 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     else if (n == "nt_loads") h->nt_loads = value ? 1 : 0;
     else if (n == "fast_max_matrix_bytes")      // (tests: force the switch to the exact kernel; 0 = the built-in 4 GiB)
         h->fast_max_matrix = value > 0 ? std::min<uint64_t>((uint64_t)value, 1ull << 32) : 1ull << 32;
+    else if (n == "flush_limit")                // (tests: flush the uint32 matrix to the host accumulator early; 0 = the built-in 2^32 - 1)
+        h->flush_limit = value > 0 ? std::min<uint64_t>((uint64_t)value, 0xFFFFFFFFull) : 0xFFFFFFFFull;
     else if (n == "debug_ablate") h->debug_ablate = (uint32_t)value;   // timing-only ablations, wrong results
     else return fail(TD_E_ARG, "unknown option " + n);
     return TD_OK;
@@ -1398,7 +1444,8 @@ int td_fold_rows(td_handle *h, const uint32_t *row_of_barcode, uint32_t n_dst_ro
     if (!h->have_index) return fail(TD_E_STATE, "td_set_index has not been called");
     HIPCHK(hipSetDevice(h->device));
     if (h->used64) return fail(TD_E_STATE, "td_fold_rows folds the uint32 matrix; tassel_tagcount weights are 64-bit");
-    for (uint64_t v : h->host_acc) if (v) return fail(TD_E_STATE, "counts were flushed to the host accumulator; fold them on the host");
+    bool flushed = false;                      // (a library of more than ~17 GB: part of its counts sits in the host accumulator)
+    for (uint64_t v : h->host_acc) if (v) { flushed = true; break; }
     for (uint32_t b = 0; b < h->barnum; b++)
         if (row_of_barcode[b] >= n_dst_rows) return fail(TD_E_ARG, "row_of_barcode entry beyond n_dst_rows");
     hipStream_t s = (hipStream_t)stream;
@@ -1412,6 +1459,22 @@ int td_fold_rows(td_handle *h, const uint32_t *row_of_barcode, uint32_t n_dst_ro
     hipLaunchKernelGGL(k_fold_rows, dim3(gx, h->barnum), dim3(256), 0, s, src, h->barnum, h->ntags, h->d_rowmap.p, (uint32_t *)d_dst);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
+    if (flushed) {
+        // the flushed part goes the same way: its low 32 bits (the destination's cells are uint32) through the same kernel
+        const size_t cells = (size_t)h->barnum * h->ntags;
+        std::vector<uint32_t> low(cells);
+        for (size_t i = 0; i < cells; i++) low[i] = (uint32_t)h->host_acc[i];
+        DevBuf<uint32_t> d_low;
+        rc = d_low.ensure(cells); if (rc) return rc;
+        hipError_t e = hipMemcpy(d_low.p, low.data(), cells * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_fold_rows, dim3(gx, h->barnum), dim3(256), 0, s, d_low.p, h->barnum, h->ntags, h->d_rowmap.p, (uint32_t *)d_dst);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+        }
+        d_low.release();
+        if (e != hipSuccess) return fail(TD_E_HIP, std::string("td_fold_rows (flushed part): ") + hipGetErrorString(e));
+    }
     unsigned long long st[TD_STAT_NSTATS];
     HIPCHK(hipMemcpy(st, h->d_stats.p, sizeof(st), hipMemcpyDeviceToHost));
     return check_device_errors(h, st);

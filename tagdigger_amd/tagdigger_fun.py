@@ -790,11 +790,12 @@ def combineReadCounts(countsdict, bckeys):
 
 
 def _csv_cell(text):
-    """One field exactly as csv.writer (default dialect, minimal quoting) writes it."""
+    """One field exactly as csv.writer (default dialect, minimal quoting) writes it as the FIRST of several fields
+    (a row of one empty field is written as '""', an empty first field of a longer row as nothing)."""
     import io
     buf = io.StringIO()
-    _csv.writer(buf).writerow([text])
-    return buf.getvalue()[:-2]                      # (without the row's \r\n)
+    _csv.writer(buf).writerow([text, "x"])
+    return buf.getvalue()[:-4]                      # (without ',x' and the row's \r\n)
 
 
 def writeCounts(filename, counts, samnames, tagnames):

@@ -126,12 +126,12 @@ def test_fuzz_vs_oracle(eng, cutsite, nl, seed):
 
 
 def test_fuzz_campaign(eng):
-    """Randomised cases against the C oracle for TD_FUZZ_SECONDS seconds (default 3; a soak run on the
+    """Randomised cases against the C oracle for TD_FUZZ_SECONDS seconds (default 20; a soak run on the
     GPU box uses minutes): random index shapes (barcode and tag counts and lengths, cut sites with IUPAC
     codes, tags longer than 32 and 64 bases), every terminator style, long lines and phase shifts, both
     tile sizes, both kernels."""
     import time
-    budget = float(os.environ.get("TD_FUZZ_SECONDS", "3"))
+    budget = float(os.environ.get("TD_FUZZ_SECONDS", "20"))
     seed0 = int(os.environ.get("TD_FUZZ_SEED", "12345"))
     t_end = time.time() + budget
     next_note = time.time() + 30

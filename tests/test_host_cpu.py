@@ -89,3 +89,18 @@ def test_synth_multicut_config():
     want, _ = synth_expected(cfg, 0, cfg.nreads)
     got = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(data)
     assert (got == want).all()
+
+
+def test_write_counts_numpy_path_is_byte_identical(tmp_path):
+    """writeCounts (reference tagdigger_fun.py:1100-1111) given a numpy matrix writes what csv.writer writes for the
+    list form -- names that need quoting, and an EMPTY sample name (a lone empty field is quoted by csv.writer, the
+    first field of a longer row is not)."""
+    from tagdigger_amd import tagdigger_fun as tf
+    names = ["", "s,1", 's"2', " plain", "x\ny"]
+    tags = ["M_A_0", "M,1", ""]
+    counts = [[0, 1, 2], [3, 4, 5], [2 ** 40, 7, 8], [9, 10, 11], [12, 13, 14]]
+    a, b = str(tmp_path / "list.csv"), str(tmp_path / "array.csv")
+    tf.writeCounts(a, counts, names, tags)
+    tf.writeCounts(b, np.array(counts, dtype=np.int64), names, tags)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert open(a, "rb").read().split(b"\r\n")[1] == b",0,1,2"

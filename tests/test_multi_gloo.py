@@ -197,3 +197,34 @@ def test_device_path_byte_sharded_file(tmp_path, maxreads):
     out = str(tmp_path / "res.pt")
     mp.spawn(_device_shard_worker, args=(2, _free_port(), path, barcodes, tags, maxreads, out), nprocs=2, join=True)
     assert torch.load(out) == want
+
+
+@pytest.mark.gpu
+def test_fold_rows_after_a_flush_to_the_host_accumulator():
+    """A library of more than ~17 GB moves part of its uint32 counts into the host accumulator (launch_count's flush);
+    K3 must fold that part too (round 2's td_fold_rows refused it).  The threshold is lowered through the test option
+    flush_limit so that the second of three launches flushes the first one's counts."""
+    import numpy as np
+    import tagdigger_amd
+    from helpers import dirty_fastq, small_index
+    from oracle import c_oracle
+    rnd = random.Random(7)
+    barcodes, tags, cutsites = small_index(rnd, "TGCAG", nbar=6, ntag=20)
+    data = dirty_fastq(rnd, barcodes, tags, cutsites, nrec=400)
+    want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data)
+    rows = [0, 2, 1, 0, 2, 1]
+    folded = np.zeros((3, len(tags)), dtype=np.int64)
+    np.add.at(folded, rows, want.astype(np.int64))
+    eng = tagdigger_amd.Engine(0)
+    try:
+        eng.set_index(barcodes, tags, "TGCAG")
+        eng.set_option("flush_limit", 1000)
+        for _ in range(3):
+            eng.count_bytes(data)
+        assert (eng.counts_numpy() == 3 * want).all()              # (td_get_counts merges the accumulator)
+        total = torch.zeros((3, len(tags)), dtype=torch.int32, device="cuda:0")
+        eng.fold_rows(rows, total.data_ptr(), 3)
+        assert (total.cpu().numpy().astype(np.int64) == 3 * folded).all()
+        eng.set_option("flush_limit", 0)
+    finally:
+        eng.close()

@@ -300,3 +300,32 @@ def test_byte_sharded_file_prints_the_progress_lines(tmp_path, capfd, maxreads):
     mp.spawn(_sharded_worker, args=(2, port, path, cfg.barcodes, cfg.tags, cfg.cutsite, maxreads), nprocs=2, join=True)
     got = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("Reads: ")]
     assert got == want and len(want) == n // 50000
+
+
+@pytest.mark.gpu
+def test_windows_with_a_barcode_index_too_large_for_k_fast2():
+    """900 barcodes x 4 concrete cut sites (RCATGY): the barcode blob (~45 KB) fits the exact kernel's LDS layout but
+    not k_fast2's, even with 16 KiB tiles.  Round 2 then ran k_fast -- which keeps no progress records -- with the
+    windows on, and k_resolve added uninitialised words to them; now the exact kernel counts when progress is on.
+    Windows == the C oracle's counters at every 50 000th read; counts == the oracle's."""
+    import tagdigger_amd
+    from tagdigger_amd.synth import SynthConfig
+    cfg = SynthConfig(nreads=160_000, nbar=900, nmarkers=400, seed=77, cutsite="RCATGY", bclen=(7, 10))
+    host = helpers.synth_host_bytes(cfg, 0, cfg.nreads)
+    o = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite)
+    want = boundary_stats(o, host, cfg.nreads)
+    full = o.count_bytes(host)
+    eng = tagdigger_amd.Engine(0)
+    try:
+        eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        for progress in (1, 0):
+            eng.set_option("progress", progress)
+            eng.reset()
+            eng.count_bytes(host)
+            assert (eng.counts_numpy() == full).all()
+            if progress:
+                w = eng.progress_windows()
+                got = list(zip(np.cumsum([a for a, _ in w]).tolist(), np.cumsum([b for _, b in w]).tolist()))
+                assert got[:len(want)] == want
+    finally:
+        eng.close()

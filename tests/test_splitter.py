@@ -201,11 +201,11 @@ def test_gpu_split_device_decisions(seed, adapter):
 @pytest.mark.gpu
 def test_gpu_split_fuzz_campaign():
     """Random barcode sets, adapter sets, read mixes, line ends and first-line offsets for
-    TD_FUZZ_SECONDS seconds (default 3): every decision of k_split equals the oracle's."""
+    TD_FUZZ_SECONDS seconds (default 20): every decision of k_split equals the oracle's."""
     import time
     import tagdigger_amd
     from tagdigger_amd import tagdigger_fun as tf
-    budget = float(os.environ.get("TD_FUZZ_SECONDS", "3"))
+    budget = float(os.environ.get("TD_FUZZ_SECONDS", "20"))
     seed0 = int(os.environ.get("TD_FUZZ_SEED", "4242"))
     t_end = time.time() + budget
     next_note = time.time() + 30
