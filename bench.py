@@ -415,6 +415,11 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes},
             "check": R["check"],
         }
+        def note(key):                                     # (stderr: what has been measured so far, should a later stage fail)
+            print("bench.py: %s = %s" % (key, json.dumps(out.get(key))[:400]), file=sys.stderr)
+            sys.stderr.flush()
+        note("value")
+        note("roofline")
         if world > 1:
             out["rccl_ranks"] = dist.get_world_size()
             out["collective_backend"] = backend + (" (RCCL over xGMI)" if backend == "nccl" else " (REHEARSAL on one GPU: not a measurement)")
@@ -449,6 +454,7 @@ def main():
             out["count_and_trim"] = count_and_trim(eng, cfg, fastq, nbytes, first_line, my_reads, stream)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample, my_reads), min(args.cpu_python_sample, my_reads))
+            note("cpu_baseline")
         others = ("2,4,5" if default_workload else "") if args.other_configs == "auto" else args.other_configs
         if world == 1 and others and not args.debug_ablate:
             del fastq
@@ -459,6 +465,7 @@ def main():
             out["other_configs"] = {}
             for cid in [int(c) for c in others.split(",") if c]:
                 out["other_configs"]["c%d" % cid] = other_config(eng, args, cid, dev, stream)
+                note("other_configs")
             fastq = None
         if world == 1 and args.tier_reads > 0 and not args.debug_ablate:
             fastq = None
@@ -658,6 +665,7 @@ def tiers(eng, cfg, reads):
     from compress_formats import bgzf_bytes, gzip_one_member      # (writers of the test files: no product code, no oracle)
     rb = cfg.record_bytes
     nb = reads * rb
+    eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)               # (the other configs' passes left theirs)
     d = eng.dev_alloc(nb)
     cfg.fill_device(eng, d, 0, reads)
     host = np.frombuffer(eng.d2h(d, nb), dtype=np.uint8)

@@ -333,7 +333,9 @@ size_t lds_bytes(const td_handle *h, int tile_kb) {
 }
 
 int zero_results(td_handle *h) {
-    if (h->d_counts.p) HIPCHK(hipMemsetAsync(h->d_counts.p, 0, (size_t)h->barnum * h->ntags * 4, h->work_stream));
+    // (the handle's own matrix may be left over from a smaller index while a caller's matrix is bound: only what is
+    // allocated is cleared; td_bind_counts(NULL) grows and clears it before it is used again)
+    if (h->d_counts.p) HIPCHK(hipMemsetAsync(h->d_counts.p, 0, std::min<size_t>((size_t)h->barnum * h->ntags, h->d_counts.n) * 4, h->work_stream));
     if (h->d_counts64.p) HIPCHK(hipMemsetAsync(h->d_counts64.p, 0, (size_t)h->barnum * h->ntags * 8, h->work_stream));
     HIPCHK(hipMemsetAsync(h->d_stats.p, 0, STATS_SLOTS * 8, h->work_stream));
     if (h->d_win.p) HIPCHK(hipMemsetAsync(h->d_win.p, 0, h->d_win.n * 8, h->work_stream));
