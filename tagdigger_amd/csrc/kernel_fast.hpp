@@ -37,6 +37,7 @@ constexpr uint32_t FX_NEG = 4;                  // subtract instead of add
 constexpr uint32_t FX_LIMIT = 8;                // apply the maxreads limit (needs P)
 constexpr uint32_t FX_HICHECK = 16;             // only look for bytes >= 0x80 inside counted sequence lines
 constexpr uint32_t FX_PREDICT = 32;             // (main pass) predict the phase
+constexpr uint32_t FX_WINONLY = 64;             // only add the tile's wanted lines to the progress windows (nothing is counted)
 
 struct FParams {
     KParams k;
@@ -44,11 +45,13 @@ struct FParams {
     uint4 *fixlist;          // [fix_cap]
     uint32_t *nfix;
     uint32_t fix_cap;
-    // progress windows (KParams::win): per tile, PROG_SLOTS x {which of the 64 wanted lines of a phase-D pass had a
-    // barcode, which a tag} as the main pass (k_fast2) saw them; k_resolve adds up the tiles whose phase was right
-    uint4 *prog_bits;
+    // progress windows (KParams::win): per tile, how many of its wanted lines had a barcode (low half) and a tag
+    // (high half) as the main pass (k_fast2) saw them -- zeroed by the host before the launch, added to by every
+    // phase-D pass.  k_resolve adds the sums of the tiles whose phase was right to the window their reads fall
+    // into; the one tile in ~450 that straddles a window boundary goes to the fix-up pass (FX_WINONLY), which
+    // knows every line's number.
+    uint32_t *tile_sums;
 };
-constexpr uint32_t PROG_SLOTS = 8;              // wanted lines per tile the main pass records: 64 x this
 
 // Wave priority per phase (KParams::prio: bits 1:0 phase A and the tile's end, 3:2 phases B-C,
 // 5:4 phase D, 7:6 the end of phase A: pending line, next tile's loads).  The short, serial,
@@ -345,7 +348,8 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
 
         const uint64_t P = FIX ? Pg : 0;                            // valid in fix-up mode only
         const bool use_limit = (codeq & FX_LIMIT) != 0;
-        const int sign = (codeq & FX_NEG) ? -1 : 1;
+        const int sign = (codeq & FX_NEG) ? -1 : (FIX && (codeq & FX_WINONLY)) ? 0 : 1;
+        const bool to_windows = FIX && p.win && sign >= 0;     // (FX_NEG undoes a count whose record never reached the windows)
 
         if (__builtin_expect((codeq & FX_HICHECK) != 0, 0)) {
             // ------------ bytes >= 0x80 inside a counted sequence line?  (fix-up mode, true phase)
@@ -412,12 +416,12 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
             if (p.dbg & DBG_NO_PHASE2) nw = 0;
             auto commit = [&](uint64_t res, uint64_t line) {
                 const uint32_t kind = (uint32_t)(res >> 62);
-                if (FIX && p.win && sign > 0) win_add(p, line >> 2, kind);       // (sequence line L is read L >> 2)
+                if (to_windows) win_add(p, line >> 2, kind);       // (sequence line L is read L >> 2)
                 st_reads += sign;
                 if (kind >= 1) st_bar += sign;
                 if (kind == 2) {
                     st_tag += sign;
-                    if (!(p.dbg & DBG_NO_ATOMIC))
+                    if (sign != 0 && !(p.dbg & DBG_NO_ATOMIC))
                         __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), (uint32_t)sign, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const F
                         commit(match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true), line);
                         vm_settled();
                     } else {
-                        if (FIX && p.win && sign > 0 && k == 2u) win_add(p, line >> 2, 1u);
+                        if (to_windows && k == 2u) win_add(p, line >> 2, 1u);
                         st_reads += sign;
                         if (k == 2u) st_bar += sign;
                     }
@@ -603,31 +607,24 @@ __global__ __launch_bounds__(1024) void k_resolve(const FParams fp, const unsign
         atomicAdd(p.stats + ST_LINES, P + v);
         if (p.cursor_out) *p.cursor_out = carried + P + v;
     }
-    // Progress windows: the tiles the main pass counted under the right phase (nothing queued for them above) hand
-    // in what it recorded per wanted line; wanted line j of tile i is read (first_line + P + truth + 1) / 4 + j.
+    // Progress windows: a tile the main pass counted under the right phase (nothing queued for it above) hands in its
+    // sums when all its wanted lines -- reads (first_line + P + truth + 1) / 4 .. + nwant - 1 -- fall into one window;
+    // a tile that straddles a window boundary is queued for the fix-up pass, which adds line by line (FX_WINONLY).
     // The 64 tiles of a wave are neighbours: their reads fall into one or two windows -- two atomics per wave.
-    if (p.win && fp.prog_bits) {                                    // (uniform)
+    if (p.win && fp.tile_sums) {                                    // (uniform)
         const uint32_t truth = (4u - (uint32_t)((first_line + P) & 3)) & 3u;
         const bool mine = i < p.ntiles && !(info & TI_SKIP) && ((info >> TI_R0_SHIFT) & 3u) == truth &&
                           !(finite && first_line + P + v > p.limit_line);
         const uint64_t rid0 = (first_line + P + truth + 1) >> 2;
         const uint32_t nwant = mine ? ((uint32_t)v + 3u - truth) >> 2 : 0u;
-        const uint64_t wb = wave_min64(nwant ? rid0 / PROG_WINDOW : ~0ull);
-        unsigned long long a = 0, b = 0;
-        auto add = [&](uint64_t w, uint64_t bar, uint64_t tag) {
-            const unsigned long long pk = (unsigned long long)__builtin_popcountll(bar) | ((unsigned long long)__builtin_popcountll(tag) << 32);
-            if (w == wb) a += pk;
-            else if (w == wb + 1) b += pk;
-            else if (pk && w < p.win_cap) atomicAdd(p.win + w, pk);
-        };
-        for (uint32_t sl = 0; sl * 64u < nwant; sl++) {
-            const uint4 q = fp.prog_bits[(size_t)i * PROG_SLOTS + sl];
-            const uint64_t bar = ((uint64_t)q.y << 32) | q.x, tag = ((uint64_t)q.w << 32) | q.z;
-            const uint64_t r = rid0 + 64u * sl, wl = r / PROG_WINDOW, nlow = (wl + 1) * PROG_WINDOW - r;
-            const uint64_t low = nlow >= 64 ? ~0ull : (1ull << nlow) - 1ull;
-            add(wl, bar & low, tag & low);
-            if (nlow < 64) add(wl + 1, bar & ~low, tag & ~low);
-        }
+        const uint64_t w0 = rid0 / PROG_WINDOW;
+        const bool single = nwant != 0 && (rid0 + nwant - 1) / PROG_WINDOW == w0;
+        if (nwant != 0 && !single) push(i, truth | FX_WINONLY, P);
+        const uint32_t sums = single ? fp.tile_sums[i] : 0u;
+        const unsigned long long pk = (unsigned long long)(sums & 0xFFFFu) | ((unsigned long long)(sums >> 16) << 32);
+        const uint64_t wb = wave_min64(single ? w0 : ~0ull);
+        unsigned long long a = single && w0 == wb ? pk : 0ull, b = single && w0 == wb + 1 ? pk : 0ull;
+        if (single && w0 > wb + 1 && pk && w0 < p.win_cap) atomicAdd(p.win + w0, pk);       // (lines of a few bytes)
         a = wave_sum64(a); b = wave_sum64(b);
         if (lane == 0 && wb != ~0ull) {
             if (a && wb < p.win_cap) atomicAdd(p.win + wb, a);

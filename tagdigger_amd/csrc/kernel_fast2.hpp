@@ -94,21 +94,26 @@ __device__ __forceinline__ uint32_t eq_mask16_ascii(const uint4 &v, uint32_t c4,
     return ((lo >> 7) | (hi << 1)) ^ 0xFFFFu;
 }
 
-// codes (16 bases, first base in the top bits) and invalid flags (bit k = byte k is not a base) of 16 ASCII bytes
+// codes (16 bases, first base in the top bits) and invalid flags (bit k = byte k is not a base) of 16 ASCII bytes.
+// Per dword seven instructions: t = x & 0x06060606 is TWICE the base code of every byte (A 0, C 2, T 4, G 6) -- it
+// selects the expected letter from an 8-byte table without a shift (v_perm), and its dot product with 64, 16, 4, 1
+// is twice the four codes' 8 bits (the shift is folded into the words' placement); flags as before.  The two flag
+// dot products of a half are chained through the addend (the five pieces of a line give the scheduler independent
+// chains to interleave).
 __device__ __forceinline__ uint2 pack16_ascii(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
     const uint32_t x[4] = {x0, x1, x2, x3};
-    uint32_t c[4], f[4];
-    // (four independent chains: a dot product that feeds the next one costs wait states)
+    uint32_t c[4], nz[4];
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        const uint32_t code = (x[d] >> 1) & 0x03030303u;
-        const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, code);
-        const uint32_t nz = (((x[d] & 0xDFDFDFDFu) ^ expect) + 0x7F7F7F7Fu) & 0x80808080u;   // 0x80 where the byte is not a base
-        c[d] = udot4(code, 0x01041040u, 0u);                                 // four codes = 8 bits
-        f[d] = udot4(nz, (d & 1) ? 0x80402010u : 0x08040201u, 0u);           // 128 x (four flags in bits 0-3 or 4-7)
+        const uint32_t t = x[d] & 0x06060606u;
+        const uint32_t expect = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);          // selector 0 A, 2 C, 4 T, 6 G
+        nz[d] = (((x[d] & 0xDFDFDFDFu) ^ expect) + 0x7F7F7F7Fu) & 0x80808080u;               // 0x80 where the byte is not a base
+        c[d] = udot4(t, 0x01041040u, 0u);                                                    // 2 x (four codes = 8 bits)
     }
-    const uint32_t cw = (((c[0] << 8) | c[1]) << 16) | (c[2] << 8) | c[3];
-    return make_uint2(cw, (((f[2] | f[3]) << 1) | ((f[0] | f[1]) >> 7)));
+    const uint32_t flo = udot4(nz[1], 0x80402010u, udot4(nz[0], 0x08040201u, 0u));           // 128 x (flags of bytes 0-7)
+    const uint32_t fhi = udot4(nz[3], 0x80402010u, udot4(nz[2], 0x08040201u, 0u));           // 128 x (flags of bytes 8-15)
+    const uint32_t cw = (((c[0] << 23) | (c[1] << 15)) | (c[2] << 7)) | (c[3] >> 1);
+    return make_uint2(cw, (fhi << 1) | (flo >> 7));
 }
 
 // 16 bytes of LDS at any byte offset
@@ -271,13 +276,16 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
     constexpr bool PIPE = W <= 3;
     Pending<W> pd;
     bool pd_valid = false;
-    // progress windows: what the pass a pending line belongs to has seen so far, and where its record goes
-    constexpr bool prog = PROG;                             // (its own instantiation: the record keeping costs registers)
-    uint64_t pd_bar = 0, pd_tag = 0;
-    uint32_t pd_rec = 0;
-    bool pd_pass = false;                                   // (wave-uniform) a pass's record waits for its pending lines
-    auto prog_store = [&](uint32_t rec, uint64_t bar, uint64_t tag) {
-        if (lane == 0) fp.prog_bits[rec] = make_uint4((uint32_t)bar, (uint32_t)(bar >> 32), (uint32_t)tag, (uint32_t)(tag >> 32));
+    // progress windows: every phase-D pass adds what its lines matched -- barcode hits in the low half, tag hits in the
+    // high half -- to the tile's sum in LDS (two slots, by the parity of the workgroup's iteration: the tag hits of a
+    // pass's pending lines arrive in the NEXT iteration, before its barrier 1); after that barrier thread 0 writes the
+    // previous tile's sum to FParams::tile_sums.  No wave-uniform state is carried (the kernel is short of SGPRs).
+    //   L_misc[12 + parity] the sums, L_misc[14] the previous tile's index + 1 (0: it recorded nothing)
+    constexpr bool prog = PROG;                             // (its own instantiation)
+    uint32_t parity = 0;
+    if (prog && tid == 0) { L_misc[12] = 0; L_misc[13] = 0; L_misc[14] = 0; }
+    auto sums_add = [&](uint32_t slot, uint32_t add) {
+        if (lane == 0 && add) __hip_atomic_fetch_add(L_misc + 12 + slot, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
     const uint64_t first_line = p.first_line + carried;
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         {
             bool tagged = false;
             if (PIPE && pd_valid) { finish_pending(phit, pcell); pd_valid = false; tagged = phit_tag; }
-            if (prog && pd_pass) { prog_store(pd_rec, pd_bar, pd_tag | __ballot(tagged)); pd_pass = false; }
+            if (prog) sums_add(parity ^ 1u, (uint32_t)__builtin_popcountll(__ballot(tagged)) << 16);
         }
         TD_STAMP(3);   // pending line: wait for its bucket, compares
         if (nit < nwork) fetch_tile(nit);
@@ -537,12 +545,17 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         }
         const bool tile_has_hi = flg4.y != 0;
         const uint32_t nwant = (total + 3u - r0) >> 2;
-        // (with progress windows a tile's record holds 64 PROG_SLOTS wanted lines; more -- lines of a few bytes -- and
-        // the tile is left to the fix-up pass, which knows every line's number)
-        const bool regular = t != 0 && (flg4.y | flg4.z | flg4.w) == 0 && tbase + TILE + halo <= p.nbytes &&
-                             (!prog || nwant <= 64u * PROG_SLOTS);
-        if (tid == 0)
+        const bool regular = t != 0 && (flg4.y | flg4.z | flg4.w) == 0 && tbase + TILE + halo <= p.nbytes;
+        if (tid == 0) {
             fp.tile_info[t] = total | (r0 << TI_R0_SHIFT) | (tile_has_hi ? TI_HI : 0u) | (regular ? 0u : TI_SKIP);
+            if (prog) {
+                // (every add to the other slot -- the previous tile's passes, its pending lines -- came before barrier 1)
+                const uint32_t prev = L_misc[14];
+                if (prev) fp.tile_sums[prev - 1u] = L_misc[12 + (parity ^ 1u)];
+                L_misc[12 + (parity ^ 1u)] = 0;
+                L_misc[14] = regular ? t + 1u : 0u;
+            }
+        }
         TD_STAMP(6);   // C: phase
 
         // ---------------- D: wanted line j follows the terminator with in-tile ordinal r0 + 4 j
@@ -592,12 +605,9 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                     vm_settled();
                 }
                 if (prog) {
-                    // this pass is slot j / 64 of the tile's record (the same for every lane of the wave; the wave's
-                    // first lane holds its smallest j, so it is here whenever any lane is)
-                    const uint64_t bar_bits = __ballot(barred), tag_bits = __ballot(tagged);
-                    const uint32_t rec = t * PROG_SLOTS + (j >> 6);
-                    if (keep && __any(k == 1u)) { pd_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec); pd_bar = bar_bits; pd_tag = tag_bits; pd_pass = true; }
-                    else prog_store(rec, bar_bits, tag_bits);
+                    // (the wave's first lane holds its smallest j, so it is here whenever any lane is; a pending line's
+                    // barcode counts now, its tag when it is finished)
+                    sums_add(parity, (uint32_t)__builtin_popcountll(__ballot(barred)) | ((uint32_t)__builtin_popcountll(__ballot(tagged)) << 16));
                 }
             }
         }
@@ -620,6 +630,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         carry_ok = nit == t + 1u && t != 0;
         run_pos = run_pos + 1u < RUN ? run_pos + 1u : 0u;
         t = nit;
+        parity ^= 1u;
     }
     {
         bool tagged = false;
@@ -629,9 +640,16 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
             tagged = phit_tag;
             hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
         }
-        if (prog && pd_pass) prog_store(pd_rec, pd_bar, pd_tag | __ballot(tagged));
+        if (prog) sums_add(parity ^ 1u, (uint32_t)__builtin_popcountll(__ballot(tagged)) << 16);
     }
     if (p.hot_cache) hc_flush(p.counts, hcS, (uint32_t)lane);
+    if (prog) {
+        lds_barrier();                                      // (the last tile's pending lines have added their tag hits)
+        if (tid == 0) {
+            const uint32_t prev = L_misc[14];
+            if (prev) fp.tile_sums[prev - 1u] = L_misc[12 + (parity ^ 1u)];
+        }
+    }
 #ifdef TD_PHASE_PROF
     if (tid == 0)
         for (int i = 0; i < PROF_PHASES; i++) atomicAdd(p.stats + 8 + i, prof_acc[i]);

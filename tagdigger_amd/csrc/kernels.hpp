@@ -311,15 +311,15 @@ __device__ __forceinline__ uint32_t nl_mask16_ascii(const uint4 &v) {
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        // bit 7 of a byte of (x ^ c) + 0x7F..7F is clear iff the byte equals c (bytes < 0x80: no carries)
-        const uint32_t u = xor_add(x[d], 0x0A0A0A0Au, 0x7F7F7F7Fu) & 0x80808080u;       // 0x80 where the byte is NOT '\n'
+        // y = byte ^ c is 0..0x7F; (y ^ 0x7F) + 1 = 0x80 - y has bit 7 set iff y == 0 (no carries between bytes):
+        // the mask comes out in the positive sense, with no complement at the end
+        const uint32_t u = xor_add(x[d], 0x0A0A0A0Au ^ 0x7F7F7F7Fu, 0x01010101u) & 0x80808080u;       // 0x80 where the byte IS '\n'
         if (d == 0) lo = udot4(u, 0x08040201u, 0u);
         else if (d == 1) lo = udot4(u, 0x80402010u, lo);
         else if (d == 2) hi = udot4(u, 0x08040201u, 0u);
         else hi = udot4(u, 0x80402010u, hi);
     }
-    // each dot is 128 * (the complement of eight mask bits)
-    return ((lo >> 7) | (hi << 1)) ^ 0xFFFFu;
+    return (lo >> 7) | (hi << 1);             // each dot is 128 * (eight mask bits)
 }
 
 // CPT: 16-byte chunks per thread per tile (tile = CPT*4 KiB); W: 64-bit words per packed tag

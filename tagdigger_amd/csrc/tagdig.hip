@@ -170,7 +170,7 @@ struct td_handle {
     uint32_t sp_gcap = 4;                     // entries per (barcode, last two bases) group of entries16
     std::vector<uint64_t> split_win;          // td_split_file's: {with barcode, clipped} per window of 50 000 reads
     DevBuf<unsigned long long> d_win;
-    DevBuf<uint4> d_progbits;                 // k_fast2's per-tile record of what its wanted lines matched
+    DevBuf<uint32_t> d_tilesums;              // k_fast2's per-tile sums of what its wanted lines matched (progress windows)
     std::vector<uint64_t> host_acc;           // flushed counts
     uint64_t bytes_since_flush = 0;
     uint64_t flush_limit = 0xFFFFFFFFull;     // hits a uint32 cell may have taken before the matrix is flushed (tests lower it)
@@ -461,8 +461,9 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
         tdk::FParams fp{};
         fp.k = p; fp.tile_info = h->d_tileinfo.p; fp.fixlist = h->d_fixlist.p; fp.nfix = h->d_nfix.p; fp.fix_cap = fix_cap;
         if (h->progress) {
-            rc = h->d_progbits.ensure((size_t)ntiles * tdk::PROG_SLOTS); if (rc) return rc;
-            fp.prog_bits = h->d_progbits.p;
+            rc = h->d_tilesums.ensure(ntiles); if (rc) return rc;
+            HIPCHK(hipMemsetAsync(h->d_tilesums.p, 0, (size_t)ntiles * 4, stream));
+            fp.tile_sums = h->d_tilesums.p;
         }
         HIPCHK(hipMemsetAsync(h->d_nfix.p, 0, 4, stream));
         FFn ffn = gen2 ? pick_fast2(tile_kb, h->W, h->nch2, h->progress != 0) : pick_fast(tile_kb, h->W, false), fixfn = pick_fix(tile_kb, h->W);
@@ -639,7 +640,7 @@ void td_destroy(td_handle *h) {
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
     if (h->pin_cursor) (void)hipHostFree(h->pin_cursor);
-    h->d_win.release(); h->d_progbits.release(); h->d_sp_entries16.release();
+    h->d_win.release(); h->d_tilesums.release(); h->d_sp_entries16.release();
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
     h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release(); h->d_rowmap.release();
     for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
