@@ -20,8 +20,15 @@ namespace tdk {
 constexpr uint32_t SPLIT2_HALO = 512;       // bytes staged behind the tile (multiple of 64)
 
 // One sequence line whose bytes are raw[s0 .. nx - 1) (nx: start of the next line; all inside the staged window).
+#ifdef TD_PHASE_PROF
+#define TD_LSTAMP(i) do { if (pacc) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long now_ = __builtin_amdgcn_s_memtime(); pacc[i] += now_ - *plast; *plast = now_; } } while (0)
+#else
+#define TD_LSTAMP(i) do {} while (0)
+#endif
 __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsigned long long *L_bval, const uint32_t *L_bmeta,
-                                               const uint16_t *L_bdir, const uint8_t *raw, uint32_t s0, uint32_t nx) {
+                                               const uint16_t *L_bdir, const uint8_t *raw, uint32_t s0, uint32_t nx,
+                                               unsigned long long *pacc = nullptr, unsigned long long *plast = nullptr) {
+    TD_LSTAMP(6);    // line selection (list reads) before the call
     // the terminator (one byte, or "\r\n") off the end, then line.strip(): blanks off both ends
     uint32_t s = s0, e = nx - 1u;
     if (e > s && raw[e] == 0x0Au && raw[e - 1] == 0x0Du) e--;
@@ -29,6 +36,7 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
     while (e > s && is_blank(raw[e - 1])) e--;
     const uint32_t len = e - s;
     const uint8_t *src = raw + s;
+    TD_LSTAMP(7);    // terminator + strip (dependent byte reads)
 
     // ---- barcode + cut site: the first (up to 32) valid bases, packed like the index
     const uint4 q0 = lds_read16(src), q1 = lds_read16(src + 16);
@@ -50,6 +58,7 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
             ci++;
         }
     }
+    TD_LSTAMP(8);    // pack 2 pieces + barcode walk
     if (!hit) return make_int2(-1, 999);
     const uint32_t bar = meta >> 16;
     const uint32_t start = ((meta >> 6) & 63u) + p.cutlen;           // searchstart = len(barcode) + len(cutsite)
@@ -85,8 +94,10 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
             }
         }
         const uint32_t k0 = start >> 4;
-        for (uint32_t k = k0; 16u * k < len && (rs0 == 0xFFFFFFFFu || rs1 == 0xFFFFFFFFu); k++) {
-            uint4 v = lds_read16(src + 16u * k);
+        uint4 ahead = lds_read16(src + 16u * k0);                   // (the next piece is requested before this one is searched: it
+        for (uint32_t k = k0; 16u * k < len && (rs0 == 0xFFFFFFFFu || rs1 == 0xFFFFFFFFu); k++) {   //  lies inside the staged window
+            uint4 v = ahead;                                        //  whether the line reaches it or not -- the halo is 512 bytes)
+            ahead = lds_read16(src + 16u * (k + 1u));
             v.x &= 0xDFDFDFDFu; v.y &= 0xDFDFDFDFu; v.z &= 0xDFDFDFDFu; v.w &= 0xDFDFDFDFu;      // (a == A for the four letters)
             // text positions of this piece that take part: start <= position < len
             const uint32_t left = len - 16u * k, from = start > 16u * k ? start - 16u * k : 0u;
@@ -120,6 +131,7 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
             }
         }
     }
+    TD_LSTAMP(9);    // entry loads issued + site search
     if (rs0 != 0xFFFFFFFFu || rs1 != 0xFFFFFFFFu) {
         uint32_t cut;
         if (rs1 == 0xFFFFFFFFu) cut = rs0 + p.site0_len;
@@ -141,17 +153,31 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
         __builtin_memcpy(&w, raw + e - n4, 4);                           // bytes e - n4 .. e - n4 + 3
         t4 = (w << (8u * (4u - n4))) & 0xDFDFDFDFu;                      // the last character in the top byte
     }
+    // Of the group's four entries in registers, a lane takes the FIRST one its last four characters agree with and compares
+    // the rest of it -- one round of pool loads for the whole wave; only a lane whose candidate fails looks at its next
+    // one (two entries of a group share their last four characters only where the adapter repeats itself).  (Round 2
+    // compared entry by entry: up to four pool round trips per pass, one behind the other -- 29 % of the kernel's time.)
     int found = 999;
-    bool more = true;
-    for (uint32_t k = 0; more; k += 4) {
+    uint32_t tried = 0;                     // entries of the current four already looked at
+    uint32_t k = 0;
+    for (bool more = true; more;) {
+        // the first entry not yet tried whose key agrees (entries with len 0 close a group: never a candidate)
+        uint4 E = make_uint4(0u, 0u, 999u, 0u);
+        uint32_t sel = 4u;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 3; u >= 0; u--) {
             const uint32_t elen = ent[u].y;
             const uint32_t kmask = elen >= 4u ? 0xFFFFFFFFu : elen == 0u ? 0u : 0xFFFFFFFFu << (8u * (4u - elen));
-            bool same = found == 999 && elen <= len && elen != 0 && ((t4 ^ ent[u].w) & kmask) == 0;
-            if (same && elen > 4u) {
+            const bool ok = !((tried >> u) & 1u) && elen <= len && elen != 0 && ((t4 ^ ent[u].w) & kmask) == 0;
+            if (ok) { E = ent[u]; sel = (uint32_t)u; }
+        }
+        if (sel < 4u) {
+            tried |= 1u << sel;
+            const uint32_t elen = E.y;
+            bool same = true;
+            if (elen > 4u) {
                 const uint32_t rest = elen - 4u;                          // characters e - elen .. e - 4 against pool[off .. off + rest)
-                const uint8_t *a = p.pool + ent[u].x, *r = raw + e - elen;
+                const uint8_t *a = p.pool + E.x, *r = raw + e - elen;
                 constexpr int NB = 10;                                    // (entries of up to 84 characters in one go; longer: the loop below)
                 unsigned long long y[NB];
 #pragma unroll
@@ -175,15 +201,19 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
                     if (((x & 0xDFDFDFDFDFDFDFDFull) ^ yy) & m) same = false;
                 }
             }
-            found = same ? (int)ent[u].z : found;
-        }
-        // the group's next four entries, if it has any (unused entries close a group: len 0)
-        more = found == 999 && ent[3].y != 0 && k + 4 < p.gcap;
-        if (more) {
+            if (same) { found = (int)E.z; more = false; }
+        } else {
+            // none of these four (left): the group's next four entries, if it has any
+            more = ent[3].y != 0 && k + 4 < p.gcap;
+            if (more) {
+                k += 4;
+                tried = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) ent[u] = grp[k + 4 + u];
+                for (int u = 0; u < 4; u++) ent[u] = grp[k + u];
+            }
         }
     }
+    TD_LSTAMP(10);   // adapter search
     return make_int2((int)bar, found);
 }
 
@@ -212,9 +242,15 @@ __global__ __launch_bounds__(FBLOCK, 4) void k_split2(const SplitParams p) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const uint32_t voff = (uint32_t)wave * WBYTES + (uint32_t)lane * 16u;
     __syncthreads();
+#ifdef TD_PHASE_PROF
+    unsigned long long prof_acc[PROF_PHASES] = {};
+    unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#endif
 
     for (uint32_t t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
         const uint64_t tbase = (uint64_t)t * TILE;
+        TD_STAMP(0);   // loop head
+        const uint64_t P = t ? (p.prefix[t - 1] & ~FLAG_INC) : 0ull;            // terminators before this tile (used in C: its latency runs under A and B)
         // ---------------- A: this wave's quarter: raw bytes and terminator masks -> LDS (bytes past the buffer read as zero)
         const uint64_t rem = p.nbytes - tbase;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.buf + tbase), 0,
@@ -261,6 +297,7 @@ __global__ __launch_bounds__(FBLOCK, 4) void k_split2(const SplitParams p) {
             wave_crb = __any((crs & 0x8000u) != 0);
         }
         wave_lds_fence();
+        TD_STAMP(1);   // A: loads issued, waited for, raw + masks -> LDS
 
         // ---------------- B: terminators of this thread's CPT consecutive chunks, wave scan, list of line starts
         uint32_t mm[CPT / 2];
@@ -313,13 +350,14 @@ __global__ __launch_bounds__(FBLOCK, 4) void k_split2(const SplitParams p) {
                 if (incl > WCH) L_misc[2] = 1;
             }
         }
+        TD_STAMP(2);   // B
         lds_barrier();
+        TD_STAMP(3);   // barrier 1
 
         // ---------------- C: running totals, the tile's first line number
         const uint4 tot4 = *reinterpret_cast<const uint4 *>(L_misc + 4);
         const uint4 flg4 = *reinterpret_cast<const uint4 *>(L_misc);
         const uint32_t wb1 = tot4.x, wb2 = wb1 + tot4.y, wb3 = wb2 + tot4.z, total = wb3 + tot4.w;
-        const uint64_t P = t ? (p.prefix[t - 1] & ~FLAG_INC) : 0ull;            // terminators before this tile
         const uint32_t r0 = (4u - (uint32_t)((p.first_line + P) & 3)) & 3u;      // ordinals == r0 (mod 4) precede sequence lines
         const uint32_t nwant = (total + 3u - r0) >> 2;
         const bool regular = t != 0 && (flg4.y | flg4.z) == 0 && tbase + TILE + HALO <= p.nbytes;
@@ -341,15 +379,23 @@ __global__ __launch_bounds__(FBLOCK, 4) void k_split2(const SplitParams p) {
                 uint32_t nx = 0;                                               // start of the next line (0: not inside the window)
                 if (o + 1u < total) nx = at(o + 1u);
                 else {
-                    // the tile's last line: its terminator lies in the halo, if the line is not longer than that
-                    for (uint32_t q = srel > TILE ? srel : TILE; q < TILE + HALO && nx == 0; q++) {
-                        const uint32_t ch = L_raw[q];
-                        if (ch == 0x0Au || ch == 0x0Du) nx = q + 1u;
+                    // the tile's last line: its terminator lies in the halo, if the line is not longer than that -- looked for
+                    // sixteen bytes at a time (one lane of the tile walks here while its wave waits: byte by byte this was
+                    // an eighth of a pass's time)
+                    for (uint32_t q = srel > TILE ? srel : TILE; q < TILE + HALO && nx == 0; q += 16) {
+                        const uint4 v = lds_read16(L_raw + q);
+                        uint32_t m = eq_mask16(v, 0x0A0A0A0Au) | eq_mask16(v, 0x0D0D0D0Du);
+                        if (q + 16u > TILE + HALO) m &= (1u << (TILE + HALO - q)) - 1u;
+                        if (m) nx = q + (uint32_t)__builtin_ctz(m) + 1u;
                     }
                 }
                 const uint64_t line = p.first_line + P + o + 1u;
                 int2 r;
+#ifdef TD_PHASE_PROF
+                if (nx != 0) r = split_line_lds(p, L_bval, L_bmeta, L_bdir, L_raw, srel, nx, tid == 0 ? prof_acc : nullptr, &prof_last);
+#else
                 if (nx != 0) r = split_line_lds(p, L_bval, L_bmeta, L_bdir, L_raw, srel, nx);
+#endif
                 else r = split_line(p, L_bval, L_bmeta, L_bdir, tbase + srel);
                 p.out[(line - seq0) >> 2] = r;
             }
@@ -373,9 +419,15 @@ __global__ __launch_bounds__(FBLOCK, 4) void k_split2(const SplitParams p) {
                 }
             }
         }
+        TD_STAMP(4);   // C + D (thread 0's share)
         if (tid == 0) { L_misc[1] = 0; L_misc[2] = 0; }
         lds_barrier();                                    // LDS is reused by the next tile
+        TD_STAMP(5);   // end barrier
     }
+#ifdef TD_PHASE_PROF
+    if (tid == 0)
+        for (int i = 0; i < PROF_PHASES; i++) atomicAdd(p.stats + 8 + i, prof_acc[i]);
+#endif
 }
 
 }  // namespace tdk

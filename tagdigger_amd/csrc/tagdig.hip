@@ -15,6 +15,7 @@
 #include <string>
 #include <chrono>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/tagdig.h"
@@ -1916,6 +1917,23 @@ int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, co
     std::vector<uint32_t> groups((size_t)nbar * 4, 0);
     std::vector<uint8_t> pool;
     ents.reserve(nent);
+    // The entries' characters are interned: an entry that is a prefix of a string already in the pool points into it.
+    // (What a read may end with are the beginnings of ONE adapter per cutter -- build_adapter_tree :1208-1249 -- so a
+    // barcode's ~100 entries are prefixes of two strings, one of them the same for every barcode: the pool shrinks
+    // from ~1 MB to ~25 KB at 384 barcodes, and the compare's loads find their lines in the caches.)
+    std::unordered_map<std::string, uint32_t> pool_prefix;          // every prefix of every placed string -> its offset
+    {
+        std::vector<std::string> distinct;
+        for (uint32_t e = 0; e < nent; e++) distinct.emplace_back(ent_seq[e]);
+        std::sort(distinct.begin(), distinct.end(), [](const std::string &a, const std::string &c) { return a.size() != c.size() ? a.size() > c.size() : a < c; });
+        distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+        for (const std::string &str : distinct) {                    // longest first
+            if (str.empty() || pool_prefix.count(str)) continue;
+            const uint32_t off = (uint32_t)pool.size();
+            pool.insert(pool.end(), str.begin(), str.end());
+            for (size_t L = 1; L <= str.size(); L++) pool_prefix.emplace(str.substr(0, L), off);
+        }
+    }
     for (uint32_t b = 0; b < nbar; b++) {
         if (ent_begin[b] > ent_begin[b + 1] || ent_begin[b + 1] > nent) return fail(TD_E_ARG, "ent_begin must not decrease");
         for (uint32_t code = 0; code < 4; code++) {
@@ -1927,13 +1945,12 @@ int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, co
                 for (size_t q = 0; q < L; q++)
                     if (!strchr("ACGT", ent_seq[e][q])) return fail(TD_E_ALPHABET, "adapter entries must be upper-case ACGT");
                 tdk::SplitEntry en;
-                en.off = (uint32_t)pool.size(); en.len = (uint32_t)L; en.slice = ent_slice[e];
+                en.off = L ? pool_prefix.at(std::string(ent_seq[e], L)) : 0u; en.len = (uint32_t)L; en.slice = ent_slice[e];
                 // its last (up to) four characters as the word read from a read's last four bytes holds them: the last
                 // character in the top byte (k_split2 looks at the rest only when these agree)
                 en.key = 0;
                 for (size_t q = 0; q < std::min<size_t>(L, 4); q++) en.key |= (uint32_t)(uint8_t)ent_seq[e][L - 1 - q] << (8 * (3 - q));
                 ents.push_back(en);
-                pool.insert(pool.end(), (const uint8_t *)ent_seq[e], (const uint8_t *)ent_seq[e] + L);
             }
         }
     }
