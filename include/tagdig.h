@@ -127,6 +127,20 @@ int td_gunzip_file(const char *path, void *dst, uint64_t capacity, uint64_t chun
 int td_count_lines_device(td_handle *h, const void *d_fastq, uint64_t nbytes,
                           void *stream, uint64_t *terminators_out);
 
+/* ---- one file over several GPUs (tagdigger_amd/multi.py count_file_sharded; the reference reads a file with one
+ * text-mode loop, tagdigger_fun.py:240-250: a rank's byte range, or its range of BGZF members, replaces that loop's
+ * input for the rank).  Both bring the bytes into DEVICE memory through the handle's pinned staging pieces -- the host
+ * never holds more than two of them -- and return when they have landed. */
+/* bytes [offset, offset + length) of `path` -> d_dst[0 .. length) */
+int td_load_file_range(td_handle *h, const char *path, uint64_t offset, uint64_t length, void *d_dst);
+/* the members of a BGZF file: file offset and inflated size of each (the end-of-file member included); *n_members is
+ * the count whatever `capacity` holds.  TD_E_IO when some member is not BGZF. */
+int td_bgzf_index(const char *path, uint64_t *member_off, uint32_t *member_isize, uint64_t capacity, uint64_t *n_members);
+/* the members that START in [off_begin, off_end) of the file (off_begin must be a member's offset) inflated on the GPU,
+ * one after the other, into d_dst[0 .. *nbytes); every member's size and CRC-32 are checked on the device. */
+int td_bgzf_inflate_range(td_handle *h, const char *path, uint64_t off_begin, uint64_t off_end, void *d_dst, uint64_t capacity,
+                          uint64_t *nbytes_out);
+
 /* ---- barcode splitter (the adapter-trim branch) -----------------------------
  * Replaces the record loop of barcodeSplitter (tagdigger_fun.py:1318-1368) with its per-read
  * decisions -- sequence_index_lookup on barcode+cutsite (:1340) and findAdapterSeq (:1251-1283)

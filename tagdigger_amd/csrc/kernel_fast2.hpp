@@ -141,6 +141,7 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
     uint4 q[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; i++) q[i] = lds_read16(src + 16 * i);
+    TD_MSTAMP(cx, 9, 1);     // D: line start from the list + the line's pieces from LDS (waited for)
     const uint32_t first = q[0].x & 0xFFu;
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
@@ -163,6 +164,7 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
             }
         }
     }
+    TD_MSTAMP(cx, 10, 0);    // D: pack + nvalid
     // ---- barcode + cut site (reference :257)
     const uint64_t K = ((uint64_t)S[0] << 32) | S[1];
     uint32_t ci = cx.L_bdir[S[0] >> (32 - 2 * BDIR_BASES)];
@@ -177,6 +179,7 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
             ci++;
         }
     }
+    TD_MSTAMP(cx, 11, 1);    // D: barcode directory walk
     if (!bhit) return 0u;
     const uint32_t off = (meta >> 6) & 63u, row = meta >> 16;
     if (nvalid <= off) return 2u;
@@ -212,6 +215,7 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
     } else if (p.nshort == 0) {
         return 2u;
     }
+    TD_MSTAMP(cx, 12, 0);    // D: tag words, hash, bucket loads issued
     return 1u;
 }
 
@@ -334,6 +338,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
 #ifdef TD_PHASE_PROF
     unsigned long long prof_acc[PROF_PHASES] = {};
     unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+    cx.pacc = prof_acc; cx.plast = &prof_last;
 #endif
     // Tiles are dealt to the workgroups in RUNS of p.run consecutive tiles (run r of the buffer goes to workgroup
     // r mod gridDim): inside a run the line phase is CARRIED from tile to tile -- exact given the run's first tile --

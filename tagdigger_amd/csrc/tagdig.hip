@@ -200,6 +200,7 @@ struct td_handle {
     struct ZSlot { uint8_t *d_in = nullptr, *d_out = nullptr; tdinf::Member *pin_mem = nullptr, *d_mem = nullptr;
                    uint32_t *d_status = nullptr, *pin_status = nullptr; uint8_t *pin_tail = nullptr; hipEvent_t copied = nullptr; } zslot[2];
     struct ZPiece { uint8_t *pin = nullptr; hipEvent_t sent = nullptr; bool busy = false; } zpiece[2];     // pinned staging of the compressed bytes
+    ZPiece ldpiece[2];                        // td_load_file_range's pinned staging
     uint8_t *d_zscratch = nullptr; uint32_t *d_crctab = nullptr;
     uint32_t zcap_members = 0; size_t zcap_in = 0;   // what the batch buffers above were allocated for
     int gpu_inflate = 1;                      // BGZF input: inflate on the GPU (0: member-parallel on the host)
@@ -653,6 +654,7 @@ void td_destroy(td_handle *h) {
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     release_bgzf_buffers(h);
+    for (auto &lp : h->ldpiece) { if (lp.pin) (void)hipHostFree(lp.pin); if (lp.sent) (void)hipEventDestroy(lp.sent); }
     if (h->d_crctab) (void)hipFree(h->d_crctab);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->work_stream) (void)hipStreamDestroy(h->work_stream);
@@ -974,6 +976,48 @@ constexpr size_t ZB_PIECE = (size_t)64 << 20;                // ... staged throu
 constexpr size_t ZB_CARRY = (size_t)4 << 20;                 // longest line end-less tail carried to the next batch
 constexpr size_t ZB_TAIL = (size_t)1 << 20;                  // bytes of a batch's end looked at for its last line end
 
+// count_bgzf_gpu's / td_bgzf_inflate_range's batch buffers (kept on the handle between files; grown when a larger
+// file comes), the CRC tables, the kernel's LDS attribute.  *ok = false: no room on the device.
+int ensure_bgzf_buffers(td_handle *h, uint32_t need_members, size_t need_in, bool *ok_out) {
+    *ok_out = true;
+    if (need_members > h->zcap_members || need_in > h->zcap_in) {
+        need_members = std::max(need_members, h->zcap_members);
+        need_in = std::max(need_in, h->zcap_in);
+        release_bgzf_buffers(h);
+        const size_t out_cap = (size_t)need_members * 65536 + ZB_CARRY + 4096;
+        bool ok = true;
+        auto dev = [&](void **p, size_t n) { if (ok && hipMalloc(p, n) != hipSuccess) { ok = false; (void)hipGetLastError(); } };
+        auto pin = [&](void **p, size_t n) { if (ok && hipHostMalloc(p, n, hipHostMallocDefault) != hipSuccess) { ok = false; (void)hipGetLastError(); } };
+        for (auto &zp : h->zpiece) {
+            pin((void **)&zp.pin, std::min(ZB_PIECE, need_in + 64) + 64);
+            if (ok && hipEventCreateWithFlags(&zp.sent, hipEventDisableTiming) != hipSuccess) ok = false;
+        }
+        for (auto &z : h->zslot) {
+            dev((void **)&z.d_in, need_in + 1024);
+            dev((void **)&z.d_out, out_cap);
+            pin((void **)&z.pin_mem, (size_t)need_members * sizeof(tdinf::Member));
+            dev((void **)&z.d_mem, (size_t)need_members * sizeof(tdinf::Member));
+            dev((void **)&z.d_status, (size_t)need_members * 4);
+            pin((void **)&z.pin_status, (size_t)need_members * 4);
+            pin((void **)&z.pin_tail, ZB_TAIL);
+            if (ok && hipEventCreateWithFlags(&z.copied, hipEventDisableTiming) != hipSuccess) ok = false;
+        }
+        dev((void **)&h->d_zscratch, (size_t)need_members * tdinf::SCRATCH_BYTES);
+        if (!ok) { release_bgzf_buffers(h); *ok_out = false; return TD_OK; }
+        h->zcap_members = need_members; h->zcap_in = need_in;
+    }
+    if (!h->d_crctab) {
+        uint32_t T[1024];                                        // slicing-by-4: T[256 k + b] = CRC of byte b followed by k zero bytes
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; T[i] = c; }
+        for (uint32_t k = 1; k < 4; k++)
+            for (uint32_t i = 0; i < 256; i++) T[256 * k + i] = T[T[256 * (k - 1) + i] & 0xFFu] ^ (T[256 * (k - 1) + i] >> 8);
+        HIPCHK(hipMalloc((void **)&h->d_crctab, sizeof(T)));
+        HIPCHK(hipMemcpy(h->d_crctab, T, sizeof(T), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipFuncSetAttribute((const void *)tdinf::k_bgzf_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * tdinf::TABLE_U16 * 2 + 4096));
+    return TD_OK;
+}
+
 int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weights, bool *not_bgzf) {
     *not_bgzf = false;
     tdhost::GzSource src;
@@ -999,46 +1043,14 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
         need_members = std::min<uint32_t>(ZB_MEMBERS, std::max<uint32_t>(64, (n + 63) / 64 * 64));
         need_in = std::min<size_t>(ZB_IN, (src.bsize + 4095) / 4096 * 4096);
     }
-    if (need_members > h->zcap_members || need_in > h->zcap_in) {
-        // (kept on the handle between files; grown when a larger file comes)
-        release_bgzf_buffers(h);
-        const size_t out_cap = (size_t)need_members * 65536 + ZB_CARRY + 4096;
+    {
         bool ok = true;
-        auto dev = [&](void **p, size_t n) { if (ok && hipMalloc(p, n) != hipSuccess) { ok = false; (void)hipGetLastError(); } };
-        auto pin = [&](void **p, size_t n) { if (ok && hipHostMalloc(p, n, hipHostMallocDefault) != hipSuccess) { ok = false; (void)hipGetLastError(); } };
-        for (auto &zp : h->zpiece) {
-            pin((void **)&zp.pin, std::min(ZB_PIECE, need_in + 64) + 64);
-            if (ok && hipEventCreateWithFlags(&zp.sent, hipEventDisableTiming) != hipSuccess) ok = false;
-        }
-        for (auto &z : h->zslot) {
-            dev((void **)&z.d_in, need_in + 1024);
-            dev((void **)&z.d_out, out_cap);
-            pin((void **)&z.pin_mem, (size_t)need_members * sizeof(tdinf::Member));
-            dev((void **)&z.d_mem, (size_t)need_members * sizeof(tdinf::Member));
-            dev((void **)&z.d_status, (size_t)need_members * 4);
-            pin((void **)&z.pin_status, (size_t)need_members * 4);
-            pin((void **)&z.pin_tail, ZB_TAIL);
-            if (ok && hipEventCreateWithFlags(&z.copied, hipEventDisableTiming) != hipSuccess) ok = false;
-        }
-        dev((void **)&h->d_zscratch, (size_t)need_members * tdinf::SCRATCH_BYTES);
-        if (!ok) {                                                 // no room on the device: the host inflater takes the file
-            release_bgzf_buffers(h);
-            *not_bgzf = true;
-            return TD_OK;
-        }
-        h->zcap_members = need_members; h->zcap_in = need_in;
+        const int rc_b = ensure_bgzf_buffers(h, need_members, need_in, &ok);
+        if (rc_b) return rc_b;
+        if (!ok) { *not_bgzf = true; return TD_OK; }          // no room on the device: the host inflater takes the file
     }
     const uint32_t batch_members = std::min<uint32_t>(h->zcap_members, h->zb_members);
     const size_t batch_in = h->zcap_in, piece_cap = std::min(ZB_PIECE, h->zcap_in + 64);
-    if (!h->d_crctab) {
-        uint32_t T[1024];                                        // slicing-by-4: T[256 k + b] = CRC of byte b followed by k zero bytes
-        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; T[i] = c; }
-        for (uint32_t k = 1; k < 4; k++)
-            for (uint32_t i = 0; i < 256; i++) T[256 * k + i] = T[T[256 * (k - 1) + i] & 0xFFu] ^ (T[256 * (k - 1) + i] >> 8);
-        HIPCHK(hipMalloc((void **)&h->d_crctab, sizeof(T)));
-        HIPCHK(hipMemcpy(h->d_crctab, T, sizeof(T), hipMemcpyHostToDevice));
-    }
-    HIPCHK(hipFuncSetAttribute((const void *)tdinf::k_bgzf_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * tdinf::TABLE_U16 * 2 + 4096));
     HIPCHK(hipMemsetAsync(h->d_cursor.p, 0, 16, h->work_stream));
     struct Batch { uint32_t n = 0; size_t out_total = 0; bool last = false; };
     size_t pos = 0;
@@ -1218,6 +1230,156 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
     int rc = pump(h, reader, 0, 0, max_reads, weights, nullptr);
     close(fd);
     return rc;
+}
+
+// ---- a byte range of a file, or a range of BGZF members, brought into DEVICE memory (multi-GPU: one file over several
+// ranks, tagdigger_amd/multi.py count_file_sharded): staged through the handle's pinned buffers -- the host never holds
+// more than two staging pieces of the shard
+int td_load_file_range(td_handle *h, const char *path, uint64_t offset, uint64_t length, void *d_dst) {
+    if (!h || !path || (!d_dst && length)) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (length == 0) return TD_OK;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(TD_E_IO, std::string("cannot open ") + path);
+    struct FdEnd { int fd; ~FdEnd() { close(fd); } } fd_end{fd};
+    constexpr size_t PIECE = (size_t)32 << 20;
+    for (auto &lp : h->ldpiece) {
+        if (lp.pin) continue;
+        HIPCHK(hipHostMalloc((void **)&lp.pin, PIECE, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&lp.sent, hipEventDisableTiming));
+    }
+    int k = 0;
+    for (uint64_t pos = 0; pos < length; pos += PIECE, k ^= 1) {
+        td_handle::ZPiece &lp = h->ldpiece[k];
+        if (lp.busy) { HIPCHK(hipEventSynchronize(lp.sent)); lp.busy = false; }
+        const size_t n = (size_t)std::min<uint64_t>(PIECE, length - pos);
+        const bool ok = stage_parallel(n, [&](size_t off, size_t len) {
+            while (len) {
+                const ssize_t got = pread(fd, lp.pin + off, len, (off_t)(offset + pos + off));
+                if (got <= 0) return false;
+                off += (size_t)got; len -= (size_t)got;
+            }
+            return true;
+        });
+        if (!ok) return fail(TD_E_IO, "read error (or the file is shorter than offset + length)");
+        HIPCHK(hipMemcpyAsync((uint8_t *)d_dst + pos, lp.pin, n, hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(hipEventRecord(lp.sent, h->copy_stream));
+        lp.busy = true;
+    }
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    for (auto &lp : h->ldpiece) lp.busy = false;
+    return TD_OK;
+}
+
+int td_bgzf_index(const char *path, uint64_t *member_off, uint32_t *member_isize, uint64_t capacity, uint64_t *n_members) {
+    if (!path || !n_members || (capacity && (!member_off || !member_isize))) return fail(TD_E_ARG, "NULL argument");
+    tdhost::GzSource src;
+    if (!src.map_only(path)) return fail(TD_E_IO, std::string("cannot open ") + path);
+    uint64_t n = 0;
+    for (size_t at = 0; at < src.bsize;) {
+        uint32_t bs = 0, hs = 0;
+        if (!tdhost::GzSource::bgzf_header(src.map + at, src.bsize - at, &bs, &hs) || bs < hs + 8 || at + bs > src.bsize)
+            return fail(TD_E_IO, "not a BGZF file (a member without the BC extra field, or damaged)");
+        const uint8_t *tail = src.map + at + bs - 8;
+        const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (isize > 65536) return fail(TD_E_IO, "BGZF member larger than 64 KiB");
+        if (n < capacity) { member_off[n] = at; member_isize[n] = isize; }
+        n++;
+        at += bs;
+    }
+    *n_members = n;
+    return TD_OK;
+}
+
+int td_bgzf_inflate_range(td_handle *h, const char *path, uint64_t off_begin, uint64_t off_end, void *d_dst, uint64_t capacity,
+                          uint64_t *nbytes_out) {
+    if (!h || !path || !nbytes_out || (!d_dst && capacity)) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    *nbytes_out = 0;
+    tdhost::GzSource src;
+    if (!src.map_only(path)) return fail(TD_E_IO, std::string("cannot open ") + path);
+    if (off_end > src.bsize) off_end = src.bsize;
+    if (off_begin >= off_end) return TD_OK;
+    uint32_t need_members = ZB_MEMBERS;
+    size_t need_in = ZB_IN;
+    if (off_end - off_begin <= ((uint64_t)1 << 30)) {
+        need_in = std::min<size_t>(ZB_IN, (size_t)((off_end - off_begin + 4095) / 4096 * 4096));
+        need_members = (uint32_t)std::min<uint64_t>(ZB_MEMBERS, std::max<uint64_t>(64, ((off_end - off_begin) / 28 + 64) / 64 * 64));   // (a member is 28 bytes at least)
+        // (an upper bound only: walk the range when it is small enough for the bound to be wasteful)
+        uint32_t n = 0;
+        for (size_t at = off_begin; at < off_end; n++) {
+            uint32_t bs = 0, hs = 0;
+            if (!tdhost::GzSource::bgzf_header(src.map + at, src.bsize - at, &bs, &hs) || bs < hs + 8 || at + bs > src.bsize)
+                return fail(TD_E_IO, "damaged BGZF member header");
+            at += bs;
+        }
+        need_members = std::min<uint32_t>(ZB_MEMBERS, std::max<uint32_t>(64, (n + 63) / 64 * 64));
+    }
+    bool ok = true;
+    int rc = ensure_bgzf_buffers(h, need_members, need_in, &ok);
+    if (rc) return rc;
+    if (!ok) return fail(TD_E_HIP, "no room on the device for the BGZF batch buffers");
+    const uint32_t batch_members = std::min<uint32_t>(h->zcap_members, h->zb_members);
+    const size_t batch_in = h->zcap_in, piece_cap = std::min(ZB_PIECE, h->zcap_in + 64);
+    size_t pos = off_begin;
+    uint64_t out_pos = 0;
+    struct Batch { uint32_t n = 0; size_t out_total = 0; };
+    auto prepare = [&](int slot, Batch &b) -> int {
+        td_handle::ZSlot &z = h->zslot[slot];
+        b = Batch();
+        const size_t first = pos;
+        while (pos < off_end && b.n < batch_members) {
+            uint32_t bs = 0, hs = 0;
+            if (!tdhost::GzSource::bgzf_header(src.map + pos, src.bsize - pos, &bs, &hs) || bs < hs + 8 || pos + bs > src.bsize)
+                return fail(TD_E_IO, "damaged BGZF member header");
+            if (pos + bs - first > batch_in) break;
+            const uint8_t *tail = src.map + pos + bs - 8;
+            const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+            const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+            if (isize > 65536) return fail(TD_E_IO, "BGZF member larger than 64 KiB");
+            z.pin_mem[b.n] = tdinf::Member{pos + hs - first, b.out_total, bs - hs - 8, isize, crc, 0};
+            b.out_total += isize; b.n++;
+            pos += bs;
+        }
+        const size_t nin = pos - first;
+        int k = 0;
+        for (size_t off = 0; off < nin + 64; off += piece_cap, k ^= 1) {
+            td_handle::ZPiece &zp = h->zpiece[k];
+            if (zp.busy) { HIPCHK(hipEventSynchronize(zp.sent)); zp.busy = false; }
+            const size_t want = std::min(piece_cap, nin + 64 - off), have = off < nin ? std::min(want, nin - off) : 0;
+            if (have) stage_parallel(have, [&](size_t o2, size_t len) { memcpy(zp.pin + o2, src.map + first + off + o2, len); return true; });
+            if (want > have) memset(zp.pin + have, 0, want - have);
+            HIPCHK(hipMemcpyAsync(z.d_in + off, zp.pin, want, hipMemcpyHostToDevice, h->copy_stream));
+            HIPCHK(hipEventRecord(zp.sent, h->copy_stream));
+            zp.busy = true;
+        }
+        if (b.n) HIPCHK(hipMemcpyAsync(z.d_mem, z.pin_mem, (size_t)b.n * sizeof(tdinf::Member), hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(hipEventRecord(z.copied, h->copy_stream));
+        return TD_OK;
+    };
+    Batch cur, nxt;
+    int slot = 0;
+    rc = prepare(0, cur); if (rc) return rc;
+    while (cur.n) {
+        td_handle::ZSlot &z = h->zslot[slot];
+        if (out_pos + cur.out_total > capacity) return fail(TD_E_LIMIT, "destination too small for the inflated members");
+        HIPCHK(hipStreamWaitEvent(h->work_stream, z.copied, 0));
+        hipLaunchKernelGGL(tdinf::k_bgzf_inflate, dim3((cur.n + 63) / 64), dim3(64), 64 * tdinf::TABLE_U16 * 2 + 4096, h->work_stream,
+                           z.d_in, (uint8_t *)d_dst + out_pos, z.d_mem, cur.n, h->d_zscratch, z.d_status, h->d_crctab, (uint32_t)h->gpu_inflate_crc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(z.pin_status, z.d_status, (size_t)cur.n * 4, hipMemcpyDeviceToHost, h->work_stream));
+        // the next batch is read and sent while this one inflates
+        rc = prepare(slot ^ 1, nxt); if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(h->work_stream));
+        for (uint32_t i = 0; i < cur.n; i++)
+            if (z.pin_status[i]) return fail(TD_E_IO, z.pin_status[i] == 100 ? "BGZF member fails its CRC-32" : "inflate error in a BGZF member");
+        out_pos += cur.out_total;
+        cur = nxt; slot ^= 1;
+    }
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    for (auto &zp : h->zpiece) zp.busy = false;
+    *nbytes_out = out_pos;
+    return TD_OK;
 }
 
 int td_get_stats(td_handle *h, uint64_t stats[TD_STAT_NSTATS]) {

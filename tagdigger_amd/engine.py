@@ -7,6 +7,7 @@ lists to libtagdig (td_set_index), which builds the flat device index.  The
 record loop (:239-277) runs on the GPU.
 """
 import ctypes as C
+import os
 import gzip
 import math
 
@@ -237,6 +238,16 @@ class Engine:
         B.check(self._L.td_count_lines_device(self._h, C.c_void_p(d_ptr), nbytes,
                                               C.c_void_p(stream) if stream else None, C.byref(out)))
         return out.value
+
+    def load_file_range(self, path, offset, length, d_dst):
+        """bytes [offset, offset + length) of a file -> device memory at d_dst, through the library's pinned staging pieces"""
+        B.check(self._L.td_load_file_range(self._h, os.fsencode(path), int(offset), int(length), C.c_void_p(d_dst)))
+
+    def bgzf_inflate_range(self, path, off_begin, off_end, d_dst, capacity):
+        """the BGZF members starting in [off_begin, off_end) of a file, inflated on the GPU into d_dst; returns the bytes written"""
+        n = C.c_uint64(0)
+        B.check(self._L.td_bgzf_inflate_range(self._h, os.fsencode(path), int(off_begin), int(off_end), C.c_void_p(d_dst), int(capacity), C.byref(n)))
+        return n.value
 
     def fold_rows(self, rows, d_dst, n_dst_rows, stream=0):
         """K3: add this library's barcode rows into sample rows on the device (d_dst: n_dst_rows x ntags uint32 in

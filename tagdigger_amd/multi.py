@@ -131,60 +131,193 @@ def count_terminators(data):
     return n
 
 
+# ---------------------------------------------------------------------------------------------
+# The same for a BGZF file (bgzip: independent gzip members of at most 64 KiB): a rank takes a contiguous range of
+# MEMBERS (nominal equal shares of the compressed bytes); members do not end at line ends, so a rank's lines run
+# from the first line start in its members to the first line start in the members behind them.
+# ---------------------------------------------------------------------------------------------
+def bgzf_index(path):
+    """(member offsets, inflated sizes) of a BGZF file as numpy arrays -- td_bgzf_index (host only)."""
+    import ctypes as C
+    from . import _binding as B
+    L = B.load()
+    n = C.c_uint64(0)
+    B.check(L.td_bgzf_index(path.encode(), None, None, 0, C.byref(n)))
+    off = np.zeros(max(1, n.value), dtype=np.uint64)
+    isz = np.zeros(max(1, n.value), dtype=np.uint32)
+    B.check(L.td_bgzf_index(path.encode(), C.c_void_p(off.ctypes.data), C.c_void_p(isz.ctypes.data), n.value, C.byref(n)))
+    return off[:n.value], isz[:n.value]
+
+
+def bgzf_member_ranges(member_off, file_size, world):
+    """[(first member, end member)] per rank: the members that START in the rank's nominal share of the file."""
+    first = [int(np.searchsorted(member_off, np.uint64(file_size * r // world), side="left")) for r in range(world)] + [len(member_off)]
+    return [(first[r], max(first[r], first[r + 1])) for r in range(world)]
+
+
+def first_line_start(data, prev_byte):
+    """Offset of the first line START inside `data` (bytes-like), given the byte before it (None: the file begins
+    here, so 0); len(data) when no line starts in it.  A line starts after \n, \r\n or a bare \r."""
+    n = len(data)
+    if prev_byte is None or prev_byte == 0x0A:
+        return 0
+    if prev_byte == 0x0D:
+        return 1 if n and data[0] == 0x0A else 0
+    a = np.frombuffer(data, dtype=np.uint8)
+    hits = np.flatnonzero((a == 0x0A) | (a == 0x0D))
+    if hits.size == 0:
+        return n
+    i = int(hits[0])
+    if a[i] == 0x0D and i + 1 < n and a[i + 1] == 0x0A:
+        return i + 2
+    return i + 1          # (a \r in the last byte: if a \n opens the next shard, that shard's own rule skips it)
+
+
+def _bgzf_member_bytes(path, off, end):
+    """members [off, end) of the file inflated on the host (zlib): the CPU stand-in, and single members (a shard's neighbour)"""
+    import zlib
+    out = []
+    with open(path, "rb") as fh:
+        fh.seek(int(off))
+        raw = fh.read(int(end - off))
+    pos = 0
+    while pos < len(raw):
+        d = zlib.decompressobj(31)
+        out.append(d.decompress(raw[pos:]))
+        pos = len(raw) - len(d.unused_data)
+    return b"".join(out)
+
+
 def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, counter=None, device=None, as_array=False,
                        progress=False):
-    """find_tags_fastq on one plain FASTQ file, byte-sharded over the ranks of the default process
-    group (every rank calls this with the same arguments; backend "nccl" = RCCL for GPUs).
+    """find_tags_fastq on one FASTQ file -- plain, or BGZF-compressed (bgzip) -- sharded over the ranks of the default
+    process group (every rank calls this with the same arguments; backend "nccl" = RCCL for GPUs).
     Returns the whole file's matrix on every rank, bit-identical to the single-GPU result for any
     number of ranks.
 
-    counter=None (the product path): the shard is read into pinned-able host memory once, copied to this
-    rank's GPU, its line terminators are counted THERE (td_count_lines_device), the counts are all-gathered
-    (-> this shard's first line index), the shard is counted in place with the global maxreads bound, and the
-    device matrix is all-reduced.
+    counter=None (the product path): the rank's byte range (plain) or member range (BGZF: inflated on the GPU) is
+    brought into device memory through the library's pinned staging pieces -- the host never holds the shard --, its
+    line terminators are counted THERE (td_count_lines_device), the counts are all-gathered (-> this shard's first line
+    index), the shard is counted in place with the global maxreads bound, and the device matrix is all-reduced.
     counter(data, barcodes, tags, cutsite, first_line, maxreads) -> matrix stands in for the GPU in the CPU
     rehearsal.
     progress=True (device path): rank 0 prints the reference's progress lines (:268-271) -- every shard keeps its
     per-window counters by GLOBAL read ordinal, so the windows of all ranks simply add up (one more small all-reduce)."""
     import math
+    import os
     rank, world = _rank_world()
-    if path[-2:].lower() == 'gz':
-        raise ValueError("byte sharding needs an uncompressed file; split gzip input per library instead")
-    start, end = shard_bounds(path, world)[rank]
-    data = np.fromfile(path, dtype=np.uint8, count=end - start, offset=start)
+    is_gz = path[-2:].lower() == 'gz'
     # The maxreads bound is global and so is the line index each shard is counted with: device and oracle
     # both compare the bound with the GLOBAL read ordinal (first_line + lines seen), so it is passed on
     # unchanged; a shard that starts at or past the bound is skipped.
     bound = max(1, int(math.ceil(min(maxreads, 2 ** 62))))
 
-    def first_line_of(my_terminators, where):
-        mine = torch.tensor([my_terminators], dtype=torch.int64, device=where)
+    def gather_ints(value, where):
+        mine = torch.tensor([value], dtype=torch.int64, device=where)
         if world == 1:
-            return 0
+            return [int(value)]
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        return int(sum(int(t[0]) for t in every[:rank]))
+        return [int(t[0]) for t in every]
 
-    if counter is None:
+    def first_line_of(my_terminators, where):
+        return int(sum(gather_ints(my_terminators, where)[:rank]))
+
+    use_gpu = counter is None
+    if use_gpu:
         from . import tagdigger_fun
         if isinstance(device, torch.device):
             dev = device if device.index is not None else torch.device("cuda", 0)
         else:
             dev = torch.device("cuda", int(device or 0))
         eng = tagdigger_fun.default_engine(dev.index)
+    where = dev if use_gpu else "cpu"
+
+    # ---- this rank's bytes: `shard` (device tensor, 16-byte aligned) or `data` (host bytes, the stand-in), n bytes
+    data, shard = None, None
+    if not is_gz:
+        start, end = shard_bounds(path, world)[rank]
+        n = end - start
+        if use_gpu:
+            shard = torch.empty(max(16, n), dtype=torch.uint8, device=dev)         # (torch allocations are 256-byte aligned)
+            if n:
+                eng.load_file_range(path, start, n, shard.data_ptr())
+        else:
+            data = np.fromfile(path, dtype=np.uint8, count=n, offset=start).tobytes()
+    else:
+        try:
+            moff, misz = bgzf_index(path)
+        except Exception:
+            raise ValueError("sharding a compressed file needs BGZF (bgzip); split other gzip input per library instead")
+        fsize = os.path.getsize(path)
+        ends = np.append(moff[1:], np.uint64(fsize))
+        gpos = np.concatenate(([0], np.cumsum(misz.astype(np.int64))))            # inflated offset of every member (and the total)
+        m0, m1 = bgzf_member_ranges(moff, fsize, world)[rank]
+        own_len = int(gpos[m1] - gpos[m0])
+        # the byte before my members (the last byte of the nearest non-empty member before them)
+        prev_byte = None
+        k = m0 - 1
+        while k >= 0 and misz[k] == 0:
+            k -= 1
+        if k >= 0:
+            prev_byte = _bgzf_member_bytes(path, moff[k], ends[k])[-1]
+        if use_gpu:
+            buf = torch.empty(max(16, own_len + (1 << 20)), dtype=torch.uint8, device=dev)
+            got = eng.bgzf_inflate_range(path, int(moff[m0]) if m0 < len(moff) else fsize, int(moff[m1]) if m1 < len(moff) else fsize,
+                                         buf.data_ptr(), own_len) if own_len else 0
+            assert got == own_len
+            # my first line start: the first terminator is looked for in pieces copied back (the first one holds it)
+            a, seen, pb = own_len, 0, prev_byte
+            while seen < own_len:
+                piece = buf[seen:min(own_len, seen + (1 << 20))].cpu().numpy().tobytes()
+                f = first_line_start(piece, pb)
+                if f < len(piece):
+                    a = seen + f
+                    break
+                seen += len(piece)
+                pb = piece[-1]               # (a terminator in the piece's last byte: the next piece's first byte decides)
+        else:
+            own = _bgzf_member_bytes(path, moff[m0], ends[m1 - 1]) if m1 > m0 else b""
+            a = first_line_start(own, prev_byte)
+        # every rank's first line start as an offset into the inflated file; mine end where the next one's begin
+        starts = gather_ints(int(gpos[m0]) + a if a < own_len else -1, where) + [int(gpos[-1])]
+        for r in range(world - 1, -1, -1):                                         # (a shard without a line start owns nothing)
+            if starts[r] < 0:
+                starts[r] = starts[r + 1]
+        g0, g1 = starts[rank], starts[rank + 1]
+        n = g1 - g0
+        # the part of my lines that lies in the members behind mine
+        tail_len = max(0, g1 - int(gpos[m1]))
+        if use_gpu:
+            if tail_len:
+                mt = int(np.searchsorted(gpos, g1, side="left"))                   # members m1 .. mt - 1 hold it
+                cap = int(gpos[mt] - gpos[m1])
+                if own_len + cap > buf.numel():
+                    bigger = torch.empty(own_len + cap, dtype=torch.uint8, device=dev)
+                    bigger[:own_len].copy_(buf[:own_len])
+                    buf = bigger
+                eng.bgzf_inflate_range(path, int(moff[m1]), int(moff[mt]) if mt < len(moff) else fsize, buf.data_ptr() + own_len, cap)
+            lo = g0 - int(gpos[m0])
+            shard = buf[lo:lo + n].clone() if n else torch.empty(16, dtype=torch.uint8, device=dev)   # (a 256-byte aligned copy)
+            del buf
+        else:
+            if tail_len:
+                mt = int(np.searchsorted(gpos, g1, side="left"))
+                own = own + _bgzf_member_bytes(path, moff[m1], ends[mt - 1])
+            lo = g0 - int(gpos[m0])
+            data = own[lo:lo + n]
+
+    if use_gpu:
         eng.set_index(barcodes, tags, cutsite)
         eng.set_option("progress", 1 if progress else 0)
         total = torch.zeros(len(barcodes) * len(tags), dtype=torch.int32, device=dev)
-        shard = torch.empty(max(16, data.size), dtype=torch.uint8, device=dev)         # (torch allocations are 256-byte aligned)
-        if data.size:
-            shard[:data.size].copy_(torch.from_numpy(data))
         torch.cuda.synchronize(dev)
-        terms = eng.count_lines_device(shard.data_ptr(), int(data.size)) if data.size else 0
+        terms = eng.count_lines_device(shard.data_ptr(), int(n)) if n else 0
         first_line = first_line_of(terms, dev)
         eng.bind_counts(total.data_ptr())
         try:
-            if data.size and (first_line + 2) // 4 < bound:
-                eng.count_device(shard.data_ptr(), int(data.size), first_line=first_line, maxreads=bound)
+            if n and (first_line + 2) // 4 < bound:
+                eng.count_device(shard.data_ptr(), int(n), first_line=first_line, maxreads=bound)
             st = eng.stats()                                   # (synchronises; raises what a kernel flagged)
             if progress:
                 # reads of the whole file, then every rank's windows laid over the same axis and summed
@@ -215,8 +348,8 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
     else:
         first_line = first_line_of(count_terminators(data), "cpu")
         out = np.zeros((len(barcodes), len(tags)), dtype=np.int64)
-        if data.size and (first_line + 2) // 4 < bound:     # sequence lines (index 1 mod 4) below first_line: (first_line + 2) // 4
-            out += np.asarray(counter(data.tobytes(), barcodes, tags, cutsite, first_line, bound), dtype=np.int64).reshape(out.shape)
+        if n and (first_line + 2) // 4 < bound:     # sequence lines (index 1 mod 4) below first_line: (first_line + 2) // 4
+            out += np.asarray(counter(bytes(data), barcodes, tags, cutsite, first_line, bound), dtype=np.int64).reshape(out.shape)
         if world > 1:
             dist.all_reduce(torch.from_numpy(out), op=dist.ReduceOp.SUM)
     return out if as_array else out.tolist()

@@ -228,3 +228,139 @@ def test_fold_rows_after_a_flush_to_the_host_accumulator():
         eng.set_option("flush_limit", 0)
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------- one BGZF file over the ranks (members, not bytes)
+def _bgzf_file(tmp_path, style, block, seed=7):
+    from helpers import bgzf_bytes
+    path, data, barcodes, tags = _dirty_file(tmp_path, style, seed=seed)
+    gz = path + ".gz"
+    open(gz, "wb").write(bgzf_bytes(data, block=block, level=6))
+    return gz, data, barcodes, tags
+
+
+@pytest.mark.parametrize("style,block", [("mixed", 4096), ("crlf", 997), ("cr", 1500), ("nofinal", 0xFF00), ("mixed", 61)])
+def test_bgzf_member_shards_tile_the_file_at_line_starts(tmp_path, style, block):
+    """The pieces of the ownership rule, for every number of ranks: a rank's lines run from the first line start in its
+    members to the first line start behind them (members do not end at line ends; with 61-byte members most ranks'
+    members hold no line start at all); the ranges tile the inflated file, begin at line starts, and counted with
+    their own first line index add up to the whole file's matrix."""
+    from oracle import c_oracle
+    from tagdigger_amd import multi
+    gz, data, barcodes, tags = _bgzf_file(tmp_path, style, block)
+    want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data)
+    moff, misz = multi.bgzf_index(gz)
+    assert int(misz.astype("int64").sum()) == len(data) and misz[-1] == 0            # (the end-of-file member)
+    import numpy as np
+    gpos = np.concatenate(([0], np.cumsum(misz.astype(np.int64))))
+    fsize = os.path.getsize(gz)
+    for world in (1, 2, 3, 7, 16):
+        ranges = multi.bgzf_member_ranges(moff, fsize, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == len(moff) and all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
+        starts = []
+        for m0, m1 in ranges:
+            own = data[int(gpos[m0]):int(gpos[m1])]
+            prev = data[int(gpos[m0]) - 1] if gpos[m0] > 0 else None
+            a = multi.first_line_start(own, prev)
+            starts.append(int(gpos[m0]) + a if a < len(own) else -1)
+        starts.append(len(data))
+        for r in range(world - 1, -1, -1):
+            if starts[r] < 0:
+                starts[r] = starts[r + 1]
+        assert starts[0] == 0
+        total, first_line = 0 * want, 0
+        for r in range(world):
+            a, b = starts[r], starts[r + 1]
+            assert a <= b
+            if 0 < a < len(data) and a < b:
+                assert data[a - 1:a] in (b"\n", b"\r") and not (data[a - 1:a] == b"\r" and data[a:a + 1] == b"\n")
+            piece = data[a:b]
+            if piece:
+                total = total + c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(piece, first_line=first_line)
+                first_line += multi.count_terminators(piece)
+        assert (total == want).all(), world
+
+
+def _bgzf_worker(rank, world, port, path, barcodes, tags, maxreads, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tagdigger_amd import multi
+    res = multi.count_file_sharded(path, barcodes, tags, "TGCAG", maxreads=maxreads, counter=_oracle_shard_counter)
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,block,maxreads", [(2, 4096, 5e9), (2, 997, 250), (3, 61, 5e9), (3, 1500, 150)])
+def test_ranks_shard_one_bgzf_file(tmp_path, world, block, maxreads):
+    """count_file_sharded on a BGZF file (CPU stand-in for the counter, members inflated with zlib): the whole
+    file's matrix for any number of ranks, the maxreads bound applied in the shard it falls into."""
+    from oracle import c_oracle
+    gz, data, barcodes, tags = _bgzf_file(tmp_path, "mixed", block, seed=11)
+    want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data, maxreads=maxreads).tolist()
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_bgzf_worker, args=(world, _free_port(), gz, barcodes, tags, maxreads, out), nprocs=world, join=True)
+    assert torch.load(out) == want
+
+
+def test_sharding_refuses_a_gzip_file_that_is_not_bgzf(tmp_path):
+    import gzip
+    from tagdigger_amd import multi
+    path, data, barcodes, tags = _dirty_file(tmp_path, "mixed")
+    gz = path + ".gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(data)
+    with pytest.raises(ValueError):
+        multi.count_file_sharded(gz, barcodes, tags, "TGCAG", counter=_oracle_shard_counter)
+
+
+def _device_bgzf_worker(rank, world, port, path, barcodes, tags, maxreads, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tagdigger_amd import multi
+    res = multi.count_file_sharded(path, barcodes, tags, "TGCAG", maxreads=maxreads, device=torch.device("cuda", 0))
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block,maxreads", [(4096, 5e9), (997, 300), (61, 5e9)])
+def test_device_path_member_sharded_bgzf_file(tmp_path, block, maxreads):
+    """The product path on a BGZF file: the rank's members inflated on the GPU into device memory
+    (td_bgzf_inflate_range), its first line start found there, the lines' tail fetched from the members behind its
+    own, counted in place; one process, then two ranks rehearsing on GPU 0."""
+    from oracle import c_oracle
+    from tagdigger_amd import multi
+    gz, data, barcodes, tags = _bgzf_file(tmp_path, "mixed", block, seed=11)
+    want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data, maxreads=maxreads).tolist()
+    assert multi.count_file_sharded(gz, barcodes, tags, "TGCAG", maxreads=maxreads, device=0) == want
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_device_bgzf_worker, args=(2, _free_port(), gz, barcodes, tags, maxreads, out), nprocs=2, join=True)
+    assert torch.load(out) == want
+
+
+@pytest.mark.gpu
+def test_load_file_range_streams_through_two_pinned_pieces(tmp_path):
+    """td_load_file_range: a byte range of a file into device memory (pieces of 32 MiB: this range takes three), byte
+    for byte; the host side holds the staging pieces only."""
+    import numpy as np
+    import tagdigger_amd
+    rng = np.random.default_rng(5)
+    blob = rng.integers(0, 256, 80 * (1 << 20) + 12345, dtype=np.uint8)
+    path = str(tmp_path / "blob.bin")
+    blob.tofile(path)
+    eng = tagdigger_amd.Engine(0)
+    try:
+        off, n = 4097, 70 * (1 << 20) + 777
+        dst = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+        eng.load_file_range(path, off, n, dst.data_ptr())
+        assert bool((dst.cpu().numpy() == blob[off:off + n]).all())
+        with pytest.raises(tagdigger_amd._binding.TagdigError):
+            eng.load_file_range(path, blob.size - 10, 100, dst.data_ptr())      # (beyond the file's end)
+    finally:
+        eng.close()

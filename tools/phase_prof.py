@@ -24,8 +24,8 @@ NAMES = ["loop head", "A: wait bytes + masks + pack", "barrier A", "B: scan + lo
 
 
 NAMES2 = ["loop head", "A: wait bytes, raw + masks -> LDS (own quarter)", "B: masks, scan, vote, list", "  pending: wait bucket + compares",
-          "  next loads issued, pending commit", "barrier 1", "C: phase", "D: pack + match (thread 0)", "end barrier",
-          "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-"]
+          "  next loads issued, pending commit", "barrier 1", "C: phase", "D: remainder (thread 0)", "end barrier",
+          "  D: list + pieces from LDS", "  D: pack + nvalid", "  D: barcode walk", "  D: tag words, hash, bucket loads", "-", "-", "-", "-", "-", "-", "-"]
 
 
 def main():
