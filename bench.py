@@ -111,6 +111,9 @@ def measure_traffic(args):
     prof = shutil.which("rocprofv3")
     if not prof:
         return None
+    # (this run is itself being profiled: no profiler inside a profiler)
+    if any(("rocprof" in (os.environ.get(k) or "").lower()) for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY_CTOR")):
+        return None
     got = {}
     t0 = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -119,7 +122,10 @@ def measure_traffic(args):
             env = dict(os.environ, TMPDIR="/tmp")
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", "--steps", "2", "--warmup", "1"]
-            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            except OSError:
+                return None
             try:
                 p.wait(timeout=300)
             except subprocess.TimeoutExpired:

@@ -39,6 +39,11 @@ struct SplitParams {
     // k_split2: group (16 bar + 4 code(last) + code(second last)) of gcap entries each (unused ones: len 0)
     const SplitEntry *entries16;
     uint32_t gcap;
+    // k_split2 (round 3): group (64 bar + 16 code(last) + 4 code(second last) + code(third last)) of EIGHT compact entries
+    // {key, len | (slice & 0xFF) << 8 | master << 16} in 64 bytes (unused ones: len 0; a short entry sits in every group
+    // of its characters); an entry's characters are the first `len` of its master string, pool2[128 master ..]
+    const uint2 *entries8;
+    const uint8_t *pool2;
     int2 *out;
     unsigned long long *stats; // ST_ERR
     uint32_t dbg;              // timing-only ablations (results wrong when nonzero): 64 no site search, 128 no adapter search

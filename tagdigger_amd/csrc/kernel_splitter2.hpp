@@ -62,18 +62,20 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
     if (!hit) return make_int2(-1, 999);
     const uint32_t bar = meta >> 16;
     const uint32_t start = ((meta >> 6) & 63u) + p.cutlen;           // searchstart = len(barcode) + len(cutsite)
-    // The adapter entries this read could end with -- those of its barcode that end with its last two characters: a
-    // group of p.gcap entries found by address alone, so its first four are requested NOW and arrive under the
-    // search for the restriction sites.  (A second-last byte that is no base leaves the one-character entries,
-    // which every group of their character holds.)
+    // The adapter entries this read could end with -- those of its barcode that end with its last THREE characters: a
+    // group of eight compact entries (64 bytes) found by address alone, so it is requested NOW and arrives under the
+    // search for the restriction sites.  (A second- or third-last byte that is no base leaves the shorter entries,
+    // which every group of their characters holds; round 2 grouped by two characters: up to sixteen entries of 16 bytes,
+    // fetched four at a time, one dependent round trip after the other.)
     const uint32_t lastc = len ? (uint32_t)raw[e - 1] & 0xDFu : 0u;
     const uint32_t lcode = (lastc >> 1) & 3u;
     const bool tail_is_base = len != 0 && lastc == ((0x47544341u >> (8 * lcode)) & 0xFFu) && !(p.dbg & 128u);
     const uint32_t prevc = len >= 2u ? (uint32_t)raw[e - 2] & 0xDFu : 0x41u;
-    const uint4 *grp = reinterpret_cast<const uint4 *>(p.entries16) + (size_t)(16u * bar + 4u * lcode + ((prevc >> 1) & 3u)) * p.gcap;
+    const uint32_t thirdc = len >= 3u ? (uint32_t)raw[e - 3] & 0xDFu : 0x41u;
+    const uint4 *grp = reinterpret_cast<const uint4 *>(p.entries8 + (size_t)(64u * bar + 16u * lcode + 4u * ((prevc >> 1) & 3u) + ((thirdc >> 1) & 3u)) * 8u);
     uint4 ent[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) ent[u] = tail_is_base ? grp[u] : make_uint4(0u, 0u, 999u, 0u);      // {off, len, slice, key}
+    for (int u = 0; u < 4; u++) ent[u] = tail_is_base ? grp[u] : make_uint4(0u, 0u, 0u, 0u);      // two entries each: {key, meta}
 
     // ---- first full restriction site at or after `start` (str.find)
     uint32_t rs0 = 0xFFFFFFFFu, rs1 = 0xFFFFFFFFu;
@@ -153,31 +155,31 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
         __builtin_memcpy(&w, raw + e - n4, 4);                           // bytes e - n4 .. e - n4 + 3
         t4 = (w << (8u * (4u - n4))) & 0xDFDFDFDFu;                      // the last character in the top byte
     }
-    // Of the group's four entries in registers, a lane takes the FIRST one its last four characters agree with and compares
-    // the rest of it -- one round of pool loads for the whole wave; only a lane whose candidate fails looks at its next
-    // one (two entries of a group share their last four characters only where the adapter repeats itself).  (Round 2
-    // compared entry by entry: up to four pool round trips per pass, one behind the other -- 29 % of the kernel's time.)
+    // Of the group's eight entries in registers, a lane takes the FIRST one (the longest) its last four characters agree
+    // with and compares the rest of it -- one round of pool loads for the whole wave; only a lane whose candidate fails
+    // looks at its next one (two entries of a group share their last four characters only where the adapter repeats
+    // itself).  (Round 2 compared entry by entry: up to four pool round trips per pass, one behind the other.)
     int found = 999;
-    uint32_t tried = 0;                     // entries of the current four already looked at
-    uint32_t k = 0;
+    uint32_t tried = 0;                     // entries already looked at
+    const uint32_t ek[8] = {ent[0].x, ent[0].z, ent[1].x, ent[1].z, ent[2].x, ent[2].z, ent[3].x, ent[3].z};
+    const uint32_t em[8] = {ent[0].y, ent[0].w, ent[1].y, ent[1].w, ent[2].y, ent[2].w, ent[3].y, ent[3].w};
     for (bool more = true; more;) {
-        // the first entry not yet tried whose key agrees (entries with len 0 close a group: never a candidate)
-        uint4 E = make_uint4(0u, 0u, 999u, 0u);
-        uint32_t sel = 4u;
+        uint32_t key = 0, meta = 0, sel = 8u;
 #pragma unroll
-        for (int u = 3; u >= 0; u--) {
-            const uint32_t elen = ent[u].y;
+        for (int u = 7; u >= 0; u--) {
+            const uint32_t elen = em[u] & 0xFFu;
             const uint32_t kmask = elen >= 4u ? 0xFFFFFFFFu : elen == 0u ? 0u : 0xFFFFFFFFu << (8u * (4u - elen));
-            const bool ok = !((tried >> u) & 1u) && elen <= len && elen != 0 && ((t4 ^ ent[u].w) & kmask) == 0;
-            if (ok) { E = ent[u]; sel = (uint32_t)u; }
+            const bool ok = !((tried >> u) & 1u) && elen <= len && elen != 0 && ((t4 ^ ek[u]) & kmask) == 0;
+            if (ok) { key = ek[u]; meta = em[u]; sel = (uint32_t)u; }
         }
-        if (sel < 4u) {
+        (void)key;
+        if (sel < 8u) {
             tried |= 1u << sel;
-            const uint32_t elen = E.y;
+            const uint32_t elen = meta & 0xFFu;
             bool same = true;
             if (elen > 4u) {
-                const uint32_t rest = elen - 4u;                          // characters e - elen .. e - 4 against pool[off .. off + rest)
-                const uint8_t *a = p.pool + E.x, *r = raw + e - elen;
+                const uint32_t rest = elen - 4u;                          // characters e - elen .. e - 4 against the master's first `rest`
+                const uint8_t *a = p.pool2 + (size_t)(meta >> 16) * 128u, *r = raw + e - elen;
                 constexpr int NB = 10;                                    // (entries of up to 84 characters in one go; longer: the loop below)
                 unsigned long long y[NB];
 #pragma unroll
@@ -201,16 +203,9 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
                     if (((x & 0xDFDFDFDFDFDFDFDFull) ^ yy) & m) same = false;
                 }
             }
-            if (same) { found = (int)E.z; more = false; }
+            if (same) { found = (int)(int8_t)((meta >> 8) & 0xFFu); more = false; }
         } else {
-            // none of these four (left): the group's next four entries, if it has any
-            more = ent[3].y != 0 && k + 4 < p.gcap;
-            if (more) {
-                k += 4;
-                tried = 0;
-#pragma unroll
-                for (int u = 0; u < 4; u++) ent[u] = grp[k + u];
-            }
+            more = false;
         }
     }
     TD_LSTAMP(10);   // adapter search

@@ -192,6 +192,9 @@ struct td_handle {
     uint32_t sp_site_len[2] = {0, 0};
     DevBuf<uint32_t> d_sp_bblob, d_sp_ent_begin, d_sp_ent_group;
     DevBuf<tdk::SplitEntry> d_sp_entries16;
+    DevBuf<uint2> d_sp_e8;                    // k_split2: compact entries, 64 groups of eight per barcode
+    DevBuf<uint8_t> d_sp_pool2;               // ... and their master strings at a stride of 128 bytes
+    bool sp_compact = false;
     DevBuf<tdk::SplitEntry> d_sp_entries;
     DevBuf<uint8_t> d_sp_pool;
     DevBuf<uint4> d_fixlist;
@@ -642,7 +645,7 @@ void td_destroy(td_handle *h) {
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
     if (h->pin_cursor) (void)hipHostFree(h->pin_cursor);
-    h->d_win.release(); h->d_tilesums.release(); h->d_sp_entries16.release();
+    h->d_win.release(); h->d_tilesums.release(); h->d_sp_entries16.release(); h->d_sp_e8.release(); h->d_sp_pool2.release();
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
     h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release(); h->d_rowmap.release();
     for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -1757,7 +1760,7 @@ size_t lds_bytes_split2(const td_handle *h) {
     return (size_t)24 * 1024 + tdk::SPLIT2_HALO + 64 + (size_t)6 * tdk::FBLOCK * 2 + 256 + h->sp_bblob_bytes;
 }
 bool use_split2(const td_handle *h) {
-    return h->split_kernel == 2 && h->sp_sites_acgt && lds_bytes_split2(h) <= (size_t)40 * 1024;
+    return h->split_kernel == 2 && h->sp_sites_acgt && h->sp_compact && lds_bytes_split2(h) <= (size_t)40 * 1024;
 }
 
 int launch_split_prefix(td_handle *h, const void *d_fastq, uint64_t nbytes, hipStream_t s, bool counted = false) {
@@ -1792,6 +1795,7 @@ int launch_split(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     sp.site0 = h->sp_site[0]; sp.site1 = h->sp_site[1]; sp.site0_len = h->sp_site_len[0]; sp.site1_len = h->sp_site_len[1];
     sp.ent_begin = h->d_sp_ent_begin.p; sp.ent_group = h->d_sp_ent_group.p; sp.entries = h->d_sp_entries.p; sp.pool = h->d_sp_pool.p;
     sp.gcap = h->sp_gcap; sp.entries16 = h->d_sp_entries16.p;
+    sp.entries8 = h->d_sp_e8.p; sp.pool2 = h->d_sp_pool2.p;
     sp.out = d_out; sp.stats = h->d_stats.p; sp.dbg = (uint32_t)h->debug_ablate;
     if (two) {
         hipLaunchKernelGGL((tdk::k_split2<6>), dim3(g), dim3(tdk::FBLOCK), lds_bytes_split2(h), s, sp);
@@ -2146,6 +2150,57 @@ int td_set_splitter(td_handle *h, const char *const *barcodes, uint32_t nbar, co
         h->sp_gcap = (uint32_t)cap;
         rc = h->d_sp_entries16.ensure(std::max<size_t>(1, e16.size())); if (rc) return rc;
         HIPCHK(hipMemcpy(h->d_sp_entries16.p, e16.data(), e16.size() * sizeof(tdk::SplitEntry), hipMemcpyHostToDevice));
+    }
+    {   // k_split2's view (round 3): per barcode 64 groups by the codes of the LAST THREE characters (an entry shorter than
+        // that sits in every group of its characters), eight compact entries of 8 bytes per group -- ONE 64-byte fetch per
+        // read, issued as soon as its barcode is known.  An entry's characters are the first `len` of its master string
+        // (the interned pool string it points into), kept at a fixed stride so that the compact entry needs no offset.
+        // Entry sets that do not fit (a group of more than eight, strings beyond 128 characters, slices beyond a byte)
+        // leave sp_compact false: the splitter then runs k_split.
+        h->sp_compact = true;
+        std::unordered_map<uint32_t, uint32_t> master_of;            // pool offset -> master index
+        std::vector<uint8_t> pool2;
+        auto master = [&](uint32_t off, uint32_t len) -> uint32_t {
+            auto it = master_of.find(off);
+            if (it != master_of.end()) {
+                // (the longest entry of a master comes first -- entries are interned longest first --, but a later, longer
+                // use of the same offset would need more characters than were copied: copy up to 128 from the pool anyway)
+                return it->second;
+            }
+            const uint32_t idx = (uint32_t)master_of.size();
+            master_of.emplace(off, idx);
+            pool2.resize((size_t)(idx + 1) * 128 + 8, 0);
+            for (uint32_t q = 0; q < 128 && off + q < pool.size(); q++) pool2[(size_t)idx * 128 + q] = pool[off + q];
+            (void)len;
+            return idx;
+        };
+        std::vector<uint2> e8((size_t)nbar * 64 * 8, make_uint2(0u, 0u));
+        for (uint32_t b = 0; b < nbar && h->sp_compact; b++) {
+            const uint32_t lo = groups[(size_t)b * 4], hi = b + 1 < nbar ? groups[(size_t)(b + 1) * 4] : (uint32_t)ents.size();
+            for (uint32_t g = 0; g < 64 && h->sp_compact; g++) {
+                std::vector<tdk::SplitEntry> v;
+                for (uint32_t k = lo; k < hi; k++) {
+                    const tdk::SplitEntry &en = ents[k];
+                    if (en.len == 0) continue;
+                    const uint32_t c1 = ((en.key >> 24) >> 1) & 3u, c2 = ((en.key >> 16) >> 1) & 3u, c3 = ((en.key >> 8) >> 1) & 3u;
+                    if (c1 == (g >> 4) && (en.len < 2 || c2 == ((g >> 2) & 3u)) && (en.len < 3 || c3 == (g & 3u))) v.push_back(en);
+                }
+                std::stable_sort(v.begin(), v.end(), [](const tdk::SplitEntry &a, const tdk::SplitEntry &c) { return a.len > c.len; });
+                if (v.size() > 8) { h->sp_compact = false; break; }
+                for (size_t k = 0; k < v.size(); k++) {
+                    if (v[k].len > 128 || v[k].slice < -128 || v[k].slice > 127 || master_of.size() >= 65535) { h->sp_compact = false; break; }
+                    const uint32_t m = master(v[k].off, v[k].len);
+                    e8[((size_t)b * 64 + g) * 8 + k] = make_uint2(v[k].key, v[k].len | (((uint32_t)v[k].slice & 0xFFu) << 8) | (m << 16));
+                }
+            }
+        }
+        if (h->sp_compact) {
+            pool2.resize(pool2.size() + 128, 0);                     // (the compare reads eight bytes at a time)
+            rc = h->d_sp_e8.ensure(e8.size()); if (rc) return rc;
+            HIPCHK(hipMemcpy(h->d_sp_e8.p, e8.data(), e8.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            rc = h->d_sp_pool2.ensure(pool2.size()); if (rc) return rc;
+            HIPCHK(hipMemcpy(h->d_sp_pool2.p, pool2.data(), pool2.size(), hipMemcpyHostToDevice));
+        }
     }
     rc = h->d_sp_ent_group.ensure((size_t)nbar * 4); if (rc) return rc;
     HIPCHK(hipMemcpy(h->d_sp_ent_group.p, groups.data(), groups.size() * 4, hipMemcpyHostToDevice));

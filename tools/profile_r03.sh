@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-3 profile set (one gpurun call).  Results: gpurun_out/<tag>/ ; copy what is to be judged into profiles/<tag>/.
+#   1. the default bench under rocprofv3 --kernel-trace --stats (the kernel's average duration beside the bench's own
+#      HIP-event time; the bench's live counter passes are off inside a profiled run)
+#   2. the default bench by itself (with its live FETCH_SIZE / WRITE_SIZE passes): the line the driver would see
+#   3. SQ instruction mix and waits of the main pass (tools/sq2.sh)
+#   4. k_split2's duration (tools/split_kernels.sh)
+TAG=${1:-r03_final}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
+cd /tmp
+echo "[profile] kernel trace of the default bench"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --traffic off --tier-reads 0 --cpu-sample 0 --other-configs= > "$OUT/bench_traced.log" 2> "$OUT/bench_traced.err"
+f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv"
+echo "[profile] the default bench"
+python3 "$ROOT/bench.py" > "$OUT/bench_default.log" 2> "$OUT/bench_default.err"
+echo "[profile] SQ counters"
+cd "$ROOT" && tools/sq2.sh ${TAG}_sq > /dev/null 2>&1; cp gpurun_out/${TAG}_sq/sq.txt "$OUT/sq_k_fast2.txt"
+echo "[profile] k_split2"
+READS=40000000 tools/split_kernels.sh libtagdig.so > "$OUT/split_kernels.txt" 2>&1
+rm -rf "$OUT/stats"
+ls -la "$OUT"
