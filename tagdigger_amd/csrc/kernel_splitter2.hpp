@@ -82,7 +82,6 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
     if (start <= len && !(p.dbg & 64u)) {
         if (p.site0_len == 0) rs0 = start;                           // (an empty site is found at `start` itself)
         if (p.site1_len == 0) rs1 = start;
-        uint32_t H[4] = {0u, 0u, 0u, 0u};                            // per letter A C T G: bits 16-31 this piece, 0-15 the one before
         // SP[site][letter]: bit `back` set where the site's character `back` places before its last is that letter (uniform)
         uint32_t SP[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
@@ -95,39 +94,63 @@ __device__ __forceinline__ int2 split_line_lds(const SplitParams &p, const unsig
                 for (int c = 0; c < 4; c++) SP[which][c] |= code == (uint32_t)c ? 1u << back : 0u;
             }
         }
-        const uint32_t k0 = start >> 4;
-        uint4 ahead = lds_read16(src + 16u * k0);                   // (the next piece is requested before this one is searched: it
-        for (uint32_t k = k0; 16u * k < len && (rs0 == 0xFFFFFFFFu || rs1 == 0xFFFFFFFFu); k++) {   //  lies inside the staged window
-            uint4 v = ahead;                                        //  whether the line reaches it or not -- the halo is 512 bytes)
-            ahead = lds_read16(src + 16u * (k + 1u));
-            v.x &= 0xDFDFDFDFu; v.y &= 0xDFDFDFDFu; v.z &= 0xDFDFDFDFu; v.w &= 0xDFDFDFDFu;      // (a == A for the four letters)
-            // text positions of this piece that take part: start <= position < len
-            const uint32_t left = len - 16u * k, from = start > 16u * k ? start - 16u * k : 0u;
-            const uint32_t pm = (left >= 16u ? 0xFFFFu : (1u << left) - 1u) & (0xFFFFu << from);
-            const uint32_t m[4] = {eq_mask16_ascii(v, 0x41414141u, 0x7F7F7F7Fu), eq_mask16_ascii(v, 0x43434343u, 0x7F7F7F7Fu),
-                                   eq_mask16_ascii(v, 0x54545454u, 0x7F7F7F7Fu), eq_mask16_ascii(v, 0x47474747u, 0x7F7F7F7Fu)};
+        // Round 3: the letter masks of 128 text positions at a time (eight pieces, bit b of Hd[letter][b >> 5]), the
+        // positions outside [start, len) cleared once, then per site ONE pass over its characters: the masks shifted
+        // left by the character's distance from the site's end (v_alignbit across the four words) and ANDed -- what is
+        // left are the positions where the site ends.  (Round 2 matched piece by piece with a 16-bit history: seven
+        // rounds of LDS read -> masks -> per-character loops -> branches, each waiting for the one before; here the
+        // pieces' mask chains are independent of each other and the character loops run once per line.)
+        for (uint32_t kw = start >> 4; 16u * kw < len && (rs0 == 0xFFFFFFFFu || rs1 == 0xFFFFFFFFu); kw += 7u) {
+            uint32_t Hd[4][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
-            for (int c = 0; c < 4; c++) H[c] = (H[c] >> 16) | ((m[c] & pm) << 16);
+            for (int i = 0; i < 8; i++) {
+                const uint32_t k = kw + (uint32_t)i;
+                if (16u * k < len) {
+                    uint4 v = lds_read16(src + 16u * k);
+                    v.x &= 0xDFDFDFDFu; v.y &= 0xDFDFDFDFu; v.z &= 0xDFDFDFDFu; v.w &= 0xDFDFDFDFu;      // (a == A for the four letters)
+                    const uint32_t m[4] = {eq_mask16_ascii(v, 0x41414141u, 0x7F7F7F7Fu), eq_mask16_ascii(v, 0x43434343u, 0x7F7F7F7Fu),
+                                           eq_mask16_ascii(v, 0x54545454u, 0x7F7F7F7Fu), eq_mask16_ascii(v, 0x47474747u, 0x7F7F7F7Fu)};
+#pragma unroll
+                    for (int c = 0; c < 4; c++) Hd[c][i >> 1] |= m[c] << (16 * (i & 1));
+                }
+            }
+            // text positions that take part, relative to the window: start <= position < len
+            const uint32_t rel_lo = start > 16u * kw ? start - 16u * kw : 0u, rel_hi = len - 16u * kw;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                auto below = [&](uint32_t x) -> uint32_t {             // bits of word d below position x
+                    return x <= 32u * d ? 0u : x >= 32u * d + 32u ? 0xFFFFFFFFu : (1u << (x - 32u * d)) - 1u;
+                };
+                const uint32_t R = below(rel_hi) & ~below(rel_lo);
+#pragma unroll
+                for (int c = 0; c < 4; c++) Hd[c][d] &= R;
+            }
 #pragma unroll
             for (int which = 0; which < 2; which++) {
                 const uint32_t L = which ? p.site1_len : p.site0_len;
-                // a site ends at bit b of the current piece where, for each of its characters `back` places before its
-                // last, that letter's history has bit b - back: per letter, the places it takes in the site (uniform
-                // masks, made once per line below) -- a shift and an AND per character, no selects
-                uint32_t M = L ? 0xFFFF0000u : 0u;                                // (an empty site was settled above)
+                if (L == 0) continue;                                   // (an empty site was settled above)
+                uint32_t M[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     uint32_t places = SP[which][c];
-                    const uint32_t h = H[c];
                     while (places) {
                         const uint32_t back = (uint32_t)__builtin_ctz(places);
                         places &= places - 1u;
-                        M &= h << back;
+                        if (back == 0) {
+#pragma unroll
+                            for (int d = 0; d < 4; d++) M[d] &= Hd[c][d];
+                        } else {
+#pragma unroll
+                            for (int d = 3; d >= 0; d--)
+                                M[d] &= __builtin_amdgcn_alignbit(Hd[c][d], d ? Hd[c][d - 1] : 0u, 32u - back);
+                        }
                     }
                 }
-                const uint32_t ends = M >> 16;
-                if (ends) {
-                    const uint32_t at = 16u * k + (uint32_t)__builtin_ctz(ends) + 1u - L;     // where that site starts
+                uint32_t pos = 0xFFFFFFFFu;
+#pragma unroll
+                for (int d = 3; d >= 0; d--) pos = M[d] ? 32u * d + (uint32_t)__builtin_ctz(M[d]) : pos;
+                if (pos != 0xFFFFFFFFu) {
+                    const uint32_t at = 16u * kw + pos + 1u - L;     // where that site starts
                     if (which) { if (rs1 == 0xFFFFFFFFu) rs1 = at; } else { if (rs0 == 0xFFFFFFFFu) rs0 = at; }
                 }
             }

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 2 --warmup 1 --cpu-sample 0 --tier-reads 0 --oracle-sample 0 --no-check $*"
+ARGS="--steps 2 --warmup 1 --cpu-sample 0 --tier-reads 0 --oracle-sample 0 --no-check --other-configs= --traffic off $*"
 : > "$OUT/sq.txt"
 echo "# bench args: $ARGS" >> "$OUT/sq.txt"
 pass() {   # name, counters...
