@@ -18,5 +18,13 @@ echo "[profile] SQ counters"
 cd "$ROOT" && tools/sq2.sh ${TAG}_sq > /dev/null 2>&1; cp gpurun_out/${TAG}_sq/sq.txt "$OUT/sq_k_fast2.txt"
 echo "[profile] k_split2"
 READS=40000000 tools/split_kernels.sh libtagdig.so > "$OUT/split_kernels.txt" 2>&1
+echo "[profile] k_count (the exact in-flight kernel: tassel_tagcount, early maxreads, matrices of 4 GiB and more)"
+python3 "$ROOT/bench.py" --opt fastpath=0 --steps 3 --warmup 1 --cpu-sample 0 --tier-reads 0 --oracle-sample 0 --other-configs= --traffic off 2>/dev/null | python3 -c "
+import json,sys
+o=json.loads(sys.stdin.readline())
+print('k_count (fastpath=0): kernel_ms %.3f  frac %.3f  bit-exact %s' % (o['roofline']['kernel_ms'], o['roofline']['frac'], o['check']['bit_exact_vs_expected']))" > "$OUT/k_count.txt" 2>&1
+echo "[profile] read lengths, CRLF"
+python3 "$ROOT/tools/readlen_sweep.py" > "$OUT/readlen.txt" 2>&1
+python3 "$ROOT/tools/crlf_check.py" 8000000 > "$OUT/crlf.txt" 2>&1
 rm -rf "$OUT/stats"
 ls -la "$OUT"
