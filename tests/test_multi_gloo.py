@@ -364,3 +364,22 @@ def test_load_file_range_streams_through_two_pinned_pieces(tmp_path):
             eng.load_file_range(path, blob.size - 10, 100, dst.data_ptr())      # (beyond the file's end)
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_bgzf_inflate_range_rejects_what_is_not_a_member_start(tmp_path):
+    """td_bgzf_inflate_range: an offset in the middle of a member, and a destination too small, fail loudly."""
+    import tagdigger_amd
+    from tagdigger_amd._binding import TagdigError
+    gz, data, barcodes, tags = _bgzf_file(tmp_path, "mixed", 4096)
+    eng = tagdigger_amd.Engine(0)
+    try:
+        dst = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda:0")
+        assert eng.bgzf_inflate_range(gz, 0, os.path.getsize(gz), dst.data_ptr(), len(data)) == len(data)
+        assert bytes(dst[:len(data)].cpu().numpy()) == data
+        with pytest.raises(TagdigError):
+            eng.bgzf_inflate_range(gz, 5, os.path.getsize(gz), dst.data_ptr(), len(data))
+        with pytest.raises(TagdigError):
+            eng.bgzf_inflate_range(gz, 0, os.path.getsize(gz), dst.data_ptr(), len(data) - 1)
+    finally:
+        eng.close()

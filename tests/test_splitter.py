@@ -148,7 +148,10 @@ def synth_reads(rng, barcodes, cutsite, ad, n, first_line_shift=0):
         r = rng.random()
         if r < 0.01:                       # a read far longer than the window k_split2 stages behind a tile (its global-memory path)
             seq = seq[:len(seq) // 2] + "".join(rng.choice("AT") for _ in range(rng.randrange(400, 3000))) + seq[len(seq) // 2:]
-        elif r < 0.03:                     # blanks str.strip() takes off, and a read of a few bases
+        elif r < 0.025:                    # a read of a few hundred bases: the site search's second and third window of 128 positions
+            k = rng.randrange(0, len(seq) + 1)
+            seq = seq[:k] + "".join(rng.choice("AT") for _ in range(rng.randrange(90, 380))) + seq[k:]
+        elif r < 0.045:                    # blanks str.strip() takes off, and a read of a few bases
             seq = rng.choice([" ", "\t", "  "]) + seq[:rng.randrange(0, 12)] + rng.choice(["", " ", "\t "])
         recs.append("@r%d\n%s\n+\n%s\n" % (i, seq, "I" * len(seq)))
     return ("\n" * first_line_shift + "".join(recs)).encode("ascii")
@@ -313,3 +316,37 @@ def test_splitter_cpu_restatement_rate(capsys):
     assert stats[0] == cfg.nreads and sum(map(len, outs)) > 0
     with capsys.disabled():
         print(" [python restatement of barcodeSplitter: %.1f k reads/s] " % (cfg.nreads / dt / 1e3), end="")
+
+
+@pytest.mark.gpu
+def test_gpu_split_entries_that_do_not_fit_the_compact_form():
+    """An adapter of more than 128 characters (its beginnings do not fit k_split2's compact entries, whose characters
+    live in master strings of 128 bytes): the splitter must fall back to k_split whatever split_kernel says, with the
+    oracle's decisions; and a long-period repeat that fills a three-character group beyond eight entries."""
+    import tagdigger_amd
+    from tagdigger_amd import tagdigger_fun as tf
+    rng = random.Random(99)
+    long_tail = "".join(rng.choice("ACGT") for _ in range(150))
+    for ad in ([("CCG^G", long_tail), ("CTGCA^G", "[barcode]AGATCGGAAGAGC")],
+               [("CCG^G", "ACG" * 30), ("CTGCA^G", "[barcode]" + "ACG" * 25)]):
+        barcodes = ["ACGT", "GGTCA", "TTAGC"]
+        data = synth_reads(rng, barcodes, "TGCAG", ad, 1500)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ends = tf._adapter_ends(ad, barcodes)
+        eng = tagdigger_amd.Engine(0)
+        try:
+            eng.set_splitter(barcodes, "TGCAG", ad[0][0].replace("^", ""), ad[1][0].replace("^", ""), ends)
+            for kern in (2, 1):
+                eng.set_option("split_kernel", kern)
+                d = eng.dev_alloc(len(data))
+                try:
+                    eng.h2d(d, data)
+                    res, _ = eng.split_device(d, len(data))
+                    want = []
+                    po.barcode_splitter_bytes(data, barcodes, "TGCAG", ad, decisions=want)
+                    got = [(int(a), int(b)) for a, b in res[:len(want)]]
+                    assert got == [(b, 999 if b < 0 else c) for b, c in want], kern
+                finally:
+                    eng.dev_free(d)
+        finally:
+            eng.close()
