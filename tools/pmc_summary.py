@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Condense a tools/profile_round.sh run into profiles/<tag>/ and profiles/pmc_traffic.json.
+"""Condense a tools/profile_round.sh run into profiles/<tag>/ (bench.py measures roofline.traffic itself since round 3:
+its own rocprofv3 --pmc child runs; this script is for the per-kernel table of a manual profile).
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch. On gfx950 FETCH_SIZE tallies the 128-B
 requests of a wide coalesced stream at 64 B (MI355X_MICROARCH.md, "HBM"), so the read side is
@@ -70,10 +71,11 @@ def main():
         hbm = 2 * dom[2] + dom[3]
         summary["dominant_kernel"] = dom[0]
         summary["hbm_bytes_per_launch"] = hbm
-        summary["note"] = ("hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), mean over the full-size "
-                           "dispatches of the dominant kernel; see profiles/%s/pmc_calibration.txt for the split into "
-                           "stream / table probes / count atomics" % tag)
-        json.dump(summary, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+        summary["fabric_bytes_per_launch"] = hbm
+        summary["note"] = ("fabric_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), mean over the full-size "
+                           "dispatches of the dominant kernel: requests at the L2's memory side, Infinity-Cache hits included "
+                           "(an upper bound of the HBM bytes); the calibration of FETCH_SIZE on this access pattern is "
+                           "profiles/r01_final/pmc_calibration.txt")
     json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
     with open(os.path.join(dst, "pmc_per_kernel.csv"), "w") as f:
         f.write("kernel,dispatches,FETCH_SIZE_bytes_raw,fetch_bytes_x2,WRITE_SIZE_bytes\n")
