@@ -206,9 +206,22 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
-    if world > 1:
+    # TD_BENCH_FORCE_DIST=1: ONE rank goes through the collective path all the same -- backend nccl (RCCL) with a
+    # communicator of one: what a one-GPU box can show of the N > 1 code (init, the in-place int32 all-reduce of the
+    # bound matrix overlapped with the next pass, barrier); never a scaling measurement
+    dist_on = world > 1 or os.environ.get("TD_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "gloo" if rehearsal else "nccl"
+        if world == 1:
+            import socket
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -239,7 +252,7 @@ def main():
     # The matrix lives in torch tensors so that RCCL can reduce it in place.  With several GPUs there are
     # two: the all-reduce of one pass (the path's one exchange: an integer sum over xGMI) runs on RCCL's
     # stream while the next pass counts into the other matrix.
-    nmat = 2 if world > 1 else 1
+    nmat = 2 if dist_on else 1
     mats = [torch.zeros(len(cfg.barcodes) * len(cfg.tags), dtype=torch.int32, device=dev) for _ in range(nmat)]
     reducing = [None] * nmat
     counts = mats[0]
@@ -258,7 +271,7 @@ def main():
                 reducing[b].wait()
                 reducing[b] = None
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -281,7 +294,7 @@ def main():
             mats[b].zero_()
             eng.bind_counts(mats[b].data_ptr())
             eng.count_device(fastq.data_ptr(), nbytes, first_line=first_line, stream=stream)
-            if world > 1:
+            if dist_on:
                 reducing[b] = dist.all_reduce(mats[b], async_op=True)
             return mats[b]
 
@@ -344,7 +357,7 @@ def main():
         fixups = eng.debug_counters()[11]
         eng.set_option("timing", 0)
 
-        if world > 1:
+        if dist_on:
             t = torch.tensor([elapsed, kms], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, kms = float(t[0]), float(t[1])
@@ -379,7 +392,7 @@ def main():
     strong_run = None
     if world > 1 and args.scaling == "weak" and not args.pmc_child:
         strong_run = run_scaling("strong")                 # (the metric's literal reading: ONE library over the N GPUs)
-    allreduce_ms = allreduce_alone() if world > 1 else None
+    allreduce_ms = allreduce_alone() if dist_on else None
     R = main_run
     my_reads, nbytes, first_line, kms, ktimes = R["my_reads"], R["nbytes"], R["first_line"], R["kms"], R["ktimes"]
     step = R["step"]
@@ -426,7 +439,7 @@ def main():
             sys.stderr.flush()
         note("value")
         note("roofline")
-        if world > 1:
+        if dist_on:
             out["rccl_ranks"] = dist.get_world_size()
             out["collective_backend"] = backend + (" (RCCL over xGMI)" if backend == "nccl" else " (REHEARSAL on one GPU: not a measurement)")
             out["allreduce_ms"] = allreduce_ms
@@ -481,7 +494,7 @@ def main():
             out["tiers"] = tiers(eng, cfg, min(args.tier_reads, my_reads))
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -64,10 +64,11 @@ def test_default_workload_flag():
         assert not bench.is_default_workload(bench.parse_args(extra))
 
 
-def _run_bench(extra, timeout=900):
-    env = dict(os.environ, TD_BENCH_REHEARSAL="1")
-    env.pop("WORLD_SIZE", None)
-    env.pop("RANK", None)
+def _run_bench(extra, timeout=900, env_extra=None):
+    env = dict(os.environ)
+    env.update(env_extra if env_extra is not None else {"TD_BENCH_REHEARSAL": "1"})
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
     p = subprocess.run([sys.executable, BENCH] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
@@ -110,3 +111,17 @@ def test_bench_single_gpu_line_small():
     oc = out["other_configs"]
     assert oc["c2"]["bit_exact"] and oc["c2"]["barcodes"] == 96 and oc["c2"]["tags"] == 10000
     assert oc["c5"]["bit_exact"] and oc["c5"]["cutsite"] == "CWGC" and oc["c5"]["count_and_trim"]["ms"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_through_rccl():
+    """What a one-GPU box can show of the nccl path: TD_BENCH_FORCE_DIST=1 sends the single rank through
+    init_process_group("nccl") -- RCCL with a communicator of one --, the in-place int32 all-reduce of the bound matrix
+    overlapped with the next pass, the barriers and the stand-alone all-reduce timing.  (Several ranks need several GPUs:
+    RCCL refuses two ranks on one device; the two-rank runs above go over gloo.)"""
+    out = _run_bench(["--reads", "2000000", "--steps", "3", "--warmup", "1", "--oracle-sample", "200000", "--cpu-sample", "0",
+                      "--tier-reads", "0", "--traffic", "off", "--other-configs", ""], env_extra={"TD_BENCH_FORCE_DIST": "1"})
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1
+    assert out["collective_backend"].startswith("nccl")
+    assert out["allreduce_ms"] > 0 and out["allreduce_bytes"] == 384 * 100000 * 4
+    assert out["check"]["bit_exact_vs_expected"] and out["check"]["reduced_total_equals_sum_of_shard_hits"]
