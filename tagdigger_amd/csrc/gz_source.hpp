@@ -143,6 +143,20 @@ struct GzSource {
         map = (uint8_t *)base; map_len = total; bsize = n;
         return true;
     }
+    // Device mode of the chunk-parallel decoder (par_inflate.hpp): only for what it takes -- one ordinary gzip stream of
+    // 8 MiB and more, several threads; false: open() the file the usual way.
+    bool open_dev(const char *path, const ParInflate::Allocator *al) {
+        const char *env = getenv("TAGDIG_INFLATE_THREADS");
+        const int want = env ? atoi(env) : (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+        const char *par = getenv("TAGDIG_PAR_INFLATE");
+        if (want <= 1 || getenv("TAGDIG_ZLIB") || (par && atoi(par) <= 0) || !map_only(path)) return false;
+        uint32_t bs = 0, hs = 0;
+        if (bgzf_header(map, bsize, &bs, &hs) || (!par && bsize < ((size_t)8 << 20))) { close(); return false; }
+        const char *cb = getenv("TAGDIG_INFLATE_CHUNK");
+        pi.dev_open(map, bsize, want, cb ? (size_t)atol(cb) : (size_t)1 << 20, al);
+        use_pi = true;
+        return true;
+    }
     bool map_file(const char *path, int want_threads) {
         if (!map_only(path)) return false;
         const size_t n = bsize;

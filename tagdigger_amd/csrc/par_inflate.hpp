@@ -45,11 +45,14 @@ namespace tdhost {
 
 class ParInflate {
   public:
+    // Device mode (dev_open): the chunks' buffers come from the caller's allocator -- pinned host memory, so that the
+    // symbols can go to the GPU by DMA where the decoder left them -- instead of anonymous mappings.
+    struct Allocator { void *(*alloc)(size_t bytes); void (*release)(void *p, size_t bytes); };
     static constexpr size_t PAD = FastInflate::PAD;          // readable bytes the caller guarantees behind the input
     // batches run, chunks on the chains, chunks decoded for nothing, block-start guesses rejected; seconds of
     // the producer in step 1 / steps 2 + 4 / step 3 and waiting for a free output buffer, of all threads in steps 1 / 2 / 4
     struct Stats {
-        uint64_t batches = 0, chunks = 0, dropped = 0, rejected = 0, out_bytes = 0;
+        uint64_t batches = 0, chunks = 0, dropped = 0, rejected = 0, out_bytes = 0, as_bytes = 0;
         double t_search = 0, t_decode = 0, t_chain = 0, t_resolve = 0, t_wait = 0, t_find = 0, t_busy = 0;
     } stats;
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -83,10 +86,10 @@ class ParInflate {
             cv_.notify_all();
             producer_.join();
             if (getenv("TAGDIG_INFLATE_STATS"))
-                fprintf(stderr, "par_inflate: %d threads, %zu KiB chunks: %lu batches, %lu chunks (+%lu dropped), %lu guesses rejected, %.1f MB out; "
+                fprintf(stderr, "par_inflate: %d threads, %zu KiB chunks: %lu batches, %lu chunks (+%lu dropped), %lu guesses rejected, %.1f MB out (%.1f MB decoded as bytes); "
                         "producer: search %.3f s, decode + markers %.3f s, chain %.3f s, waiting for the reader %.3f s; threads: search %.3f s, decode %.3f s, markers + CRC %.3f s\n",
                         threads_, chunk_ >> 10, (unsigned long)stats.batches, (unsigned long)stats.chunks, (unsigned long)stats.dropped,
-                        (unsigned long)stats.rejected, stats.out_bytes / 1e6, stats.t_search, stats.t_decode, stats.t_chain, stats.t_wait,
+                        (unsigned long)stats.rejected, stats.out_bytes / 1e6, stats.as_bytes / 1e6, stats.t_search, stats.t_decode, stats.t_chain, stats.t_wait,
                         stats.t_find, stats.t_busy, stats.t_resolve);
         }
     }
@@ -135,6 +138,68 @@ class ParInflate {
         return (long)done;
     }
 
+    // ---------------------------------------------------------------- device mode
+    // Steps 1-3 as above; step 4 -- markers into bytes, the CRC-32 -- is the CALLER's (on the GPU: tagdig.hip
+    // count_gzip_dev).  A batch that has been decoded and chained is handed over as pieces of symbols (or, for the
+    // batch's first chunk, bytes) with the 32 KiB window each chunk's markers point into; the caller uploads them,
+    // calls dev_release() as soon as the buffers may be decoded into again, and dev_check() with the pieces' CRC-32s.
+    struct DevPiece {
+        const void *src;          // len symbols (uint16_t), or len bytes when `narrow`
+        size_t len;
+        bool narrow;
+        const uint8_t *window;    // 32 KiB: marker 0x8000 | i is window[i]
+        uint32_t min_idx;         // a marker below it points before the member's start: the stream is invalid
+        size_t dest_off;          // where the piece's bytes go in the batch's output
+    };
+    struct DevBatch {
+        std::vector<DevPiece> pieces;
+        size_t total = 0;
+        bool member_done = false; uint32_t want_crc = 0;
+        bool failed = false, last = false;
+        int state = 0;            // 0 free (the producer may decode into its chunk set), 1 ready for the caller, 2 uploaded
+    };
+    void dev_open(const uint8_t *data, size_t n, int threads, size_t chunk_bytes, const Allocator *al) {
+        open(data, n, threads, chunk_bytes);
+        device_ = true; al_ = al;
+        for (auto &set : sets_)
+            for (int k = 0; k < max_chunks_; k++) { set[k].wide.al = al; set[k].narrow.al = al; }
+        for (DevBatch &b : dev_) { b.state = 0; b.pieces.clear(); }
+        dev_rd_ = 0; dev_done_ = false;
+    }
+    // the next batch (blocks until the producer has one); nullptr when the stream is through or has failed (error())
+    const DevBatch *dev_next() {
+        if (dev_done_) return nullptr;
+        if (!producer_.joinable()) producer_ = std::thread([this]() { produce_device(); });
+        DevBatch &b = dev_[dev_rd_];
+        {
+            std::unique_lock<std::mutex> g(mu_);
+            cv_.wait(g, [&]() { return b.state == 1; });
+        }
+        if (b.failed && b.pieces.empty()) { dev_done_ = true; return nullptr; }
+        return &b;
+    }
+    // the batch dev_next() returned has been read out of the decoder's buffers
+    void dev_release() {
+        DevBatch &b = dev_[dev_rd_];
+        cur_last_ = b.last || b.failed;
+        { std::lock_guard<std::mutex> g(mu_); b.state = 0; }
+        cv_.notify_all();
+        dev_rd_ ^= 1;
+        if (cur_last_) dev_done_ = true;
+    }
+    // the CRC-32s of the batch's pieces, in order (a copy of what dev_next() returned must be kept by the caller:
+    // the batch itself may be reused after dev_release()); false: a member fails its check
+    bool dev_check(const std::vector<std::pair<uint32_t, size_t>> &crc_len, bool member_done, uint32_t want_crc) {
+        for (const auto &cl : crc_len) crc_run_ = FI::crc32_join(crc_run_, cl.first, cl.second);
+        if (member_done) {
+            const bool ok = crc_run_ == want_crc;
+            crc_run_ = 0;
+            if (!ok) { err_ = "gzip member fails its CRC-32 check"; return false; }
+        }
+        return true;
+    }
+    bool dev_failed() const { return failed_; }
+
   private:
     using FI = FastInflate;
     static constexpr uint32_t WIN = 32768;
@@ -143,11 +208,23 @@ class ParInflate {
     template <typename T>
     struct Buf {                                              // uninitialised storage that can grow: its own mapping,
         T *p = nullptr; size_t cap = 0;                       // on huge pages where the system hands them out on request
-        ~Buf() { if (p) munmap(p, bytes(cap)); }              // (a page fault per 4 KiB of these buffers is most of a short run)
+        const Allocator *al = nullptr;                        // (or the caller's allocator: growth = new block, copy, release)
+        ~Buf() { drop(); }                                    // (a page fault per 4 KiB of these buffers is most of a short run)
+        void drop() {
+            if (p) { if (al) al->release(p, bytes(cap)); else munmap(p, bytes(cap)); }
+            p = nullptr; cap = 0;
+        }
         static size_t bytes(size_t n) { return (n * sizeof(T) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); }
         void reserve(size_t n) {
             if (n <= cap) return;
             const size_t want = bytes(n);
+            if (al) {
+                void *q = al->alloc(want);
+                if (!q) abort();
+                if (p) { memcpy(q, p, cap * sizeof(T)); al->release(p, bytes(cap)); }
+                p = (T *)q; cap = want / sizeof(T);
+                return;
+            }
             void *q = p ? mremap(p, bytes(cap), want, MREMAP_MAYMOVE)
                         : mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
             if (q == MAP_FAILED) abort();
@@ -188,7 +265,7 @@ class ParInflate {
         uint8_t window[WIN];                         // the 32 KiB of output before it
         uint64_t member_before = 0;                  // bytes of the current member before it
         size_t dest_off = 0;                         // where its bytes go in the batch's output
-        bool is_narrow = false;
+        size_t wide_len = 0;                         // the first wide_len symbols of the output lie in `wide`, the rest as bytes in `narrow`
         double t_begin = 0, t_end = 0;               // (step 2, for TAGDIG_INFLATE_STATS=2)
     };
 
@@ -225,6 +302,66 @@ class ParInflate {
         bool failed = false, last = false;                 // the stream is bad / ends behind this batch
     } pend_;
 
+    bool device_ = false, dev_done_ = false, cur_last_ = false;
+    const Allocator *al_ = nullptr;
+    DevBatch dev_[2];
+    int dev_rd_ = 0;
+
+    // the producer of device mode: batch b uses chunk set b & 1 -- as soon as the caller has read batch b - 2 out of it
+    void produce_device() {
+        for (int b = 0;; b++) {
+            DevBatch &d = dev_[b & 1];
+            {
+                const double tw = now();
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&]() { return d.state == 0 || stop_; });
+                if (stop_) return;
+                stats.t_wait += now() - tw;
+            }
+            d.pieces.clear(); d.total = 0; d.member_done = false; d.failed = false; d.last = false;
+            if (failed_ || end_) {                                  // (an empty or bad stream, or nothing left)
+                d.failed = failed_; d.last = true;
+                { std::lock_guard<std::mutex> g(mu_); d.state = 1; }
+                cv_.notify_all();
+                return;
+            }
+            const double t0 = now();
+            chunks_ = sets_[b & 1].get();
+            territories();
+            parallel(nch_ - 1, [this](int k) { find_start(k + 1); });
+            for (int k = nch_ - 1; k >= 0; k--)
+                chunks_[k].target = k == nch_ - 1 ? batch_end_ : (chunks_[k + 1].start != NONE ? chunks_[k + 1].start : chunks_[k + 1].target);
+            const double td = now();
+            stats.t_search += td - t0;
+            parallel(nch_, [this](int i) { decode_chunk(i); });
+            const double t1 = now();
+            stats.t_decode += t1 - td;
+            stats.batches++;
+            chain(slot_[b & 1]);
+            stats.t_chain += now() - t1;
+            // what chain() left in pend_ becomes the caller's batch
+            for (const Piece &pc : pend_.pieces) {
+                Chunk &c = *pc.c;
+                const uint64_t before = c.member_before + pc.off;
+                DevPiece dp;
+                dp.narrow = pc.off >= c.wide_len;
+                dp.src = dp.narrow ? (const void *)(c.narrow.p + WIN + pc.off - c.wide_len) : (const void *)(c.wide.p + WIN + pc.off);
+                dp.len = pc.len; dp.window = c.window;
+                dp.min_idx = WIN - (uint32_t)std::min<uint64_t>(WIN, before);
+                dp.dest_off = c.dest_off + pc.off;
+                d.pieces.push_back(dp);
+            }
+            d.total = pend_.total; d.member_done = pend_.member_done; d.want_crc = pend_.want_crc;
+            d.failed = pend_.failed; d.last = pend_.last;
+            stats.out_bytes += pend_.total;
+            pend_.valid = false;
+            const bool fin = d.failed || d.last;
+            { std::lock_guard<std::mutex> g(mu_); d.state = 1; }
+            cv_.notify_all();
+            if (fin) return;
+        }
+    }
+
     void produce() {
         for (int b = 0;; b++) {
             const bool more = !failed_ && !end_;
@@ -260,8 +397,7 @@ class ParInflate {
             const int ndec = nch_, npieces = pend_.valid ? (int)pend_.pieces.size() : 0;
             parallel(ndec + npieces, [this, ndec](int i) {
                 if (i >= ndec) resolve_piece(pend_.pieces[(size_t)(i - ndec)]);
-                else if (i == 0) decode_chunk<uint8_t>(0);
-                else decode_chunk<uint16_t>(i);
+                else decode_chunk(i);
             });
             const double t1 = now();
             stats.t_decode += t1 - td;
@@ -311,7 +447,7 @@ class ParInflate {
         const double t0 = now();
         Chunk &c = *pc.c;
         uint8_t *dst = pend_.slot->b.p + c.dest_off + pc.off;
-        if (c.is_narrow) memcpy(dst, c.narrow.p + WIN + pc.off, pc.len);
+        if (pc.off >= c.wide_len) memcpy(dst, c.narrow.p + WIN + pc.off - c.wide_len, pc.len);
         else {
             const uint64_t before = c.member_before + pc.off;
             pc.bad = !resolve(c.wide.p + WIN + pc.off, pc.len, c.window, dst, WIN - (uint32_t)std::min<uint64_t>(WIN, before));
@@ -434,8 +570,6 @@ class ParInflate {
         }
     };
 
-    template <typename T> static Buf<T> &buffer(Chunk &c);
-
     // ---- one Huffman block into out (growing the buffer as needed).  0: ended on its end-of-block code
     template <typename T>
     int huff_block(Bits &b, const Tables &t, Buf<T> &buf, T *&out, size_t valid_back, size_t limit, const char *&err) const {
@@ -546,45 +680,73 @@ class ParInflate {
         stats.rejected += rejected; stats.t_find += now() - t0;
     }
 
-    // ---- step 2: chunk k from c.resume up to the first block boundary at or past c.target
+    // ---- step 2: chunk k from c.resume up to the first block boundary at or past c.target.  A chunk decoded in symbols
+    // goes over to plain bytes at the first block boundary where its last 32 KiB hold no marker (nothing behind can
+    // reach one any more): the byte decoder is faster and its output needs no step 4 beyond a copy
     template <typename T>
-    void decode_chunk(int k) {
-        Chunk &c = chunks_[k];
-        if (c.start == NONE) return;
-        const double t0 = now();
-        if (!c.tables) c.tables.reset(new Tables);
-        Tables &t = *c.tables;
-        Buf<T> &buf = buffer<T>(c);
-        if (k == 0) {
-            buf.reserve(WIN + chunk_ * 8 + 4096);
-            memcpy(buf.p, window_, WIN);
-            c.valid_back = (size_t)std::min<uint64_t>(WIN, member_out_);
-        }
-        Bits b;
-        b.seek(data_, c.resume);
-        T *out = buf.p + WIN + c.out_len;
+    int blocks(Chunk &c, Bits &b, Tables &t, Buf<T> &buf, T *&out, size_t valid_back, bool first, bool may_switch) {   // 1: go over to bytes
         const char *err = "";
-        for (bool first = k == 0;; first = false) {
+        size_t scanned = 0, clean_from = 0;                          // (symbols of the output looked at for markers; none in [clean_from, scanned))
+        for (;; first = false) {
             const uint64_t here = b.bitpos(data_);
-            if (!first && (here >= c.target || (size_t)(out - buf.p) - WIN > cap_)) { c.stop = here; break; }
+            const size_t n = (size_t)(out - buf.p) - WIN;
+            if (!first && (here >= c.target || c.wide_len + n > cap_)) { c.stop = here; return 0; }
+            if (may_switch && sizeof(T) == 2 && n >= WIN) {
+                const uint16_t *sy = (const uint16_t *)buf.p + WIN;
+                size_t i = scanned;
+                for (; i + 4 <= n; i += 4) { uint64_t v; memcpy(&v, sy + i, 8); if (v & 0x8000800080008000ull) clean_from = i + 4; }
+                for (; i < n; i++) if (sy[i] & 0x8000u) clean_from = i + 1;
+                scanned = n;
+                if (n - clean_from >= WIN) return 1;
+            }
             bool final = false; uint32_t slen = 0;
             const int h = block_header(b, t, false, final, slen, err);
-            if (h == H_BAD) { c.failed = true; c.err = err; c.stop = here; break; }
+            if (h == H_BAD) { c.failed = true; c.err = err; c.stop = here; return 0; }
             if (h == H_STORED) {
                 const uint8_t *s = b.in - (b.cnt >> 3);
-                if (s + slen > data_ + n_) { c.failed = true; c.err = "truncated stored block"; c.stop = here; break; }
+                if (s + slen > data_ + n_) { c.failed = true; c.err = "truncated stored block"; c.stop = here; return 0; }
                 const size_t off = (size_t)(out - buf.p);
                 buf.reserve(off + slen + 1024);
                 out = buf.p + off;
                 for (uint32_t i = 0; i < slen; i++) out[i] = (T)s[i];
                 out += slen;
                 b.in = s + slen; b.buf = 0; b.cnt = 0;
-            } else if (huff_block<T>(b, t, buf, out, c.valid_back, ~(size_t)0, err) != 0) {
-                c.failed = true; c.err = err; c.stop = here; break;
+            } else if (huff_block<T>(b, t, buf, out, valid_back, ~(size_t)0, err) != 0) {
+                c.failed = true; c.err = err; c.stop = here; return 0;
             }
-            if (final) { c.member_done = true; c.stop = b.bitpos(data_); break; }
+            if (final) { c.member_done = true; c.stop = b.bitpos(data_); return 0; }
         }
-        c.out_len = (size_t)(out - buf.p) - WIN;
+    }
+    void decode_chunk(int k) {
+        Chunk &c = chunks_[k];
+        if (c.start == NONE) return;
+        const double t0 = now();
+        if (!c.tables) c.tables.reset(new Tables);
+        Tables &t = *c.tables;
+        Bits b;
+        b.seek(data_, c.resume);
+        c.wide_len = 0;
+        if (k == 0) {                                                // (the window is known: bytes from the start)
+            c.narrow.reserve(WIN + chunk_ * 8 + 4096);
+            memcpy(c.narrow.p, window_, WIN);
+            c.valid_back = (size_t)std::min<uint64_t>(WIN, member_out_);
+            uint8_t *out = c.narrow.p + WIN;
+            blocks<uint8_t>(c, b, t, c.narrow, out, c.valid_back, true, false);
+            c.out_len = (size_t)(out - c.narrow.p) - WIN;
+        } else {
+            uint16_t *out = c.wide.p + WIN + c.out_len;
+            static const bool no_switch = getenv("TAGDIG_INFLATE_NO_BYTES") != nullptr;
+            const int r = blocks<uint16_t>(c, b, t, c.wide, out, c.valid_back, false, !no_switch);
+            c.wide_len = c.out_len = (size_t)(out - c.wide.p) - WIN;
+            if (r == 1) {
+                c.narrow.reserve(WIN + chunk_ * 8 + 4096);
+                const uint16_t *tail = c.wide.p + c.wide_len;          // (= the last WIN symbols: WIN in front of the output)
+                for (uint32_t i = 0; i < WIN; i++) c.narrow.p[i] = (uint8_t)tail[i];
+                uint8_t *o8 = c.narrow.p + WIN;
+                blocks<uint8_t>(c, b, t, c.narrow, o8, WIN, false, false);
+                c.out_len = c.wide_len + ((size_t)(o8 - c.narrow.p) - WIN);
+            }
+        }
         c.t_begin = t0; c.t_end = now();
         std::lock_guard<std::mutex> g(mu_);
         stats.t_busy += c.t_end - t0;
@@ -654,7 +816,7 @@ class ParInflate {
             c.search_to = (uint64_t)std::min(lo + chunk_, n_) * 8;
             c.start = k == 0 ? pos_ : NONE; c.resume = pos_;
             c.stop = 0; c.member_done = false; c.failed = false; c.err = ""; c.out_len = 0;
-            c.is_narrow = k == 0;
+            c.wide_len = 0;
             nch_++;
         }
         batch_end_ = chunks_[nch_ - 1].search_to;
@@ -676,11 +838,12 @@ class ParInflate {
             chain[nchain++] = &c;
             last = k;
             c.member_before = member_out_ + total;
-            if (k > 0) {
-                memcpy(c.window, window_, WIN);
+            if (k > 0) memcpy(c.window, window_, WIN);
+            if (c.wide_len == c.out_len && k > 0) {
                 for (uint32_t i = 0; i < WIN; i++) { const uint32_t v = c.wide.p[c.out_len + i]; window_[i] = v & 0x8000u ? c.window[v & 0x7FFFu] : (uint8_t)v; }
             } else {
-                memcpy(window_, c.narrow.p + c.out_len, WIN);
+                // (a chunk that went over to bytes took its last 32 KiB along, in front of them)
+                memcpy(window_, c.narrow.p + (c.out_len - c.wide_len), WIN);
             }
             total += c.out_len;
             pos_ = c.stop;
@@ -691,6 +854,7 @@ class ParInflate {
             k = j;
         }
         stats.chunks += (uint64_t)nchain;
+        for (int i = 0; i < nchain; i++) stats.as_bytes += chain[i]->out_len - chain[i]->wide_len;
         // chunks behind the end of the chain were decoded for nothing (a false start, or a member ended
         // inside the batch): try fewer next time, more again when all were used
         const bool whole = nchain > 0 && (pos_ >= batch_end_ || last == nch_ - 1);
@@ -705,7 +869,10 @@ class ParInflate {
         for (int i = 0; i < nchain; i++) {
             Chunk &c = *chain[i];
             c.dest_off = off;
-            for (size_t at = 0; at < c.out_len; at += PIECE) pend_.pieces.push_back({&c, at, std::min(PIECE, c.out_len - at), 0, false});
+            // (tasks of step 4 on the host; for the device, whose copies want to be large, a chunk's symbols and its bytes whole)
+            const size_t piece = device_ ? ~(size_t)0 >> 1 : PIECE;
+            for (size_t at = 0; at < c.wide_len; at += std::min(piece, c.wide_len - at)) pend_.pieces.push_back({&c, at, std::min(piece, c.wide_len - at), 0, false});
+            for (size_t at = c.wide_len; at < c.out_len; at += std::min(piece, c.out_len - at)) pend_.pieces.push_back({&c, at, std::min(piece, c.out_len - at), 0, false});
             off += c.out_len;
         }
         pend_.member_done = !pend_.failed && nchain && chunks_[last].member_done;
@@ -726,7 +893,5 @@ class ParInflate {
     static constexpr size_t PIECE = (size_t)1 << 19;          // symbols per task of step 4
 };
 
-template <> inline ParInflate::Buf<uint8_t> &ParInflate::buffer<uint8_t>(Chunk &c) { return c.narrow; }
-template <> inline ParInflate::Buf<uint16_t> &ParInflate::buffer<uint16_t>(Chunk &c) { return c.wide; }
 
 }  // namespace tdhost

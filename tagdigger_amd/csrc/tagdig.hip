@@ -28,6 +28,7 @@
 #include "kernel_splitter2.hpp"
 #include "gz_source.hpp"
 #include "gpu_inflate.hpp"
+#include "gz_resolve.hpp"
 
 namespace {
 
@@ -204,6 +205,12 @@ struct td_handle {
                    uint32_t *d_status = nullptr, *pin_status = nullptr; uint8_t *pin_tail = nullptr; hipEvent_t copied = nullptr; } zslot[2];
     struct ZPiece { uint8_t *pin = nullptr; hipEvent_t sent = nullptr; bool busy = false; } zpiece[2];     // pinned staging of the compressed bytes
     ZPiece ldpiece[2];                        // td_load_file_range's pinned staging
+    // ordinary gzip: symbols decoded by the host, resolved on the GPU (count_gzip_dev): two batches in flight
+    struct GSlot { DevBuf<uint8_t> d_sym, d_out, d_win; DevBuf<tdgz::Block> d_blk; DevBuf<uint32_t> d_crc;
+                   tdgz::Block *pin_blk = nullptr; uint32_t *pin_crc = nullptr; uint8_t *pin_tail = nullptr; size_t pin_cap = 0;
+                   hipEvent_t copied = nullptr; } gslot[2];
+    DevBuf<uint32_t> d_gzflag;
+    int gpu_resolve = 1;                      // ordinary gzip of 8 MiB and more: markers -> bytes and CRC-32 on the GPU (0: all on the host)
     uint8_t *d_zscratch = nullptr; uint32_t *d_crctab = nullptr;
     uint32_t zcap_members = 0; size_t zcap_in = 0;   // what the batch buffers above were allocated for
     int gpu_inflate = 1;                      // BGZF input: inflate on the GPU (0: member-parallel on the host)
@@ -658,6 +665,14 @@ void td_destroy(td_handle *h) {
     }
     release_bgzf_buffers(h);
     for (auto &lp : h->ldpiece) { if (lp.pin) (void)hipHostFree(lp.pin); if (lp.sent) (void)hipEventDestroy(lp.sent); }
+    for (auto &g : h->gslot) {
+        g.d_sym.release(); g.d_out.release(); g.d_win.release(); g.d_blk.release(); g.d_crc.release();
+        if (g.pin_blk) (void)hipHostFree(g.pin_blk);
+        if (g.pin_crc) (void)hipHostFree(g.pin_crc);
+        if (g.pin_tail) (void)hipHostFree(g.pin_tail);
+        if (g.copied) (void)hipEventDestroy(g.copied);
+    }
+    h->d_gzflag.release();
     if (h->d_crctab) (void)hipFree(h->d_crctab);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->work_stream) (void)hipStreamDestroy(h->work_stream);
@@ -1146,6 +1161,174 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
 }
 }  // namespace
 
+// ---- ordinary (one-stream) gzip: steps 1-3 of the chunk-parallel decoder on the host threads (block-start search,
+// symbolic decode, chain + windows: par_inflate.hpp), step 4 -- markers into bytes, CRC-32 -- on the GPU (gz_resolve.hpp).
+// The symbols are decoded straight into pinned memory (the decoder's chunk buffers come from the pool below) and go to
+// the device by DMA: no resolve pass, no CRC pass and no copy into a staging buffer on the 16 host threads that bound
+// this tier.  *not_applicable: the file is not for this path (BGZF, small, zlib fallback requested): nothing was read.
+namespace {
+// pinned blocks for the decoder's chunk buffers, kept between files (pinning costs ~0.3 ms per MiB)
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> free_blocks;
+    size_t held = 0;
+    static constexpr size_t KEEP = (size_t)3 << 30;
+    void *alloc(size_t n) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < free_blocks.size(); i++)
+                if (free_blocks[i].second >= n && free_blocks[i].second <= 2 * n) {
+                    void *p = free_blocks[i].first;
+                    held -= free_blocks[i].second;
+                    free_blocks.erase(free_blocks.begin() + (long)i);
+                    return p;
+                }
+        }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, n, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return p;
+    }
+    void release(void *p, size_t n) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            // (blocks come back with the size they were asked for: the decoder rounds to 2 MiB both times)
+            if (held + n <= KEEP) { free_blocks.emplace_back(p, n); held += n; return; }
+        }
+        (void)hipHostFree(p);
+    }
+};
+PinnedPool g_pinned;
+const tdhost::ParInflate::Allocator g_pinned_alloc = {
+    [](size_t n) -> void * { return g_pinned.alloc(n); },
+    [](void *p, size_t n) { g_pinned.release(p, n); }};
+
+int count_gzip_dev(td_handle *h, const char *path, uint64_t max_reads, int weights, bool *not_applicable) {
+    using PI = tdhost::ParInflate;
+    *not_applicable = false;
+    tdhost::GzSource src;
+    if (!src.open_dev(path, &g_pinned_alloc)) { *not_applicable = true; return TD_OK; }
+    int rc = h->d_gzflag.ensure(4); if (rc) return rc;
+    HIPCHK(hipMemsetAsync(h->d_gzflag.p, 0, 16, h->work_stream));
+    if (!h->d_crctab) { bool ok = true; rc = ensure_bgzf_buffers(h, 0, 0, &ok); if (rc) return rc; }      // (the CRC tables)
+    HIPCHK(hipMemsetAsync(h->d_cursor.p, 0, 16, h->work_stream));
+    if (!h->pin_cursor) HIPCHK(hipHostMalloc((void **)&h->pin_cursor, 16, hipHostMallocDefault));
+    h->pin_cursor[0] = 0;
+    for (auto &g : h->gslot) if (!g.copied) HIPCHK(hipEventCreateWithFlags(&g.copied, hipEventDisableTiming));
+    struct Batch {
+        bool valid = false, last = false, member_done = false;
+        uint32_t want_crc = 0, nblk = 0;
+        size_t total = 0;
+        std::vector<std::pair<uint32_t, size_t>> crc_len;       // filled from pin_crc after the batch has been resolved
+    };
+    const uint64_t stop_line = max_reads >= (1ull << 60) ? ~0ull : 4 * (std::max<uint64_t>(1, max_reads) - 1) + 2;
+    size_t carry = 0;                                           // bytes of an unfinished line at the front of the current slot's output
+    // the next batch from the decoder: block table, symbols and windows on their way to the device; the decoder's buffers
+    // are handed back as soon as the copies have been made
+    auto prepare = [&](int slot, Batch &b) -> int {
+        td_handle::GSlot &g = h->gslot[slot];
+        b = Batch();
+        const PI::DevBatch *db = src.pi.dev_next();
+        if (!db) {
+            if (src.pi.dev_failed()) return fail(TD_E_IO, std::string("gzip: ") + src.pi.error());
+            return TD_OK;                                       // (the stream is through)
+        }
+        if (db->failed) { src.pi.dev_release(); return fail(TD_E_IO, std::string("gzip: ") + src.pi.error()); }
+        // blocks of 64 Ki symbols; the windows of the batch's chunks (pieces of one chunk share theirs)
+        size_t nblk = 0, sym_bytes = 0;
+        for (const PI::DevPiece &pc : db->pieces) { nblk += (pc.len + tdgz::BLOCK_SYMS - 1) / tdgz::BLOCK_SYMS; sym_bytes += (pc.len * (pc.narrow ? 1 : 2) + 15) & ~(size_t)15; }
+        std::vector<const uint8_t *> wins;
+        if (nblk > g.pin_cap) {
+            if (g.pin_blk) (void)hipHostFree(g.pin_blk);
+            if (g.pin_crc) (void)hipHostFree(g.pin_crc);
+            g.pin_blk = nullptr; g.pin_crc = nullptr;
+            const size_t cap = nblk * 2 + 1024;
+            HIPCHK(hipHostMalloc((void **)&g.pin_blk, cap * sizeof(tdgz::Block), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **)&g.pin_crc, cap * 4, hipHostMallocDefault));
+            g.pin_cap = cap;
+        }
+        if (!g.pin_tail) HIPCHK(hipHostMalloc((void **)&g.pin_tail, ZB_TAIL + 16, hipHostMallocDefault));     // (+ the marker flag)
+        int rc2 = g.d_sym.ensure(sym_bytes + 64); if (rc2) return rc2;
+        rc2 = g.d_out.ensure(ZB_CARRY + db->total + 4096 + (db->total >> 3)); if (rc2) return rc2;
+        rc2 = g.d_blk.ensure(nblk + 1); if (rc2) return rc2;
+        rc2 = g.d_crc.ensure(nblk + 1); if (rc2) return rc2;
+        size_t at = 0, kb = 0;
+        for (const PI::DevPiece &pc : db->pieces) {
+            uint32_t wi = 0;
+            while (wi < wins.size() && wins[wi] != pc.window) wi++;
+            if (wi == wins.size()) wins.push_back(pc.window);
+            const size_t esz = pc.narrow ? 1 : 2;
+            HIPCHK(hipMemcpyAsync(g.d_sym.p + at, pc.src, pc.len * esz, hipMemcpyHostToDevice, h->copy_stream));
+            for (size_t o = 0; o < pc.len; o += tdgz::BLOCK_SYMS, kb++)
+                g.pin_blk[kb] = tdgz::Block{at + o * esz, pc.dest_off + o, (uint32_t)std::min<size_t>(tdgz::BLOCK_SYMS, pc.len - o), wi,
+                                            pc.min_idx, pc.narrow ? 1u : 0u};
+            at += (pc.len * esz + 15) & ~(size_t)15;
+        }
+        rc2 = g.d_win.ensure(std::max<size_t>(1, wins.size()) * tdgz::WINDOW); if (rc2) return rc2;
+        for (size_t w = 0; w < wins.size(); w++)
+            HIPCHK(hipMemcpyAsync(g.d_win.p + w * tdgz::WINDOW, wins[w], tdgz::WINDOW, hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(hipMemcpyAsync(g.d_blk.p, g.pin_blk, nblk * sizeof(tdgz::Block), hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(hipEventRecord(g.copied, h->copy_stream));
+        b.valid = true; b.last = db->last; b.member_done = db->member_done; b.want_crc = db->want_crc;
+        b.nblk = (uint32_t)nblk; b.total = db->total;
+        b.crc_len.resize(nblk);
+        for (size_t k = 0; k < nblk; k++) b.crc_len[k].second = g.pin_blk[k].len;
+        // the decoder may have its buffers back once the copies have left them
+        HIPCHK(hipEventSynchronize(g.copied));
+        src.pi.dev_release();
+        return TD_OK;
+    };
+    Batch cur, nxt;
+    int slot = 0;
+    rc = prepare(0, cur); if (rc) return rc;
+    uint64_t bytes_submitted = 0;
+    unsigned pieces = 0;
+    while (cur.valid) {
+        td_handle::GSlot &g = h->gslot[slot];
+        HIPCHK(hipStreamWaitEvent(h->work_stream, g.copied, 0));
+        if (cur.nblk) {
+            // (the batch's bytes go behind what the batch before left of its last line: d_out + carry)
+            hipLaunchKernelGGL(tdgz::k_gz_resolve, dim3(cur.nblk), dim3(256), 0, h->work_stream, g.d_sym.p, g.d_win.p, g.d_out.p + carry, g.d_blk.p, cur.nblk, h->d_gzflag.p);
+            hipLaunchKernelGGL(tdgz::k_gz_crc, dim3((cur.nblk + 63) / 64), dim3(64), 0, h->work_stream, g.d_out.p + carry, g.d_blk.p, cur.nblk, h->d_crctab, g.d_crc.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(g.pin_crc, g.d_crc.p, (size_t)cur.nblk * 4, hipMemcpyDeviceToHost, h->work_stream));
+        }
+        const size_t total = carry + cur.total;
+        const size_t ntail = std::min(total, ZB_TAIL);
+        if (ntail && !cur.last) HIPCHK(hipMemcpyAsync(g.pin_tail, g.d_out.p + total - ntail, ntail, hipMemcpyDeviceToHost, h->work_stream));
+        uint32_t *flag = (uint32_t *)(g.pin_tail + ZB_TAIL);
+        HIPCHK(hipMemcpyAsync(flag, h->d_gzflag.p, 4, hipMemcpyDeviceToHost, h->work_stream));
+        // the next batch is taken from the decoder and sent while this one is resolved
+        if (!cur.last) { rc = prepare(slot ^ 1, nxt); if (rc) return rc; }
+        HIPCHK(hipStreamSynchronize(h->work_stream));
+        if (*flag) return fail(TD_E_IO, "gzip: distance reaches before the start of the output");
+        for (uint32_t k = 0; k < cur.nblk; k++) cur.crc_len[k].first = g.pin_crc[k];
+        if (!src.pi.dev_check(cur.crc_len, cur.member_done, cur.want_crc)) return fail(TD_E_IO, std::string("gzip: ") + src.pi.error());
+        if (h->pin_cursor[0] >= stop_line) break;               // (the batches counted so far already hold read number max_reads)
+        size_t cut = total;
+        if (!cur.last && total) {
+            const size_t c = cut_at_line_end(g.pin_tail, ntail);
+            if (c == 0 || total - (total - ntail + c) > ZB_CARRY) return fail(TD_E_LIMIT, "a single line exceeds the staging buffer");
+            cut = total - ntail + c;
+        }
+        if (cut) {
+            rc = launch_count(h, g.d_out.p, cut, 0, max_reads, weights, h->work_stream, h->d_cursor.p + (pieces & 1),
+                              h->d_cursor.p + ((pieces + 1) & 1), bytes_submitted);
+            if (rc) return rc;
+            bytes_submitted += cut; pieces++;
+            HIPCHK(hipMemcpyAsync(h->pin_cursor, h->d_cursor.p + (pieces & 1), 8, hipMemcpyDeviceToHost, h->work_stream));
+        }
+        if (cur.last) break;
+        const size_t carry_next = total - cut;
+        if (carry_next) HIPCHK(hipMemcpyAsync(h->gslot[slot ^ 1].d_out.p, g.d_out.p + cut, carry_next, hipMemcpyDeviceToDevice, h->work_stream));
+        carry = carry_next;
+        cur = nxt; slot ^= 1;
+    }
+    HIPCHK(hipStreamSynchronize(h->work_stream));
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    return TD_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int td_count_host(td_handle *h, const void *fastq, uint64_t nbytes, uint64_t first_line, uint64_t max_reads,
@@ -1199,6 +1382,12 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
             bool not_bgzf = false;
             const int rc = count_bgzf_gpu(h, path, max_reads, weights, &not_bgzf);
             if (rc || !not_bgzf) return rc;
+        }
+        static const bool resolve_off = getenv("TAGDIG_GPU_RESOLVE") && atoi(getenv("TAGDIG_GPU_RESOLVE")) == 0;
+        if (h->gpu_resolve && !resolve_off) {                                 // ordinary gzip: decoded on the host threads, resolved on the GPU
+            bool not_applicable = false;
+            const int rc = count_gzip_dev(h, path, max_reads, weights, &not_applicable);
+            if (rc || !not_applicable) return rc;
         }
         tdhost::GzSource src;
         if (!src.open(path)) return fail(TD_E_IO, std::string("cannot open ") + path);
@@ -1480,6 +1669,7 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     else if (n == "split_kernel") h->split_kernel = value == 1 ? 1 : 2;
     else if (n == "gpu_inflate") h->gpu_inflate = value ? 1 : 0;
     else if (n == "gpu_inflate_crc") h->gpu_inflate_crc = value ? 1 : 0;
+    else if (n == "gpu_resolve") h->gpu_resolve = value ? 1 : 0;
     else if (n == "stagger") h->stagger = (int)value;
     else if (n == "prio") h->prio = (int)value & 0xFFFF;
     else if (n == "table_load_pct") h->table_load = std::max<int64_t>(10, std::min<int64_t>(value, 95)) / 100.0;
