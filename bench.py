@@ -675,7 +675,7 @@ def cpu_baseline(cfg, sample_reads, python_reads=0):
 def tiers(eng, cfg, reads):
     """Tiers T2/T3 of SURVEY 8d on `reads` reads of the same stream and index -- inputs NOT resident in HBM:
     T2 host buffer -> pinned staging -> hipMemcpyAsync overlapped with counting; T3 from a file: plain,
-    ordinary gzip (host chunk-parallel inflate), BGZF (member-parallel inflate).  Each result is checked
+    ordinary gzip (chunk-parallel decode on the host, markers and CRC-32 on the GPU), BGZF (member-parallel inflate).  Each result is checked
     against the generator's expected matrix.  Never the bench `value`."""
     import gzip
     import tempfile
@@ -723,9 +723,17 @@ def tiers(eng, cfg, reads):
         gzp = os.path.join(tmp, "tiers_lib.fq.gz")
         with open(gzp, "wb") as fh:
             fh.write(gzip_one_member(host, level=1, threads=16))
+        # DEFLATE is decoded into symbols by the host threads; markers -> bytes and the CRC-32 on the GPU (count_gzip_dev);
+        # "gpu_resolve" 0: all of it on the host, as in rounds 1-2
+        eng.count_file(gzp)                                             # (warm: the decoder's pinned buffers)
         r = timed(lambda: eng.count_file(gzp), reads, want)
         r["reads"] = reads
         r["gz_bytes"] = os.path.getsize(gzp)
+        out["T3_gzip_file_host_decode_gpu_resolve"] = r
+        eng.set_option("gpu_resolve", 0)
+        r = timed(lambda: eng.count_file(gzp), reads, want)
+        eng.set_option("gpu_resolve", 1)
+        r["reads"] = reads
         out["T3_gzip_file_host_inflate"] = r
         os.unlink(gzp)
         # BGZF (bgzip's level 6), the whole sample twice over: a batch of the GPU inflater is 49 152 members (3 GB of FASTQ)

@@ -156,7 +156,9 @@ class ParInflate {
         size_t total = 0;
         bool member_done = false; uint32_t want_crc = 0;
         bool failed = false, last = false;
-        int state = 0;            // 0 free (the producer may decode into its chunk set), 1 ready for the caller, 2 uploaded
+        int state = 0;            // 0 free (the producer may fill it), 1 ready for the caller
+        std::vector<int> slots;   // (the decoder's: the buffers the pieces lie in, given back by dev_release())
+        std::vector<void *> spares;
     };
     void dev_open(const uint8_t *data, size_t n, int threads, size_t chunk_bytes, const Allocator *al) {
         open(data, n, threads, chunk_bytes);
@@ -182,7 +184,13 @@ class ParInflate {
     void dev_release() {
         DevBatch &b = dev_[dev_rd_];
         cur_last_ = b.last || b.failed;
-        { std::lock_guard<std::mutex> g(mu_); b.state = 0; }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (int s : b.slots) free_ring_slot(s);
+            for (void *c : b.spares) spare_free_.push_back((Chunk *)c);
+            b.slots.clear(); b.spares.clear();
+            b.state = 0;
+        }
         cv_.notify_all();
         dev_rd_ ^= 1;
         if (cur_last_) dev_done_ = true;
@@ -199,6 +207,15 @@ class ParInflate {
         return true;
     }
     bool dev_failed() const { return failed_; }
+    // a piece's bytes and their CRC-32 by the host (what the GPU does in count_gzip_dev; for checks without one); false: a marker
+    // points before the member's start
+    static bool dev_resolve_on_host(const DevPiece &pc, uint8_t *dst, uint32_t *crc) {
+        bool ok = true;
+        if (pc.narrow) memcpy(dst, pc.src, pc.len);
+        else ok = resolve((const uint16_t *)pc.src, pc.len, pc.window, dst, pc.min_idx);
+        *crc = FastInflate::crc32_update(0, dst, pc.len);
+        return ok;
+    }
 
   private:
     using FI = FastInflate;
@@ -307,58 +324,198 @@ class ParInflate {
     DevBatch dev_[2];
     int dev_rd_ = 0;
 
-    // the producer of device mode: batch b uses chunk set b & 1 -- as soon as the caller has read batch b - 2 out of it
+    // ---- device mode: no batches on the decoding side.  The file is cut into territories of chunk_ bytes on a fixed
+    // grid; the worker threads take them in order, each searching its territory for a block start (step 1) and decoding
+    // from there to the first block boundary behind the territory (step 2), into a ring of 2 * max_chunks_ chunk
+    // buffers.  This thread follows with step 3: a chunk counts if it began exactly where the stream stands; where none
+    // did (a false start, a territory without a findable start, the first block of a member, a chunk that stopped
+    // early) it decodes up to the next territory itself, as bytes, with the window it knows.  What has been chained is
+    // handed to the caller in batches of up to a quarter of the ring -- fewer when the next chunk is not ready yet --
+    // whose buffers return to the ring with dev_release().
+    enum : uint8_t { S_FREE = 0, S_BUSY, S_DONE, S_HELD };
+    std::vector<uint8_t> st_;                        // state of the ring's buffers        } all under mu_
+    std::vector<uint64_t> turn_;                     // ... and the territory each is for  }
+    std::vector<std::unique_ptr<Chunk>> spare_all_;  // chunks this thread decodes into (taken and returned under mu_)
+    std::vector<Chunk *> spare_free_;
+    std::atomic<uint64_t> next_g_{0};
+    bool quit_ = false;                              // (the stream is through: workers go home)
+    int ring_ = 0;
+    Chunk &ring_chunk(int s) { return s < max_chunks_ ? sets_[0][s] : sets_[1][s - max_chunks_]; }
+    uint64_t grid_lo(uint64_t g) const { return g * (uint64_t)chunk_ * 8; }
+    uint64_t grid_hi(uint64_t g) const { return (uint64_t)std::min<uint64_t>((g + 1) * (uint64_t)chunk_, n_) * 8; }
+    void reset_chunk(Chunk &c, uint64_t from, uint64_t to) {
+        c.search_from = from; c.search_to = to; c.target = to;
+        c.start = NONE; c.resume = from;
+        c.stop = 0; c.member_done = false; c.failed = false; c.err = ""; c.out_len = 0; c.wide_len = 0;
+    }
+    void free_ring_slot(int s) {                     // (mu_ held)
+        st_[(size_t)s] = S_FREE;
+        turn_[(size_t)s] += (uint64_t)ring_;
+    }
+
+    void device_worker() {
+        for (;;) {
+            const uint64_t g = next_g_.fetch_add(1);
+            if (g * (uint64_t)chunk_ >= n_) return;
+            const int s = (int)(g % (uint64_t)ring_);
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&]() { return (st_[(size_t)s] == S_FREE && turn_[(size_t)s] == g) || stop_ || quit_; });
+                if (stop_ || quit_) return;
+                st_[(size_t)s] = S_BUSY;
+            }
+            Chunk &c = ring_chunk(s);
+            reset_chunk(c, grid_lo(g), grid_hi(g));
+            find_start(c);
+            decode_chunk(c, false);
+            { std::lock_guard<std::mutex> lk(mu_); st_[(size_t)s] = S_DONE; }
+            cv_.notify_all();
+        }
+    }
+
+    // this thread's own decoding: from where the stream stands (pos_, window_ known) to the first block boundary at or past `target`
+    Chunk *decode_here(uint64_t target) {
+        Chunk *c = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!spare_free_.empty()) { c = spare_free_.back(); spare_free_.pop_back(); }
+        }
+        if (!c) {
+            spare_all_.emplace_back(new Chunk);
+            c = spare_all_.back().get();
+            c->wide.al = al_; c->narrow.al = al_;
+        }
+        reset_chunk(*c, pos_, target);
+        c->start = pos_;
+        decode_chunk(*c, true);
+        return c;
+    }
+
     void produce_device() {
+        ring_ = 2 * max_chunks_;
+        st_.assign((size_t)ring_, S_FREE);
+        turn_.resize((size_t)ring_);
+        uint64_t gi = (pos_ >> 3) / chunk_;                        // the territory step 3 looks at next
+        for (int s = 0; s < ring_; s++) {
+            uint64_t g = gi - gi % (uint64_t)ring_ + (uint64_t)s;
+            if (g < gi) g += (uint64_t)ring_;
+            turn_[(size_t)s] = g;
+        }
+        next_g_ = gi; quit_ = false;
+        std::vector<std::thread> workers;
+        if (!failed_ && !end_)
+            for (int i = 0; i < threads_; i++) {
+                try { workers.emplace_back([this]() { device_worker(); }); } catch (...) { break; }     // (fewer workers, or this thread alone)
+            }
+        const int most = std::max(2, ring_ / 4), least = std::max(1, std::min(most, threads_ / 2));
+        auto leave = [&]() {
+            { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
+            cv_.notify_all();
+            for (auto &t : workers) t.join();
+        };
+        auto wait_done = [&](uint64_t g) -> bool {                 // false: asked to stop
+            const size_t s = (size_t)(g % (uint64_t)ring_);
+            const double tw = now();
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&]() { return (st_[s] == S_DONE && turn_[s] == g) || stop_; });
+            stats.t_decode += now() - tw;
+            return !stop_;
+        };
+        auto held = [&](uint64_t g) -> bool {
+            const size_t s = (size_t)(g % (uint64_t)ring_);
+            std::lock_guard<std::mutex> lk(mu_);
+            return st_[s] == S_HELD;
+        };
+        const bool have_workers = !workers.empty();
         for (int b = 0;; b++) {
             DevBatch &d = dev_[b & 1];
             {
                 const double tw = now();
-                std::unique_lock<std::mutex> g(mu_);
-                cv_.wait(g, [&]() { return d.state == 0 || stop_; });
-                if (stop_) return;
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&]() { return d.state == 0 || stop_; });
+                if (stop_) { lk.unlock(); leave(); return; }
                 stats.t_wait += now() - tw;
             }
-            d.pieces.clear(); d.total = 0; d.member_done = false; d.failed = false; d.last = false;
-            if (failed_ || end_) {                                  // (an empty or bad stream, or nothing left)
-                d.failed = failed_; d.last = true;
-                { std::lock_guard<std::mutex> g(mu_); d.state = 1; }
-                cv_.notify_all();
-                return;
-            }
+            d.pieces.clear(); d.slots.clear(); d.spares.clear();
+            d.total = 0; d.member_done = false; d.want_crc = 0; d.failed = false; d.last = false;
+            int count = 0;
             const double t0 = now();
-            chunks_ = sets_[b & 1].get();
-            territories();
-            parallel(nch_ - 1, [this](int k) { find_start(k + 1); });
-            for (int k = nch_ - 1; k >= 0; k--)
-                chunks_[k].target = k == nch_ - 1 ? batch_end_ : (chunks_[k + 1].start != NONE ? chunks_[k + 1].start : chunks_[k + 1].target);
-            const double td = now();
-            stats.t_search += td - t0;
-            parallel(nch_, [this](int i) { decode_chunk(i); });
-            const double t1 = now();
-            stats.t_decode += t1 - td;
-            stats.batches++;
-            chain(slot_[b & 1]);
-            stats.t_chain += now() - t1;
-            // what chain() left in pend_ becomes the caller's batch
-            for (const Piece &pc : pend_.pieces) {
-                Chunk &c = *pc.c;
-                const uint64_t before = c.member_before + pc.off;
-                DevPiece dp;
-                dp.narrow = pc.off >= c.wide_len;
-                dp.src = dp.narrow ? (const void *)(c.narrow.p + WIN + pc.off - c.wide_len) : (const void *)(c.wide.p + WIN + pc.off);
-                dp.len = pc.len; dp.window = c.window;
-                dp.min_idx = WIN - (uint32_t)std::min<uint64_t>(WIN, before);
-                dp.dest_off = c.dest_off + pc.off;
-                d.pieces.push_back(dp);
+            while (!failed_ && !end_ && count < most) {
+                // territories the stream has already left behind (a long block, or this thread's own decoding, went through them)
+                bool own = false;
+                while (have_workers && gi * (uint64_t)chunk_ < n_ && pos_ >= grid_hi(gi)) {
+                    if (count && held(gi)) { own = true; break; }
+                    if (!wait_done(gi)) { leave(); return; }
+                    { std::lock_guard<std::mutex> lk(mu_); free_ring_slot((int)(gi % (uint64_t)ring_)); }
+                    cv_.notify_all();
+                    gi++;
+                }
+                const bool grid = have_workers && gi * (uint64_t)chunk_ < n_;
+                // (the buffer this territory is decoded into may still belong to the batch being put together -- long blocks
+                // make a batch's chunks lie far apart: hand the batch over first)
+                if (own || (grid && count && held(gi))) break;
+                Chunk *c = nullptr;
+                if (grid && pos_ >= grid_lo(gi)) {
+                    const size_t s = (size_t)(gi % (uint64_t)ring_);
+                    if (count >= least) {                          // (rather hand over what there is than wait)
+                        std::lock_guard<std::mutex> lk(mu_);
+                        if (!(st_[s] == S_DONE && turn_[s] == gi)) break;
+                    }
+                    if (!wait_done(gi)) { leave(); return; }
+                    Chunk &r = ring_chunk((int)s);
+                    if (r.start == pos_) {
+                        c = &r;
+                        { std::lock_guard<std::mutex> lk(mu_); st_[s] = S_HELD; }
+                        d.slots.push_back((int)s);
+                        gi++;
+                    } else {                                       // a false start, or none: the territory is decoded here
+                        { std::lock_guard<std::mutex> lk(mu_); free_ring_slot((int)s); }
+                        cv_.notify_all();
+                        stats.dropped++;
+                        c = decode_here(grid_hi(gi));
+                        d.spares.push_back((void *)c);
+                        gi++;
+                    }
+                } else {
+                    // the stream stands before the next territory (a member has begun, a chunk stopped early) or there are none left
+                    c = decode_here(grid ? grid_lo(gi) : ~0ull);
+                    d.spares.push_back((void *)c);
+                }
+                if (c->failed) { failed_ = true; err_ = c->err; break; }
+                c->member_before = member_out_;
+                c->dest_off = d.total;
+                if (c->wide_len == c->out_len && c->wide_len) {
+                    memcpy(c->window, window_, WIN);
+                    for (uint32_t i = 0; i < WIN; i++) { const uint32_t v = c->wide.p[c->out_len + i]; window_[i] = v & 0x8000u ? c->window[v & 0x7FFFu] : (uint8_t)v; }
+                } else if (c->out_len) {
+                    if (c->wide_len) memcpy(c->window, window_, WIN);
+                    memcpy(window_, c->narrow.p + (c->out_len - c->wide_len), WIN);
+                }
+                const uint32_t min_idx = WIN - (uint32_t)std::min<uint64_t>(WIN, member_out_);   // (a marker is a place in the 32 KiB before the chunk)
+                if (c->wide_len) d.pieces.push_back(DevPiece{c->wide.p + WIN, c->wide_len, false, c->window, min_idx, d.total});
+                if (c->out_len > c->wide_len) d.pieces.push_back(DevPiece{c->narrow.p + WIN, c->out_len - c->wide_len, true, c->window, min_idx, d.total + c->wide_len});
+                stats.chunks++; stats.as_bytes += c->out_len - c->wide_len;
+                d.total += c->out_len; member_out_ += c->out_len; pos_ = c->stop;
+                count++;
+                if (c->member_done) {
+                    const size_t at = (size_t)((pos_ + 7) >> 3);
+                    uint32_t want_len = 0;
+                    if (at + 8 > n_) { failed_ = true; err_ = "truncated gzip member (no CRC / length)"; break; }
+                    memcpy(&d.want_crc, data_ + at, 4); memcpy(&want_len, data_ + at + 4, 4);
+                    if (want_len != (uint32_t)member_out_) { failed_ = true; err_ = "gzip member fails its length check"; break; }
+                    d.member_done = true;
+                    begin_member(at + 8);
+                    break;                                         // (a batch carries one CRC-32 to check)
+                }
             }
-            d.total = pend_.total; d.member_done = pend_.member_done; d.want_crc = pend_.want_crc;
-            d.failed = pend_.failed; d.last = pend_.last;
-            stats.out_bytes += pend_.total;
-            pend_.valid = false;
-            const bool fin = d.failed || d.last;
-            { std::lock_guard<std::mutex> g(mu_); d.state = 1; }
+            stats.t_chain += now() - t0;
+            stats.batches++;
+            stats.out_bytes += d.total;
+            d.failed = failed_; d.last = failed_ || end_;
+            const bool fin = d.last;
+            { std::lock_guard<std::mutex> lk(mu_); d.state = 1; }
             cv_.notify_all();
-            if (fin) return;
+            if (fin) { leave(); return; }
         }
     }
 
@@ -369,7 +526,7 @@ class ParInflate {
             if (more) {
                 chunks_ = sets_[b & 1].get();
                 territories();
-                parallel(nch_ - 1, [this](int k) { find_start(k + 1); });
+                parallel(nch_ - 1, [this](int k) { find_start(chunks_[k + 1]); });
                 for (int k = nch_ - 1; k >= 0; k--)               // every chunk heads for the next start found
                     chunks_[k].target = k == nch_ - 1 ? batch_end_ : (chunks_[k + 1].start != NONE ? chunks_[k + 1].start : chunks_[k + 1].target);
                 tf = now();
@@ -397,7 +554,7 @@ class ParInflate {
             const int ndec = nch_, npieces = pend_.valid ? (int)pend_.pieces.size() : 0;
             parallel(ndec + npieces, [this, ndec](int i) {
                 if (i >= ndec) resolve_piece(pend_.pieces[(size_t)(i - ndec)]);
-                else decode_chunk(i);
+                else decode_chunk(chunks_[i], i == 0);
             });
             const double t1 = now();
             stats.t_decode += t1 - td;
@@ -449,7 +606,7 @@ class ParInflate {
         uint8_t *dst = pend_.slot->b.p + c.dest_off + pc.off;
         if (pc.off >= c.wide_len) memcpy(dst, c.narrow.p + WIN + pc.off - c.wide_len, pc.len);
         else {
-            const uint64_t before = c.member_before + pc.off;
+            const uint64_t before = c.member_before;          // (a marker is a place in the 32 KiB before the CHUNK)
             pc.bad = !resolve(c.wide.p + WIN + pc.off, pc.len, c.window, dst, WIN - (uint32_t)std::min<uint64_t>(WIN, before));
         }
         pc.crc = FI::crc32_update(0, dst, pc.len);
@@ -653,8 +810,7 @@ class ParInflate {
 
     // ---- step 1 for chunk k >= 1: the first position in its territory that passes as a block start.  The
     // block decoded for the check stays in the chunk's buffer; step 2 goes on behind it
-    void find_start(int k) {
-        Chunk &c = chunks_[k];
+    void find_start(Chunk &c) {
         if (!c.tables) c.tables.reset(new Tables);
         Tables &t = *c.tables;
         Buf<uint16_t> &buf = c.wide;
@@ -690,7 +846,14 @@ class ParInflate {
         for (;; first = false) {
             const uint64_t here = b.bitpos(data_);
             const size_t n = (size_t)(out - buf.p) - WIN;
-            if (!first && (here >= c.target || c.wide_len + n > cap_)) { c.stop = here; return 0; }
+            if (!first && c.wide_len + n > cap_) { c.stop = here; return 0; }
+            if (!first && here >= c.target) {
+                // on the grid of device mode a chunk's successor did not tell where it begins: stop where step 1 can have
+                // found it -- in front of a non-final dynamic block (not in front of the empty stored block of a flush)
+                if (!device_) { c.stop = here; return 0; }
+                if (b.cnt < 3) b.refill();
+                if ((b.buf & 7) == 4) { c.stop = here; return 0; }
+            }
             if (may_switch && sizeof(T) == 2 && n >= WIN) {
                 const uint16_t *sy = (const uint16_t *)buf.p + WIN;
                 size_t i = scanned;
@@ -717,8 +880,7 @@ class ParInflate {
             if (final) { c.member_done = true; c.stop = b.bitpos(data_); return 0; }
         }
     }
-    void decode_chunk(int k) {
-        Chunk &c = chunks_[k];
+    void decode_chunk(Chunk &c, bool exact) {
         if (c.start == NONE) return;
         const double t0 = now();
         if (!c.tables) c.tables.reset(new Tables);
@@ -726,7 +888,7 @@ class ParInflate {
         Bits b;
         b.seek(data_, c.resume);
         c.wide_len = 0;
-        if (k == 0) {                                                // (the window is known: bytes from the start)
+        if (exact) {                                                 // (the window is known: bytes from the start)
             c.narrow.reserve(WIN + chunk_ * 8 + 4096);
             memcpy(c.narrow.p, window_, WIN);
             c.valid_back = (size_t)std::min<uint64_t>(WIN, member_out_);

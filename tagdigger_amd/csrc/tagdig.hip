@@ -146,6 +146,8 @@ struct td_handle {
     int device = 0;
     int num_cu = 256;
     hipStream_t copy_stream = nullptr, work_stream = nullptr;
+    // (count_gzip_dev: one copy engine moves 22-25 GB/s out of pinned memory on the far socket, two or three together 50)
+    hipStream_t side_copy[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr};
     // index
     bool have_index = false;
     uint32_t barnum = 0, ntags = 0;
@@ -207,7 +209,7 @@ struct td_handle {
     ZPiece ldpiece[2];                        // td_load_file_range's pinned staging
     // ordinary gzip: symbols decoded by the host, resolved on the GPU (count_gzip_dev): two batches in flight
     struct GSlot { DevBuf<uint8_t> d_sym, d_out, d_win; DevBuf<tdgz::Block> d_blk; DevBuf<uint32_t> d_crc;
-                   tdgz::Block *pin_blk = nullptr; uint32_t *pin_crc = nullptr; uint8_t *pin_tail = nullptr; size_t pin_cap = 0;
+                   tdgz::Block *pin_blk = nullptr; uint32_t *pin_crc = nullptr; uint8_t *pin_tail = nullptr; size_t pin_cap = 0; hipEvent_t done = nullptr;
                    hipEvent_t copied = nullptr; } gslot[2];
     DevBuf<uint32_t> d_gzflag;
     int gpu_resolve = 1;                      // ordinary gzip of 8 MiB and more: markers -> bytes and CRC-32 on the GPU (0: all on the host)
@@ -671,10 +673,13 @@ void td_destroy(td_handle *h) {
         if (g.pin_crc) (void)hipHostFree(g.pin_crc);
         if (g.pin_tail) (void)hipHostFree(g.pin_tail);
         if (g.copied) (void)hipEventDestroy(g.copied);
+        if (g.done) (void)hipEventDestroy(g.done);
     }
     h->d_gzflag.release();
     if (h->d_crctab) (void)hipFree(h->d_crctab);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    for (auto &st : h->side_copy) if (st) (void)hipStreamDestroy(st);
+    for (auto &ev : h->side_done) if (ev) (void)hipEventDestroy(ev);
     if (h->work_stream) (void)hipStreamDestroy(h->work_stream);
     delete h;
 }
@@ -1213,7 +1218,16 @@ int count_gzip_dev(td_handle *h, const char *path, uint64_t max_reads, int weigh
     HIPCHK(hipMemsetAsync(h->d_cursor.p, 0, 16, h->work_stream));
     if (!h->pin_cursor) HIPCHK(hipHostMalloc((void **)&h->pin_cursor, 16, hipHostMallocDefault));
     h->pin_cursor[0] = 0;
-    for (auto &g : h->gslot) if (!g.copied) HIPCHK(hipEventCreateWithFlags(&g.copied, hipEventDisableTiming));
+    // (events the host waits on sleeping: a spinning wait would take a core from the decoder's threads)
+    for (auto &g : h->gslot) {
+        if (!g.copied) HIPCHK(hipEventCreateWithFlags(&g.copied, hipEventDisableTiming | hipEventBlockingSync));
+        if (!g.done) HIPCHK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming | hipEventBlockingSync));
+    }
+    for (int k = 0; k < 2; k++) {
+        if (!h->side_copy[k]) HIPCHK(hipStreamCreateWithFlags(&h->side_copy[k], hipStreamNonBlocking));
+        if (!h->side_done[k]) HIPCHK(hipEventCreateWithFlags(&h->side_done[k], hipEventDisableTiming));
+    }
+    static const int copy_streams = getenv("TAGDIG_GZ_COPY_STREAMS") ? std::max(1, std::min(3, atoi(getenv("TAGDIG_GZ_COPY_STREAMS")))) : 3;
     struct Batch {
         bool valid = false, last = false, member_done = false;
         uint32_t want_crc = 0, nblk = 0;
@@ -1224,10 +1238,14 @@ int count_gzip_dev(td_handle *h, const char *path, uint64_t max_reads, int weigh
     size_t carry = 0;                                           // bytes of an unfinished line at the front of the current slot's output
     // the next batch from the decoder: block table, symbols and windows on their way to the device; the decoder's buffers
     // are handed back as soon as the copies have been made
+    double t_next = 0, t_upload = 0, t_sync = 0;                // (TAGDIG_INFLATE_STATS: waiting for the decoder / the copies / the kernels)
+    uint64_t up_bytes = 0, nbatch = 0;
     auto prepare = [&](int slot, Batch &b) -> int {
         td_handle::GSlot &g = h->gslot[slot];
         b = Batch();
+        const double tn = PI::now();
         const PI::DevBatch *db = src.pi.dev_next();
+        t_next += PI::now() - tn;
         if (!db) {
             if (src.pi.dev_failed()) return fail(TD_E_IO, std::string("gzip: ") + src.pi.error());
             return TD_OK;                                       // (the stream is through)
@@ -1252,12 +1270,14 @@ int count_gzip_dev(td_handle *h, const char *path, uint64_t max_reads, int weigh
         rc2 = g.d_blk.ensure(nblk + 1); if (rc2) return rc2;
         rc2 = g.d_crc.ensure(nblk + 1); if (rc2) return rc2;
         size_t at = 0, kb = 0;
+        unsigned npiece = 0;
         for (const PI::DevPiece &pc : db->pieces) {
             uint32_t wi = 0;
             while (wi < wins.size() && wins[wi] != pc.window) wi++;
             if (wi == wins.size()) wins.push_back(pc.window);
             const size_t esz = pc.narrow ? 1 : 2;
-            HIPCHK(hipMemcpyAsync(g.d_sym.p + at, pc.src, pc.len * esz, hipMemcpyHostToDevice, h->copy_stream));
+            const int lane = (int)(npiece++ % (unsigned)copy_streams);           // (the chunks of a batch over the copy engines)
+            HIPCHK(hipMemcpyAsync(g.d_sym.p + at, pc.src, pc.len * esz, hipMemcpyHostToDevice, lane ? h->side_copy[lane - 1] : h->copy_stream));
             for (size_t o = 0; o < pc.len; o += tdgz::BLOCK_SYMS, kb++)
                 g.pin_blk[kb] = tdgz::Block{at + o * esz, pc.dest_off + o, (uint32_t)std::min<size_t>(tdgz::BLOCK_SYMS, pc.len - o), wi,
                                             pc.min_idx, pc.narrow ? 1u : 0u};
@@ -1267,13 +1287,19 @@ int count_gzip_dev(td_handle *h, const char *path, uint64_t max_reads, int weigh
         for (size_t w = 0; w < wins.size(); w++)
             HIPCHK(hipMemcpyAsync(g.d_win.p + w * tdgz::WINDOW, wins[w], tdgz::WINDOW, hipMemcpyHostToDevice, h->copy_stream));
         HIPCHK(hipMemcpyAsync(g.d_blk.p, g.pin_blk, nblk * sizeof(tdgz::Block), hipMemcpyHostToDevice, h->copy_stream));
+        for (int k = 0; k + 1 < copy_streams; k++) {
+            HIPCHK(hipEventRecord(h->side_done[k], h->side_copy[k]));
+            HIPCHK(hipStreamWaitEvent(h->copy_stream, h->side_done[k], 0));
+        }
         HIPCHK(hipEventRecord(g.copied, h->copy_stream));
         b.valid = true; b.last = db->last; b.member_done = db->member_done; b.want_crc = db->want_crc;
         b.nblk = (uint32_t)nblk; b.total = db->total;
         b.crc_len.resize(nblk);
         for (size_t k = 0; k < nblk; k++) b.crc_len[k].second = g.pin_blk[k].len;
         // the decoder may have its buffers back once the copies have left them
+        const double tu = PI::now();
         HIPCHK(hipEventSynchronize(g.copied));
+        t_upload += PI::now() - tu; up_bytes += at;
         src.pi.dev_release();
         return TD_OK;
     };
@@ -1297,9 +1323,12 @@ int count_gzip_dev(td_handle *h, const char *path, uint64_t max_reads, int weigh
         if (ntail && !cur.last) HIPCHK(hipMemcpyAsync(g.pin_tail, g.d_out.p + total - ntail, ntail, hipMemcpyDeviceToHost, h->work_stream));
         uint32_t *flag = (uint32_t *)(g.pin_tail + ZB_TAIL);
         HIPCHK(hipMemcpyAsync(flag, h->d_gzflag.p, 4, hipMemcpyDeviceToHost, h->work_stream));
+        HIPCHK(hipEventRecord(g.done, h->work_stream));
         // the next batch is taken from the decoder and sent while this one is resolved
         if (!cur.last) { rc = prepare(slot ^ 1, nxt); if (rc) return rc; }
-        HIPCHK(hipStreamSynchronize(h->work_stream));
+        const double ts = PI::now();
+        HIPCHK(hipEventSynchronize(g.done));
+        t_sync += PI::now() - ts; nbatch++;
         if (*flag) return fail(TD_E_IO, "gzip: distance reaches before the start of the output");
         for (uint32_t k = 0; k < cur.nblk; k++) cur.crc_len[k].first = g.pin_crc[k];
         if (!src.pi.dev_check(cur.crc_len, cur.member_done, cur.want_crc)) return fail(TD_E_IO, std::string("gzip: ") + src.pi.error());
@@ -1325,6 +1354,9 @@ int count_gzip_dev(td_handle *h, const char *path, uint64_t max_reads, int weigh
     }
     HIPCHK(hipStreamSynchronize(h->work_stream));
     HIPCHK(hipStreamSynchronize(h->copy_stream));
+    if (getenv("TAGDIG_INFLATE_STATS"))
+        fprintf(stderr, "count_gzip_dev: %lu batches, %.1f MB sent to the GPU; waiting for the decoder %.3f s, for the copies %.3f s, for the kernels %.3f s\n",
+                (unsigned long)nbatch, up_bytes / 1e6, t_next, t_upload, t_sync);
     return TD_OK;
 }
 }  // namespace
@@ -1349,6 +1381,40 @@ int td_count_host(td_handle *h, const void *fastq, uint64_t nbytes, uint64_t fir
 
 int td_gunzip_file(const char *path, void *dst, uint64_t capacity, uint64_t chunk, uint64_t *n_out) {
     if (!path || !dst || !n_out) return fail(TD_E_ARG, "NULL argument");
+    if (getenv("TAGDIG_GUNZIP_PIPELINE")) {
+        // the decoder as count_gzip_dev drives it (dev_next / dev_release / dev_check), markers resolved by the host: the
+        // pipeline can be checked where there is no GPU
+        static const tdhost::ParInflate::Allocator plain = {[](size_t b) -> void * { return malloc(b); }, [](void *p, size_t) { free(p); }};
+        tdhost::GzSource dsrc;
+        if (dsrc.open_dev(path, &plain)) {
+            uint64_t n = 0;
+            for (;;) {
+                const tdhost::ParInflate::DevBatch *db = dsrc.pi.dev_next();
+                if (!db) {
+                    if (dsrc.pi.dev_failed()) return fail(TD_E_IO, std::string("gzip: ") + dsrc.pi.error());
+                    break;
+                }
+                if (db->failed) { const std::string e = dsrc.pi.error(); dsrc.pi.dev_release(); return fail(TD_E_IO, "gzip: " + e); }
+                if (n + db->total > capacity) { dsrc.pi.dev_release(); return fail(TD_E_LIMIT, "destination too small"); }
+                std::vector<std::pair<uint32_t, size_t>> crc_len;
+                bool ok = true;
+                for (const auto &pc : db->pieces) {
+                    uint32_t c = 0;
+                    ok &= tdhost::ParInflate::dev_resolve_on_host(pc, (uint8_t *)dst + n + pc.dest_off, &c);
+                    crc_len.emplace_back(c, pc.len);
+                }
+                n += db->total;
+                const bool last = db->last, member_done = db->member_done;
+                const uint32_t want = db->want_crc;
+                dsrc.pi.dev_release();
+                if (!ok) return fail(TD_E_IO, "gzip: distance reaches before the start of the output");
+                if (!dsrc.pi.dev_check(crc_len, member_done, want)) return fail(TD_E_IO, std::string("gzip: ") + dsrc.pi.error());
+                if (last) break;
+            }
+            *n_out = n;
+            return TD_OK;
+        }
+    }
     tdhost::GzSource src;
     if (!src.open(path)) return fail(TD_E_IO, std::string("cannot open ") + path);
     uint64_t n = 0;
