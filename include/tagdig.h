@@ -110,7 +110,13 @@ int td_count_host(td_handle *h, const void *fastq, uint64_t nbytes,
                   uint64_t first_line, uint64_t max_reads, int weights, uint64_t *lines_out);
 
 /* Whole file, plain or gzip (chosen by name as at :240: last two characters
- * 'gz' in any case), streamed and inflated on the host.  Synchronous. */
+ * 'gz' in any case), streamed.  BGZF is inflated on the GPU; any other gzip stream is
+ * decoded by the host's threads and -- from 8 MiB of compressed data -- resolved and
+ * CRC-checked on the GPU (options "gpu_inflate", "gpu_resolve").  Synchronous.
+ * Environment: TAGDIG_INFLATE_THREADS (default: the host's cores, at most 16),
+ * TAGDIG_INFLATE_CHUNK (bytes of compressed data per chunk, default 1 MiB),
+ * TAGDIG_COPY_STREAMS (1..3 copy streams side by side for large uploads, default 3),
+ * TAGDIG_INFLATE_STATS=1 (a line of timings on stderr). */
 int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weights);
 
 /* The gzip reader td_count_file / td_split_file use, on its own (host only, no GPU; for tests):
@@ -119,7 +125,10 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
  * host's cores, at most 16); any other gzip stream (what gzip.open reads at tagdigger_fun.py:241,
  * multi-member included) by the library's own DEFLATE decoder: on the calling thread below 8 MiB
  * of compressed data, chunk-parallel on the same number of threads from there (csrc/par_inflate.hpp).
- * Every member's CRC-32 and length are checked. */
+ * Every member's CRC-32 and length are checked.
+ * TAGDIG_GUNZIP_PIPELINE=1: the chunk-parallel decoder is driven the way td_count_file drives it for the GPU (its
+ * device mode: dev_next / dev_release / dev_check), the markers resolved by the host -- so that the pipeline
+ * can be tested where there is no GPU. */
 int td_gunzip_file(const char *path, void *dst, uint64_t capacity, uint64_t chunk, uint64_t *n_out);
 
 /* Line terminators (\n, \r\n, bare \r) in a device buffer -- what a shard of a
@@ -249,6 +258,10 @@ int64_t td_format_csv_row(const int64_t *vals, uint64_t n, char *out, uint64_t c
  *                    is then k_fast2's recording instantiation (+6 % kernel time) or the exact kernel
  *   "split_kernel"   the splitter's per-read branch: 2 (default) k_split2 -- tile in LDS, one lane per read
  *                    (kernel_splitter2.hpp); 1 k_split (kernel_splitter.hpp)
+ *   "gpu_resolve"    1 (default): ordinary gzip of 8 MiB and more -- DEFLATE decoded into 16-bit symbols on the host's
+ *                    threads (copies that reach before a chunk stay markers), markers -> bytes and every member's CRC-32
+ *                    on the GPU (csrc/gz_resolve.hpp), counted where it lands; 0: all of it on the host, the bytes then
+ *                    staged like a plain file's.  (Environment TAGDIG_GPU_RESOLVE=0: the same, for every handle.)
  *   "gpu_inflate"    1 (default): BGZF members are inflated on the GPU; 0: on host threads
  *   "gpu_inflate_crc" 1 (default): every member's CRC-32 is checked on the device
  *   "zb_members"     BGZF members per GPU batch (tests; the built-in 49 152 is also the maximum)

@@ -24,7 +24,13 @@
 // next (two sets of chunk buffers): its pieces are taken up as threads run out of chunks to decode,
 // which fills the idle tail that chunks of unequal duration leave.
 // Files without findable block starts (stored or fixed-Huffman blocks only) are decoded by the first
-// thread alone.  After: Kerbiriou & Chikhi, "Parallel decompression of gzip-compressed files and random
+// thread alone.
+// Device mode (dev_open / dev_next / dev_release / dev_check, what td_count_file drives: tagdig.hip count_gzip_dev) stops
+// after step 3 -- the symbols go to the GPU as they are, step 4 runs there -- and has no batches on the decoding side:
+// the territories lie on a fixed grid, the threads decode ahead into a ring of chunk buffers, and one thread chains behind
+// them (see produce_device).  In both modes a chunk goes over from symbols to plain bytes at the first block boundary
+// where its last 32 KiB hold no marker (streams with full flushes: pigz -i, bgzip-like writers).
+// After: Kerbiriou & Chikhi, "Parallel decompression of gzip-compressed files and random
 // access to DNA sequences" (2019), without its text heuristics -- step 3 makes the search exact.
 #pragma once
 #include <emmintrin.h>
@@ -87,7 +93,8 @@ class ParInflate {
             producer_.join();
             if (getenv("TAGDIG_INFLATE_STATS"))
                 fprintf(stderr, "par_inflate: %d threads, %zu KiB chunks: %lu batches, %lu chunks (+%lu dropped), %lu guesses rejected, %.1f MB out (%.1f MB decoded as bytes); "
-                        "producer: search %.3f s, decode + markers %.3f s, chain %.3f s, waiting for the reader %.3f s; threads: search %.3f s, decode %.3f s, markers + CRC %.3f s\n",
+                        "producer: search %.3f s, decode + markers (device mode: waiting for chunks) %.3f s, chain %.3f s, waiting for the reader %.3f s; "
+                        "threads: search %.3f s, decode %.3f s, markers + CRC %.3f s\n",
                         threads_, chunk_ >> 10, (unsigned long)stats.batches, (unsigned long)stats.chunks, (unsigned long)stats.dropped,
                         (unsigned long)stats.rejected, stats.out_bytes / 1e6, stats.as_bytes / 1e6, stats.t_search, stats.t_decode, stats.t_chain, stats.t_wait,
                         stats.t_find, stats.t_busy, stats.t_resolve);
@@ -140,9 +147,10 @@ class ParInflate {
 
     // ---------------------------------------------------------------- device mode
     // Steps 1-3 as above; step 4 -- markers into bytes, the CRC-32 -- is the CALLER's (on the GPU: tagdig.hip
-    // count_gzip_dev).  A batch that has been decoded and chained is handed over as pieces of symbols (or, for the
-    // batch's first chunk, bytes) with the 32 KiB window each chunk's markers point into; the caller uploads them,
-    // calls dev_release() as soon as the buffers may be decoded into again, and dev_check() with the pieces' CRC-32s.
+    // count_gzip_dev).  What has been decoded and chained is handed over in batches: pieces of symbols (or bytes: chunks
+    // decoded with a known window, and the part of a chunk behind its last marker) with the 32 KiB window each chunk's
+    // markers point into; the caller uploads them, calls dev_release() as soon as the buffers may be decoded into
+    // again, and dev_check() with the pieces' CRC-32s.
     struct DevPiece {
         const void *src;          // len symbols (uint16_t), or len bytes when `narrow`
         size_t len;

@@ -146,7 +146,8 @@ struct td_handle {
     int device = 0;
     int num_cu = 256;
     hipStream_t copy_stream = nullptr, work_stream = nullptr;
-    // (count_gzip_dev: one copy engine moves 22-25 GB/s out of pinned memory on the far socket, two or three together 50)
+    // (one copy engine moves 22-30 GB/s out of pinned memory that lies on the far socket, two or three together 50: large
+    // uploads are spread over copy_stream and these; TAGDIG_COPY_STREAMS = 1..3, default 3)
     hipStream_t side_copy[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr};
     // index
     bool have_index = false;
@@ -639,6 +640,10 @@ int td_create(td_handle **out, int device_id) {
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(hipStreamCreateWithFlags(&h->side_copy[k], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->side_done[k], hipEventDisableTiming));
+    }
     HIPCHK(hipStreamCreateWithFlags(&h->work_stream, hipStreamNonBlocking));
     int rc = h->d_stats.ensure(STATS_SLOTS); if (rc) { delete h; return rc; }
     rc = h->d_ticket.ensure(4); if (rc) { delete h; return rc; }
@@ -837,6 +842,26 @@ int td_count_lines_device(td_handle *h, const void *d_fastq, uint64_t nbytes, vo
 
 // ---- host buffers and files: pieces cut at line ends, staged through pinned memory
 namespace {
+int copy_lanes() {
+    static const int n = getenv("TAGDIG_COPY_STREAMS") ? std::max(1, std::min(3, atoi(getenv("TAGDIG_COPY_STREAMS")))) : 3;
+    return n;
+}
+// host -> device on the copy stream, large ones in up to three parts side by side on the handle's other copy streams; what is
+// queued on copy_stream afterwards (an event, say) comes after all of it
+int upload(td_handle *h, void *dst, const void *src, size_t n) {
+    const int lanes = n >= ((size_t)4 << 20) ? copy_lanes() : 1;
+    const size_t part = ((n + lanes - 1) / lanes + 4095) & ~(size_t)4095;
+    for (int k = 1; k < lanes; k++) {
+        const size_t off = std::min(n, (size_t)k * part), len = std::min(n, off + part) - off;
+        if (!len) continue;
+        HIPCHK(hipMemcpyAsync((uint8_t *)dst + off, (const uint8_t *)src + off, len, hipMemcpyHostToDevice, h->side_copy[k - 1]));
+        HIPCHK(hipEventRecord(h->side_done[k - 1], h->side_copy[k - 1]));
+    }
+    HIPCHK(hipMemcpyAsync(dst, src, std::min(n, part), hipMemcpyHostToDevice, h->copy_stream));
+    for (int k = 1; k < lanes; k++) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->side_done[k - 1], 0));
+    return TD_OK;
+}
+
 struct Stager {
     td_handle *h = nullptr;
     static constexpr int NB = 3;
@@ -883,7 +908,7 @@ struct Stager {
     // from piece to piece through d_cursor[pieces & 1] on the device
     int submit(size_t n, uint64_t max_reads, int weights) {
         if (n == 0) return TD_OK;
-        HIPCHK(hipMemcpyAsync(dev[cur], pin[cur], n, hipMemcpyHostToDevice, h->copy_stream));
+        { const int rc = upload(h, dev[cur], pin[cur], n); if (rc) return rc; }
         HIPCHK(hipEventRecord(copied[cur], h->copy_stream));
         HIPCHK(hipStreamWaitEvent(h->work_stream, copied[cur], 0));
         int rc = launch_count(h, dev[cur], n, first_line, max_reads, weights, h->work_stream,
@@ -1105,7 +1130,7 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
             const size_t want = std::min(piece_cap, nin + 64 - off), have = off < nin ? std::min(want, nin - off) : 0;
             if (have) stage_parallel(have, [&](size_t o2, size_t len) { memcpy(zp.pin + o2, src.map + first + off + o2, len); return true; });
             if (want > have) memset(zp.pin + have, 0, want - have);
-            HIPCHK(hipMemcpyAsync(z.d_in + off, zp.pin, want, hipMemcpyHostToDevice, h->copy_stream));
+            { const int urc = upload(h, z.d_in + off, zp.pin, want); if (urc) return urc; }
             HIPCHK(hipEventRecord(zp.sent, h->copy_stream));
             zp.busy = true;
         }
@@ -1223,11 +1248,7 @@ int count_gzip_dev(td_handle *h, const char *path, uint64_t max_reads, int weigh
         if (!g.copied) HIPCHK(hipEventCreateWithFlags(&g.copied, hipEventDisableTiming | hipEventBlockingSync));
         if (!g.done) HIPCHK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming | hipEventBlockingSync));
     }
-    for (int k = 0; k < 2; k++) {
-        if (!h->side_copy[k]) HIPCHK(hipStreamCreateWithFlags(&h->side_copy[k], hipStreamNonBlocking));
-        if (!h->side_done[k]) HIPCHK(hipEventCreateWithFlags(&h->side_done[k], hipEventDisableTiming));
-    }
-    static const int copy_streams = getenv("TAGDIG_GZ_COPY_STREAMS") ? std::max(1, std::min(3, atoi(getenv("TAGDIG_GZ_COPY_STREAMS")))) : 3;
+    const int copy_streams = copy_lanes();
     struct Batch {
         bool valid = false, last = false, member_done = false;
         uint32_t want_crc = 0, nblk = 0;
@@ -1520,7 +1541,7 @@ int td_load_file_range(td_handle *h, const char *path, uint64_t offset, uint64_t
             return true;
         });
         if (!ok) return fail(TD_E_IO, "read error (or the file is shorter than offset + length)");
-        HIPCHK(hipMemcpyAsync((uint8_t *)d_dst + pos, lp.pin, n, hipMemcpyHostToDevice, h->copy_stream));
+        { const int urc = upload(h, (uint8_t *)d_dst + pos, lp.pin, n); if (urc) return urc; }
         HIPCHK(hipEventRecord(lp.sent, h->copy_stream));
         lp.busy = true;
     }
@@ -1607,7 +1628,7 @@ int td_bgzf_inflate_range(td_handle *h, const char *path, uint64_t off_begin, ui
             const size_t want = std::min(piece_cap, nin + 64 - off), have = off < nin ? std::min(want, nin - off) : 0;
             if (have) stage_parallel(have, [&](size_t o2, size_t len) { memcpy(zp.pin + o2, src.map + first + off + o2, len); return true; });
             if (want > have) memset(zp.pin + have, 0, want - have);
-            HIPCHK(hipMemcpyAsync(z.d_in + off, zp.pin, want, hipMemcpyHostToDevice, h->copy_stream));
+            { const int urc = upload(h, z.d_in + off, zp.pin, want); if (urc) return urc; }
             HIPCHK(hipEventRecord(zp.sent, h->copy_stream));
             zp.busy = true;
         }
