@@ -247,7 +247,8 @@ int64_t td_format_csv_row(const int64_t *vals, uint64_t n, char *out, uint64_t c
  *   "kernel"         main pass of the free-running path: 2 (default) k_fast2 -- raw tile in LDS, lines packed by the
  *                    lane that matches them, hot-cell cache (kernel_fast2.hpp); 1 k_fast (kernel_fast.hpp)
  *   "tile_kb2"       k_fast2's tile: 0 (default: chosen from the barcode index's LDS footprint) | 16 | 24 | 32
- *   "hot_cache"      1 (default): k_fast2 counts through its per-wave cache of hot cells in LDS
+ *   "hot_cache"      1 (default): k_fast2 counts through its per-wave cache of hot cells in LDS (a wave rests its cache
+ *                    while hardly anything hits); 0: plain atomics; 2: the cache never rests (measurements)
  *   "run"            consecutive tiles a workgroup of k_fast2 takes per turn (default 8): the line phase is carried
  *                    inside a run, only its first tile votes
  *   "stagger"        start-up stagger of co-resident workgroups, in 4096-cycle units (default 0)

@@ -624,7 +624,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
             if (hc_on) {
                 hc_flush(p.counts, hcS, (uint32_t)lane);
                 // a wave commits ~TILE / 4 / 300 hits a tile: below ~3 % of them cached, the cache is only overhead
-                if (hc_hits * 32u < HC_AGE_TILES * (TILE / 1200u)) { hc_on = false; hc_rest = HC_REST; }
+                if (p.hot_cache != 2u && hc_hits * 32u < HC_AGE_TILES * (TILE / 1200u)) { hc_on = false; hc_rest = HC_REST; }   // (2: never, for measurements)
                 hc_hits = 0;
             } else if (--hc_rest == 0) hc_on = true;
         }

@@ -1749,7 +1749,7 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
         if (value != 0 && value != 16 && value != 24 && value != 32) return fail(TD_E_ARG, "tile_kb2 must be 0 (automatic), 16, 24 or 32");
         if (value && h->have_index && lds_bytes_fast2(h, (int)value) > LDS_BUDGET) return fail(TD_E_LIMIT, "tile does not fit the LDS budget with this index");
         h->tile_kb2 = (int)value;
-    } else if (n == "hot_cache") h->hot_cache = value ? 1 : 0;
+    } else if (n == "hot_cache") h->hot_cache = value == 2 ? 2 : value ? 1 : 0;
     else if (n == "run") h->run = (int)std::max<int64_t>(1, std::min<int64_t>(value, 4096));
     else if (n == "progress") h->progress = value ? 1 : 0;
     else if (n == "zb_members") h->zb_members = (uint32_t)std::max<int64_t>(64, value);
