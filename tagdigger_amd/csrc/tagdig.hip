@@ -1201,6 +1201,7 @@ namespace {
 struct PinnedPool {
     std::mutex mu;
     std::vector<std::pair<void *, size_t>> free_blocks;
+    std::vector<void *> unpinned;
     size_t held = 0;
     static constexpr size_t KEEP = (size_t)3 << 30;
     void *alloc(size_t n) {
@@ -1215,12 +1216,18 @@ struct PinnedPool {
                 }
         }
         void *p = nullptr;
-        if (hipHostMalloc(&p, n, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipHostMalloc(&p, n, hipHostMallocPortable) == hipSuccess) return p;
+        // (no more memory can be pinned -- a locked-memory limit, say: ordinary pages then, which the copies stage themselves)
+        (void)hipGetLastError();
+        p = aligned_alloc(4096, (n + 4095) & ~(size_t)4095);
+        if (p) { std::lock_guard<std::mutex> g(mu); unpinned.push_back(p); }
         return p;
     }
     void release(void *p, size_t n) {
         {
             std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < unpinned.size(); i++)
+                if (unpinned[i] == p) { unpinned.erase(unpinned.begin() + (long)i); free(p); return; }
             // (blocks come back with the size they were asked for: the decoder rounds to 2 MiB both times)
             if (held + n <= KEEP) { free_blocks.emplace_back(p, n); held += n; return; }
         }
