@@ -290,3 +290,21 @@ def test_lane_decoder_against_zlib():
             b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
         inflate(bytes(b), len(data))
     assert inflate(comp[:len(comp) // 2], len(data))[0] != 0
+
+
+def test_random_streams_through_both_forms_of_the_parallel_decoder(decoder):
+    """tests/repro/gzip_pipeline_fuzz.py for TD_FUZZ_SECONDS (default 15) in a child process with a deadline: members of
+    independently compressed pieces (every strategy, stored blocks, sync and full flushes), one to three members, random
+    chunk sizes / thread counts, damaged copies -- equal to zlib's bytes or an error, and never a hang."""
+    import subprocess
+    import sys
+    if decoder != "sequential":
+        pytest.skip("once is enough (the script sets the decoder's environment itself)")
+    seconds = float(os.environ.get("TD_FUZZ_SECONDS", "15"))
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "repro", "gzip_pipeline_fuzz.py")
+    try:
+        r = subprocess.run([sys.executable, script, str(seconds), "20261004"], capture_output=True, text=True, timeout=seconds + 120)
+    except subprocess.TimeoutExpired as e:
+        raise AssertionError("the decoder hung: " + str(e.stdout)[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 failures" in r.stdout
