@@ -172,3 +172,57 @@ def test_damaged_gzip_raises_and_the_engine_goes_on(eng, sample, tmp_path, monke
         eng.reset()
         eng.count_file(path)
         _check(eng, want, ost, "after the damaged ones")
+
+
+def test_gzip_fuzz_campaign(eng, tmp_path, monkeypatch):
+    """TD_FUZZ_SECONDS (default 20) of random cases through the GPU-resolved gzip path against the C oracle on the plain bytes:
+    irregular FASTQ (every terminator style, blank and long lines, phase shifts) so that batches end inside lines, inside
+    \\r\\n pairs and inside runs of blank lines; members of independently compressed pieces (levels, strategies, stored blocks,
+    sync and full flushes), one to three members; chunk sizes from 1 KiB, two to eight decoder threads."""
+    import time
+    from helpers import dirty_fastq, small_index
+    budget = float(os.environ.get("TD_FUZZ_SECONDS", "20"))
+    seed0 = int(os.environ.get("TD_FUZZ_SEED", "424242"))
+    monkeypatch.setenv("TAGDIG_PAR_INFLATE", "1")
+    path = str(tmp_path / "f.fq.gz")
+    t_end, next_note, ncase = time.time() + budget, time.time() + 30, 0
+
+    def member(rnd, data):
+        pieces, pos = [], 0
+        while True:
+            n = min(len(data) - pos, rnd.choice([1, 300, 7000, 90000, 600000]))
+            last = pos + n >= len(data)
+            co = zlib.compressobj(rnd.choice([0, 1, 6, 9]), zlib.DEFLATED, -15, rnd.choice([1, 8, 9]),
+                                  rnd.choice([zlib.Z_DEFAULT_STRATEGY] * 4 + [zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE]))
+            part = data[pos:pos + n]
+            body = co.compress(part[:n // 2]) + (co.flush(zlib.Z_SYNC_FLUSH) if rnd.random() < 0.3 else b"") + co.compress(part[n // 2:])
+            pieces.append(body + co.flush(zlib.Z_FINISH if last else zlib.Z_FULL_FLUSH))
+            pos += n
+            if last:
+                return _member(data, b"".join(pieces))
+
+    while time.time() < t_end:
+        rnd = random.Random(seed0 + ncase)
+        cutsite = rnd.choice(["TGCAG", "CWGC", ""])
+        nl = rnd.choice([("\n",), ("\r\n",), ("\r",), ("\n", "\r\n", "\r")])
+        barcodes, tags, cutsites = small_index(rnd, cutsite, nbar=rnd.randint(1, 12), ntag=rnd.randint(1, 60))
+        datas = [dirty_fastq(rnd, barcodes, tags, cutsites, nrec=rnd.choice([1, 50, 3000, 20000]), nl_choices=nl,
+                             long_lines=rnd.random() < 0.3, permanent_shifts=rnd.random() < 0.3) for _ in range(rnd.choice([1, 1, 2, 3]))]
+        raw = b"".join(datas)
+        with open(path, "wb") as fh:
+            fh.write(b"".join(member(rnd, d) for d in datas))
+        ost = {}
+        want = c_oracle.COracle(barcodes, tags, cutsite).count_bytes(raw, stats=ost)
+        monkeypatch.setenv("TAGDIG_INFLATE_CHUNK", str(rnd.choice([1024, 3000, 17000, 65536, 1 << 20])))
+        monkeypatch.setenv("TAGDIG_INFLATE_THREADS", str(rnd.choice([2, 3, 8])))
+        monkeypatch.setenv("TAGDIG_INFLATE_OVERSUB", str(rnd.choice([1, 2, 4])))
+        eng.set_index(barcodes, tags, cutsite)
+        eng.reset()
+        eng.count_file(path)
+        _check(eng, want, ost, ("seed", seed0 + ncase))
+        ncase += 1
+        if time.time() >= next_note:
+            print(" [%d cases so far] " % ncase, end="", flush=True)
+            next_note = time.time() + 30
+    print(" [gzip fuzz campaign: %d cases] " % ncase, end="")
+    assert ncase > 0
