@@ -626,6 +626,9 @@ extern "C" {
 const char *td_last_error(void) { return g_err.c_str(); }
 uint32_t td_last_bad_index(void) { return g_bad; }
 
+}  // extern "C"
+namespace { void handle_born(); void handle_gone(); }   // (the pinned pool of the gzip decoder follows the handles' lives: below)
+extern "C" {
 int td_create(td_handle **out, int device_id) {
     if (!out) return fail(TD_E_ARG, "out is NULL");
     int n = 0;
@@ -650,11 +653,13 @@ int td_create(td_handle **out, int device_id) {
     rc = h->d_cursor.ensure(2); if (rc) { delete h; return rc; }
     HIPCHK(hipMemset(h->d_stats.p, 0, STATS_SLOTS * 8));
     *out = h;
+    handle_born();
     return TD_OK;
 }
 
 void td_destroy(td_handle *h) {
     if (!h) return;
+    handle_gone();
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
@@ -1223,6 +1228,11 @@ struct PinnedPool {
         if (p) { std::lock_guard<std::mutex> g(mu); unpinned.push_back(p); }
         return p;
     }
+    void trim() {                                // (blocks a decoder still holds are not in the list)
+        std::vector<std::pair<void *, size_t>> idle;
+        { std::lock_guard<std::mutex> g(mu); idle.swap(free_blocks); held = 0; }
+        for (auto &b : idle) (void)hipHostFree(b.first);
+    }
     void release(void *p, size_t n) {
         {
             std::lock_guard<std::mutex> g(mu);
@@ -1235,6 +1245,9 @@ struct PinnedPool {
     }
 };
 PinnedPool g_pinned;
+std::atomic<int> g_handles{0};                   // (the last handle to go gives the pool's idle blocks back: td_destroy)
+void handle_born() { g_handles++; }
+void handle_gone() { if (--g_handles == 0) g_pinned.trim(); }
 const tdhost::ParInflate::Allocator g_pinned_alloc = {
     [](size_t n) -> void * { return g_pinned.alloc(n); },
     [](void *p, size_t n) { g_pinned.release(p, n); }};
