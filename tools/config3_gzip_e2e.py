@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """BASELINE configs[2] as written, once: ONE gzip file (one member, one DEFLATE stream) of the canonical synthetic
 stream -- 200 M reads x 384 barcodes x 100 k tags, 43.8 GB of FASTQ -- counted end to end by
-find_tags_fastq's file path (gzip.open of the reference, tagdigger_fun.py:240-243 -> td_count_file: the host's
-chunk-parallel inflater -> pinned pieces -> hipMemcpyAsync overlapped with counting), the whole matrix checked
-against the generator's expectation.
+find_tags_fastq's file path (gzip.open of the reference, tagdigger_fun.py:240-243 -> td_count_file: DEFLATE decoded into
+symbols by the host's threads as a pipeline, the symbols uploaded from pinned memory, markers -> bytes and the CRC-32 on
+the GPU, counted where they land; TAGDIG_GPU_RESOLVE=0: all of it on the host as in rounds 1-2), the whole matrix
+checked against the generator's expectation.  TAGDIG_INFLATE_STATS=1 prints where the time went.
 
   tools/config3_gzip_e2e.py [reads] [dir]      (default 200 000 000, $TMPDIR or /tmp)
 
