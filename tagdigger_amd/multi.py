@@ -188,10 +188,53 @@ def _bgzf_member_bytes(path, off, end):
     return b"".join(out)
 
 
+def _count_one_stream(path, barcodes, tags, cutsite, bound, counter, dev, as_array, progress):
+    """An ordinary gzip file (one DEFLATE stream: no place to cut it without decoding everything before) under
+    count_file_sharded: the reference reads any .gz by name (:240-241), so it is counted -- by rank 0 alone, through
+    td_count_file (decoded by its host's threads, resolved on its GPU), the other ranks adding zeros to the same
+    all-reduce.  One library per rank (find_tags_fastq_many) or bgzip is the way to use every GPU."""
+    import gzip
+    import sys
+    rank, world = _rank_world()
+    if rank == 0 and world > 1:
+        print("tagdigger_amd: %s is one gzip stream and cannot be shared out; rank 0 reads it alone "
+              "(bgzip-compressed files are sharded by members)" % path, file=sys.stderr)
+    if counter is not None:
+        out = np.zeros((len(barcodes), len(tags)), dtype=np.int64)
+        if rank == 0:
+            with gzip.open(path, "rb") as fh:
+                data = fh.read()
+            out += np.asarray(counter(data, barcodes, tags, cutsite, 0, bound), dtype=np.int64).reshape(out.shape)
+        if world > 1:
+            dist.all_reduce(torch.from_numpy(out), op=dist.ReduceOp.SUM)
+        return out if as_array else out.tolist()
+    from . import tagdigger_fun
+    eng = tagdigger_fun.default_engine(dev.index)
+    eng.set_index(barcodes, tags, cutsite)
+    eng.set_option("progress", 1 if progress and rank == 0 else 0)
+    total = torch.zeros(len(barcodes) * len(tags), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    eng.bind_counts(total.data_ptr())
+    try:
+        if rank == 0:
+            eng.count_file(path, maxreads=bound)
+        eng.stats()                                            # (synchronises; raises what a kernel flagged)
+        if progress and rank == 0:
+            for line in eng.progress_lines(path):
+                print(line)
+    finally:
+        eng.bind_counts(0)
+        eng.set_option("progress", 0)
+    if world > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    out = total.cpu().numpy().view(np.uint32).astype(np.int64).reshape(len(barcodes), len(tags))
+    return out if as_array else out.tolist()
+
+
 def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, counter=None, device=None, as_array=False,
                        progress=False):
     """find_tags_fastq on one FASTQ file -- plain, or BGZF-compressed (bgzip) -- sharded over the ranks of the default
-    process group (every rank calls this with the same arguments; backend "nccl" = RCCL for GPUs).
+    process group; any other gzip file is counted by rank 0 alone (_count_one_stream) (every rank calls this with the same arguments; backend "nccl" = RCCL for GPUs).
     Returns the whole file's matrix on every rank, bit-identical to the single-GPU result for any
     number of ranks.
 
@@ -248,7 +291,9 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
         try:
             moff, misz = bgzf_index(path)
         except Exception:
-            raise ValueError("sharding a compressed file needs BGZF (bgzip); split other gzip input per library instead")
+            moff = None
+        if moff is None:
+            return _count_one_stream(path, barcodes, tags, cutsite, bound, counter, dev if use_gpu else None, as_array, progress)
         fsize = os.path.getsize(path)
         ends = np.append(moff[1:], np.uint64(fsize))
         gpos = np.concatenate(([0], np.cumsum(misz.astype(np.int64))))            # inflated offset of every member (and the total)

@@ -305,15 +305,24 @@ def test_ranks_shard_one_bgzf_file(tmp_path, world, block, maxreads):
     assert torch.load(out) == want
 
 
-def test_sharding_refuses_a_gzip_file_that_is_not_bgzf(tmp_path):
+@pytest.mark.parametrize("world,maxreads", [(1, 5e9), (2, 5e9), (3, 200)])
+def test_an_ordinary_gzip_file_is_counted_by_rank_0(tmp_path, world, maxreads):
+    """A gzip file that is not BGZF has no place to cut it: count_file_sharded counts it all the same (the reference reads
+    any .gz by name, :240-241) -- rank 0 alone, the other ranks adding zeros to the same all-reduce."""
     import gzip
-    from tagdigger_amd import multi
-    path, data, barcodes, tags = _dirty_file(tmp_path, "mixed")
+    from oracle import c_oracle
+    path, data, barcodes, tags = _dirty_file(tmp_path, "mixed", seed=5)
     gz = path + ".gz"
     with gzip.open(gz, "wb") as fh:
         fh.write(data)
-    with pytest.raises(ValueError):
-        multi.count_file_sharded(gz, barcodes, tags, "TGCAG", counter=_oracle_shard_counter)
+    want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data, maxreads=maxreads).tolist()
+    if world == 1:
+        from tagdigger_amd import multi
+        assert multi.count_file_sharded(gz, barcodes, tags, "TGCAG", maxreads=maxreads, counter=_oracle_shard_counter) == want
+        return
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_bgzf_worker, args=(world, _free_port(), gz, barcodes, tags, maxreads, out), nprocs=world, join=True)
+    assert torch.load(out) == want
 
 
 def _device_bgzf_worker(rank, world, port, path, barcodes, tags, maxreads, out):
@@ -337,6 +346,25 @@ def test_device_path_member_sharded_bgzf_file(tmp_path, block, maxreads):
     from oracle import c_oracle
     from tagdigger_amd import multi
     gz, data, barcodes, tags = _bgzf_file(tmp_path, "mixed", block, seed=11)
+    want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data, maxreads=maxreads).tolist()
+    assert multi.count_file_sharded(gz, barcodes, tags, "TGCAG", maxreads=maxreads, device=0) == want
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_device_bgzf_worker, args=(2, _free_port(), gz, barcodes, tags, maxreads, out), nprocs=2, join=True)
+    assert torch.load(out) == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maxreads", [5e9, 300])
+def test_device_path_counts_an_ordinary_gzip_file_on_rank_0(tmp_path, maxreads, capfd):
+    """The product path on a gzip file that is not BGZF: rank 0 counts it through td_count_file, the other rank adds zeros;
+    one process, then two ranks rehearsing on GPU 0 (rank 0 says on stderr that it reads the file alone)."""
+    import gzip
+    from oracle import c_oracle
+    from tagdigger_amd import multi
+    path, data, barcodes, tags = _dirty_file(tmp_path, "mixed", seed=5)
+    gz = path + ".gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(data)
     want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data, maxreads=maxreads).tolist()
     assert multi.count_file_sharded(gz, barcodes, tags, "TGCAG", maxreads=maxreads, device=0) == want
     out = str(tmp_path / "res.pt")
