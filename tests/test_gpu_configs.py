@@ -106,6 +106,15 @@ def test_skewed_hits(eng, s):
         eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
         eng.count_device(d, nb)
         check(eng, want, ost, ("skew", s))
+        # the same with the hot-cell cache off, and with a cache that never rests (a measurement setting)
+        try:
+            for hc in (0, 2):
+                eng.set_option("hot_cache", hc)
+                eng.reset()
+                eng.count_device(d, nb)
+                check(eng, want, ost, ("skew", s, "hot_cache", hc))
+        finally:
+            eng.set_option("hot_cache", 1)
         # and the device-side expected matrix the bench checks against
         dw = eng.dev_alloc(want.size * 4)
         try:
