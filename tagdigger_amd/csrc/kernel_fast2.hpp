@@ -297,10 +297,12 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
 
     uint4 v[CPT];
     const bool has_halo = (uint32_t)tid < halo / 16u;
+    const uint32_t hoff = has_halo ? (uint32_t)tid * 16u : 0x40000000u;      // (beyond every descriptor's range: reads as zero)
     auto tile_base = [&](uint32_t tile) -> const uint8_t * {
         return tile >= p.tail_tile ? p.tail_buf + (uint64_t)(tile - p.tail_tile) * TILE : p.buf + (uint64_t)tile * TILE;
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t misc_addr = (uint32_t)(uintptr_t)L_misc;             // (LDS byte address: the low half of the flat address)
     const uint32_t voff = (uint32_t)wave * WBYTES + (uint32_t)lane * 16u;    // this thread's first chunk; load j is 1 KiB further
     auto tile_rsrc = [&](uint32_t tile) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base(tile)), 0, (int)(TILE + 4096u), 0x00020000);
@@ -355,12 +357,12 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         TD_STAMP(0);   // loop head
         // ---------------- A: this wave's quarter: raw bytes and terminator masks -> LDS
         bool wave_crb = false;           // a chunk of this wave ends with '\r' (wave-uniform)
+        // the halo (the first bytes of the next tile): requested now by EVERY lane -- the lanes without a halo chunk ask
+        // for an offset beyond the descriptor's range, which returns zeros without touching memory -- so that the load
+        // is unconditional straight-line code and the waits for this tile's own bytes (older loads) can leave it in
+        // flight; it is consumed after phase B and the pending line, just before the next tile's loads are issued
+        const u32x4 vhq = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(t), hoff, (int)TILE, 0);
         {
-            uint4 vh = make_uint4(0u, 0u, 0u, 0u);
-            if (has_halo) {
-                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(t), (uint32_t)tid * 16u, (int)TILE, 0);
-                vh = make_uint4(q.x, q.y, q.z, q.w);
-            }
             uint32_t hiacc = 0;
 #pragma unroll
             for (int j = 0; j < CPT; j++) hiacc |= v[j].x | v[j].y | v[j].z | v[j].w;
@@ -396,11 +398,6 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                 }
                 wave_crb = __any((crs & 0x8000u) != 0);
                 if (hiacc & 0x80808080u) L_misc[1] = 1;
-            }
-            if (has_halo) {
-                *reinterpret_cast<uint4 *>(L_raw + TILE + (size_t)tid * 16u) = vh;
-                // (lines that begin in this tile are packed from these bytes with the ASCII forms)
-                if ((vh.x | vh.y | vh.z | vh.w) & 0x80808080u) L_misc[3] = 1;
             }
         }
         wave_lds_fence();          // this wave's masks and raw bytes are in LDS (nothing of another wave is read before the barrier)
@@ -514,6 +511,12 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
             if (prog) sums_add(parity ^ 1u, (uint32_t)__builtin_popcountll(__ballot(tagged)) << 16);
         }
         TD_STAMP(3);   // pending line: wait for its bucket, compares
+        vm_settled();                                       // (the halo: requested a phase A and a phase B ago)
+        if (has_halo) {
+            *reinterpret_cast<uint4 *>(L_raw + TILE + (size_t)tid * 16u) = make_uint4(vhq.x, vhq.y, vhq.z, vhq.w);
+            // (lines that begin in this tile are packed from these bytes with the ASCII forms)
+            if ((vhq.x | vhq.y | vhq.z | vhq.w) & 0x80808080u) L_misc[3] = 1;
+        }
         if (nit < nwork) fetch_tile(nit);
         if (PIPE) {
             if (hc_on) {
@@ -529,13 +532,21 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         __builtin_amdgcn_s_setprio(TD_P_D);
 
         // ---------------- C: the tile's phase and the waves' running totals
-        const uint4 tot4 = *reinterpret_cast<const uint4 *>(L_misc + 4), pk4 = *reinterpret_cast<const uint4 *>(L_misc + 8);
-        const uint4 flg4 = *reinterpret_cast<const uint4 *>(L_misc);
-        const uint32_t wb1 = tot4.x, wb2 = wb1 + tot4.y, wb3 = wb2 + tot4.z, total = wb3 + tot4.w;
+        // (flags and wave totals: two reads issued together and waited for once -- left to the compiler they become
+        // four scalarised reads, each waited for before the next is issued)
+        u32x4 flgq, totq;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(flgq), "=&v"(totq) : "v"(misc_addr) : "memory");
+        const uint32_t t_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)totq.x), t_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)totq.y),
+                       t_z = (uint32_t)__builtin_amdgcn_readfirstlane((int)totq.z), t_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)totq.w);
+        const uint4 flg4 = make_uint4(0u, (uint32_t)__builtin_amdgcn_readfirstlane((int)flgq.y), (uint32_t)__builtin_amdgcn_readfirstlane((int)flgq.z),
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)flgq.w));
+        const uint32_t wb1 = t_x, wb2 = wb1 + t_y, wb3 = wb2 + t_z, total = wb3 + t_w;
         uint32_t r0;
         if (carry_ok) {
             r0 = carry_r0;
         } else if (t != 0) {
+            const uint4 pk4 = *reinterpret_cast<const uint4 *>(L_misc + 8);
             auto rot = [](uint32_t pk, uint32_t by) { const uint32_t r = 8u * (by & 3u); return r ? ((pk << r) | (pk >> (32u - r))) : pk; };
             const uint32_t a = pk4.x, b = rot(pk4.y, wb1), c = rot(pk4.z, wb2), d = rot(pk4.w, wb3);
             const uint32_t v02 = (a & 0x00FF00FFu) + (b & 0x00FF00FFu) + (c & 0x00FF00FFu) + (d & 0x00FF00FFu);
