@@ -41,7 +41,14 @@ enum {
     TD_E_STATE = -9,      /* call order (no index set, ...)                               */
     TD_E_INTERNAL = -10,  /* look-back timeout or other should-not-happen condition       */
     TD_E_IO = -11,        /* file could not be opened / read / inflated                   */
-    TD_E_TASSEL = -12     /* tassel_tagcount: header without a parsable count= value      */
+    TD_E_TASSEL = -12,    /* tassel_tagcount: header without a parsable count= value      */
+    /* a .gz input ends the way gzip.open(fqfile, 'rt') ends it in the reference's loop
+     * (tagdigger_fun.py:240-243, :250; csrc/gz_pyrules.hpp): the binding raises the same class
+     * with the same message (td_last_error)                                               */
+    TD_E_GZ_EOF = -13,    /* the compressed stream stops before its end-of-stream marker: EOFError */
+    TD_E_GZ_BADFILE = -14,/* a member fails its CRC-32 / ISIZE check, or what follows a member is no
+                             gzip header: gzip.BadGzipFile (an OSError)                    */
+    TD_E_GZ_DATA = -15    /* invalid DEFLATE data: zlib.error                              */
 };
 
 /* stats[] slots filled by td_get_stats (all cumulative since td_reset) */
@@ -130,6 +137,14 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
  * device mode: dev_next / dev_release / dev_check), the markers resolved by the host -- so that the pipeline
  * can be tested where there is no GPU. */
 int td_gunzip_file(const char *path, void *dst, uint64_t capacity, uint64_t chunk, uint64_t *n_out);
+
+/* What the reference's loop over gzip.open(path, 'rt'), left at read number max_reads (:272-273), meets in this
+ * file (host only, no GPU): TD_OK -- it ends without an exception -- or TD_E_GZ_EOF / TD_E_GZ_BADFILE /
+ * TD_E_GZ_DATA with the exception's message in td_last_error.  td_count_file, td_gunzip_file and td_split_file
+ * ask this whenever one of their decoders has refused a file (csrc/gz_pyrules.hpp: Lib/gzip.py restated call for
+ * call over the same zlib); a file the reference reads to the bound although it is damaged further on is then
+ * counted through that reader.  TD_E_IO: the file cannot be opened. */
+int td_gzip_check(const char *path, uint64_t max_reads);
 
 /* Line terminators (\n, \r\n, bare \r) in a device buffer -- what a shard of a
  * byte-split file must know about the shards before it.  Synchronous. */

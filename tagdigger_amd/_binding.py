@@ -22,6 +22,7 @@ TD_E = {
     -1: "TD_E_HIP", -2: "TD_E_ARG", -3: "TD_E_OVERLAP", -4: "TD_E_EMPTY", -5: "TD_E_ROOTLEAF",
     -6: "TD_E_ALPHABET", -7: "TD_E_LIMIT", -8: "TD_E_NONASCII", -9: "TD_E_STATE",
     -10: "TD_E_INTERNAL", -11: "TD_E_IO", -12: "TD_E_TASSEL",
+    -13: "TD_E_GZ_EOF", -14: "TD_E_GZ_BADFILE", -15: "TD_E_GZ_DATA",
 }
 
 
@@ -106,6 +107,7 @@ def load():
     sig("td_bgzf_index", i32, C.c_char_p, vp, vp, u64, C.POINTER(u64))
     sig("td_bgzf_inflate_range", i32, vp, C.c_char_p, u64, u64, vp, u64, C.POINTER(u64))
     sig("td_gunzip_file", i32, C.c_char_p, vp, u64, u64, C.POINTER(u64))
+    sig("td_gzip_check", i32, C.c_char_p, u64)
     sig("td_set_splitter", i32, vp, C.POINTER(C.c_char_p), u32, C.c_char_p, C.c_char_p, C.c_char_p,
         C.POINTER(u32), C.POINTER(C.c_char_p), C.POINTER(C.c_int32), u32)
     sig("td_split_device", i32, vp, vp, u64, u64, vp, u64, vp, C.POINTER(u64))
@@ -140,7 +142,7 @@ def runtime_path():
 EXPORTS = [
     "td_last_error", "td_last_bad_index", "td_create", "td_destroy", "td_set_index",
     "td_bind_counts", "td_reset", "td_count_device", "td_count_host", "td_count_file",
-    "td_count_lines_device", "td_load_file_range", "td_bgzf_index", "td_bgzf_inflate_range", "td_gunzip_file", "td_set_splitter", "td_split_device", "td_count_and_split_device", "td_split_file", "td_fold_rows", "td_inflate_raw_host", "td_format_csv_row", "td_get_counts", "td_get_stats", "td_get_progress", "td_split_progress", "td_set_option",
+    "td_count_lines_device", "td_load_file_range", "td_bgzf_index", "td_bgzf_inflate_range", "td_gunzip_file", "td_gzip_check", "td_set_splitter", "td_split_device", "td_count_and_split_device", "td_split_file", "td_fold_rows", "td_inflate_raw_host", "td_format_csv_row", "td_get_counts", "td_get_stats", "td_get_progress", "td_split_progress", "td_set_option",
     "td_kernel_time_ms", "td_kernel_times_ms", "td_debug_counters", "td_dev_alloc", "td_dev_free", "td_memcpy_h2d", "td_memcpy_d2h",
     "td_device_sync", "td_synth_fill_device", "td_synth_expected_device",
 ]
@@ -162,4 +164,13 @@ def check(rc):
         raise NonAsciiSequence(msg)
     if rc == -12:     # int() of a malformed count= header, reference :253
         raise ValueError(msg)
+    # a .gz input that ends the way gzip.open ends it in the reference (:240-243, :250): same class, same message
+    if rc == -13:
+        raise EOFError(msg)
+    if rc == -14:
+        import gzip
+        raise gzip.BadGzipFile(msg)
+    if rc == -15:
+        import zlib
+        raise zlib.error(msg)
     raise TagdigError(rc, msg)

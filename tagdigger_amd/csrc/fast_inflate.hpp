@@ -21,7 +21,7 @@ class FastInflate {
     static constexpr size_t PAD = 64;          // readable bytes the caller guarantees behind the input
 
     void open(const uint8_t *data, size_t n) {
-        in_ = data; in_end_ = data + n;
+        in_ = in_begin_ = data; in_end_ = data + n;
         bitbuf_ = 0; bitcnt_ = 0;
         state_ = S_MEMBER; failed_ = false;
         if (buf_.size() != HIST + CAP + SLACK) buf_.assign(HIST + CAP + SLACK, 0);     // (kept across open() calls)
@@ -88,7 +88,7 @@ class FastInflate {
     size_t crc_pos_ = 0;                       // staging offset up to which this member's CRC has been taken
     size_t valid_from_ = 0;                    // staging offset of the oldest byte a match may copy from (this member's output)
     // ---- input
-    const uint8_t *in_ = nullptr, *in_end_ = nullptr;
+    const uint8_t *in_ = nullptr, *in_end_ = nullptr, *in_begin_ = nullptr;
     uint64_t bitbuf_ = 0;
     uint32_t bitcnt_ = 0;
     // ---- state
@@ -232,19 +232,28 @@ class FastInflate {
 
     // ---- gzip framing
   public:
-    // the member header at p: 1 and *body (the first byte of the deflate stream); 0 where the stream ends
-    // (trailing zero bytes some tools leave and anything that is not a gzip header end it, as zlib's gzread
-    // treats them); -1 and *err on a bad header
-    static int parse_member_header(const uint8_t *p, const uint8_t *end, const uint8_t **body, const char **err) {
-        if (p + 18 > end || p[0] != 0x1f || p[1] != 0x8b) return 0;
+    // the member header at p (first: the file's first member): 1 and *body (the first byte of the deflate stream); 0 where
+    // the file ends -- at its end, behind the zero bytes gzip.open skips after a member; -1 and *err for anything else (the
+    // caller refuses the file, and gz_pyrules.hpp says how the reference ends on it: EOFError for a header cut short,
+    // gzip.BadGzipFile for bytes that are no header).  Reserved flag bits are ignored, as Lib/gzip.py ignores them.
+    static int parse_member_header(const uint8_t *p, const uint8_t *end, const uint8_t **body, const char **err, bool first = false) {
+        if (!first) while (p < end && *p == 0) p++;
+        if (p >= end) return 0;
+        if (end - p < 10) { *err = "truncated gzip header (or bytes that are none) behind a member"; return -1; }
+        if (p[0] != 0x1f || p[1] != 0x8b) { *err = "bytes that are no gzip header behind a member"; return -1; }
         if (p[2] != 8) { *err = "unknown compression method in a gzip header"; return -1; }
         const uint32_t flg = p[3];
-        if (flg & 0xE0) { *err = "reserved flag bits set in a gzip header"; return -1; }
         p += 10;
-        if (flg & 4) { if (p + 2 > end) { *err = "truncated gzip header"; return -1; } p += 2 + (p[0] | (p[1] << 8)); }
-        if (flg & 8) { while (p < end && *p) p++; p++; }
-        if (flg & 16) { while (p < end && *p) p++; p++; }
-        if (flg & 2) p += 2;
+        if (flg & 4) {
+            if (end - p < 2) { *err = "truncated gzip header"; return -1; }
+            const size_t xlen = (size_t)p[0] | ((size_t)p[1] << 8);
+            p += 2;
+            if ((size_t)(end - p) < xlen) { *err = "truncated gzip header"; return -1; }
+            p += xlen;
+        }
+        if (flg & 8) { while (p < end && *p) p++; if (p < end) p++; }
+        if (flg & 16) { while (p < end && *p) p++; if (p < end) p++; }
+        if (flg & 2) { if (end - p < 2) { *err = "truncated gzip header"; return -1; } p += 2; }
         if (p >= end) { *err = "truncated gzip header"; return -1; }
         *body = p;
         return 1;
@@ -254,7 +263,7 @@ class FastInflate {
     bool member_header() {
         byte_align();
         const uint8_t *body = nullptr;
-        const int r = parse_member_header(in_, in_end_, &body, &err_);
+        const int r = parse_member_header(in_, in_end_, &body, &err_, in_ == in_begin_);
         if (r < 0) return false;
         if (r == 0) { state_ = S_END; return true; }
         in_ = body;

@@ -625,7 +625,7 @@ class ParInflate {
 
     void begin_member(size_t at_byte) {
         const uint8_t *body = nullptr;
-        const int r = FI::parse_member_header(data_ + at_byte, data_ + n_, &body, &err_);
+        const int r = FI::parse_member_header(data_ + at_byte, data_ + n_, &body, &err_, at_byte == 0);
         if (r < 0) { failed_ = true; return; }
         if (r == 0) { end_ = true; return; }
         pos_ = (uint64_t)(body - data_) * 8;

@@ -27,6 +27,7 @@
 #include "kernel_splitter.hpp"
 #include "kernel_splitter2.hpp"
 #include "gz_source.hpp"
+#include "gz_pyrules.hpp"
 #include "gpu_inflate.hpp"
 #include "gz_resolve.hpp"
 
@@ -151,6 +152,7 @@ struct td_handle {
     hipStream_t side_copy[2] = {nullptr, nullptr}; hipEvent_t side_done[2] = {nullptr, nullptr};
     // index
     bool have_index = false;
+    bool counted = false;                     // something has been counted since the results were last zeroed
     uint32_t barnum = 0, ntags = 0;
     int W = 2;
     uint32_t nch = 0, maxwo = 0, halo = 128, m_bases = 32, nshort = 0, bucket_mask = 0;
@@ -358,6 +360,7 @@ int zero_results(td_handle *h) {
     std::fill(h->host_acc.begin(), h->host_acc.end(), 0);
     h->bytes_since_flush = 0;
     h->used64 = false;
+    h->counted = false;
     return TD_OK;
 }
 
@@ -384,6 +387,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     if (((uintptr_t)d_fastq & 15) != 0) return fail(TD_E_ARG, "device FASTQ pointer must be 16-byte aligned");
     if (nbytes == 0) return TD_OK;
     if (max_reads == 0) max_reads = 1;
+    h->counted = true;
     const bool tassel = weights != 0;
     // last countable sequence line: ordinal r (1-based) sits on line 4(r-1)+1
     const uint64_t limit_line = max_reads >= (1ull << 60) ? ~0ull - 8 : 4 * (max_reads - 1) + 1;
@@ -1114,8 +1118,10 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
         const size_t first = pos;
         while (pos < src.bsize && b.n < batch_members) {
             uint32_t bs = 0, hs = 0;
-            if (!tdhost::GzSource::bgzf_header(src.map + pos, src.bsize - pos, &bs, &hs) || bs < hs + 8 || pos + bs > src.bsize)
+            if (!tdhost::GzSource::bgzf_header(src.map + pos, src.bsize - pos, &bs, &hs) || bs < hs + 8 || pos + bs > src.bsize) {
+                if (tdhost::GzSource::only_zeros(src.map + pos, src.bsize - pos)) { pos = src.bsize; break; }     // (padding: gzip.open skips it)
                 return fail(TD_E_IO, "damaged BGZF member header (or a member that is not BGZF) in a file that began as BGZF");
+            }
             if (pos + bs - first > batch_in) break;
             const uint8_t *tail = src.map + pos + bs - 8;
             const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
@@ -1175,8 +1181,13 @@ int count_bgzf_gpu(td_handle *h, const char *path, uint64_t max_reads, int weigh
         size_t cut = total;
         if (!cur.last && total) {
             const size_t c = cut_at_line_end(z.pin_tail, ntail);
-            if (c == 0 || total - (total - ntail + c) > ZB_CARRY) return fail(TD_E_LIMIT, "a single line exceeds the staging buffer");
-            cut = total - ntail + c;
+            if (c == 0) {                                       // (no line end in sight: everything waits for the next batch)
+                if (total > ZB_CARRY) return fail(TD_E_LIMIT, "a single line exceeds the staging buffer");
+                cut = 0;
+            } else {
+                if (ntail - c > ZB_CARRY) return fail(TD_E_LIMIT, "a single line exceeds the staging buffer");
+                cut = total - ntail + c;
+            }
         }
         if (cut) {
             rc = launch_count(h, z.d_out, cut, 0, max_reads, weights, h->work_stream, h->d_cursor.p + (pieces & 1),
@@ -1377,8 +1388,15 @@ int count_gzip_dev(td_handle *h, const char *path, uint64_t max_reads, int weigh
         size_t cut = total;
         if (!cur.last && total) {
             const size_t c = cut_at_line_end(g.pin_tail, ntail);
-            if (c == 0 || total - (total - ntail + c) > ZB_CARRY) return fail(TD_E_LIMIT, "a single line exceeds the staging buffer");
-            cut = total - ntail + c;
+            if (c == 0) {
+                // no line end in sight -- a member that stops inside a line, followed by an empty one or one of a few bytes
+                // (a batch closes at every member end): everything waits for the next batch
+                if (total > ZB_CARRY) return fail(TD_E_LIMIT, "a single line exceeds the staging buffer");
+                cut = 0;
+            } else {
+                if (ntail - c > ZB_CARRY) return fail(TD_E_LIMIT, "a single line exceeds the staging buffer");
+                cut = total - ntail + c;
+            }
         }
         if (cut) {
             rc = launch_count(h, g.d_out.p, cut, 0, max_reads, weights, h->work_stream, h->d_cursor.p + (pieces & 1),
@@ -1400,9 +1418,73 @@ int count_gzip_dev(td_handle *h, const char *path, uint64_t max_reads, int weigh
                 (unsigned long)nbatch, up_bytes / 1e6, t_next, t_upload, t_sync);
     return TD_OK;
 }
+
+// ---- a .gz input one of the decoders has refused: what does the reference do with it?  (gz_pyrules.hpp)
+struct MappedFile {
+    const uint8_t *p = nullptr; size_t n = 0; bool ok = false;
+    explicit MappedFile(const char *path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return;
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { ::close(fd); return; }
+        n = (size_t)sb.st_size;
+        ok = true;
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ok = false; n = 0; } else { p = (const uint8_t *)m; (void)madvise(m, n, MADV_SEQUENTIAL); }
+        }
+        ::close(fd);
+    }
+    ~MappedFile() { if (p) munmap(const_cast<uint8_t *>(p), n); }
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+};
+int gz_code(int kind) { return kind == tdhost::GZ_EOF ? TD_E_GZ_EOF : kind == tdhost::GZ_BADFILE ? TD_E_GZ_BADFILE : TD_E_GZ_DATA; }
+bool gz_refusal(int rc) { return rc == TD_E_IO || rc == TD_E_LIMIT; }
+
+// The fast route's answer `rc` for a .gz file -> the reference's: its exception (class by the code, message in
+// td_last_error), or -- where its loop is through before the damage is met, or the file is merely something the fast
+// decoders do not take -- the counts, taken again through the reference's own reading rules.  That needs results that
+// held nothing before this file (find_tags_fastq's case); into a matrix that was already accumulating the fast route's
+// refusal stands.
+int count_gz_by_reference_rules(td_handle *h, const char *path, uint64_t max_reads, int weights, int rc, bool was_fresh) {
+    const std::string refusal = g_err;
+    MappedFile mf(path);
+    if (!mf.ok) return fail(rc, refusal);
+    const tdhost::GzVerdict v = tdhost::gz_verdict(mf.p, mf.n, max_reads);
+    if (v.kind != tdhost::GZ_OK) return fail(gz_code(v.kind), v.message);
+    if (!was_fresh)
+        return fail(rc, refusal + " (the reference's loop ends before it meets this; the results were accumulating, so the file is not counted again)");
+    int rc2 = zero_results(h); if (rc2) return rc2;
+    if (h->bound_counts) {
+        HIPCHK(hipMemsetAsync(h->bound_counts, 0, (size_t)h->barnum * h->ntags * 4, h->work_stream));
+        HIPCHK(hipStreamSynchronize(h->work_stream));
+    }
+    tdhost::PyGzipReader pr(mf.p, mf.n);
+    bool through = false;
+    auto reader = [&](uint8_t *dst, size_t want) -> long {
+        size_t done = 0;
+        while (done < want && !through) {
+            const long got = pr.read(dst + done, std::min<size_t>(tdhost::PyGzipReader::CHUNK, want - done));
+            if (got <= 0) { through = true; break; }              // (damage behind the bound: the verdict above says the loop never gets there)
+            done += (size_t)got;
+        }
+        return (long)done;
+    };
+    return pump(h, reader, 0, 0, max_reads, weights, nullptr);
+}
 }  // namespace
 
 extern "C" {
+
+int td_gzip_check(const char *path, uint64_t max_reads) {
+    if (!path) return fail(TD_E_ARG, "NULL argument");
+    MappedFile mf(path);
+    if (!mf.ok) return fail(TD_E_IO, std::string("cannot open ") + path);
+    const tdhost::GzVerdict v = tdhost::gz_verdict(mf.p, mf.n, max_reads);
+    if (v.kind != tdhost::GZ_OK) return fail(gz_code(v.kind), v.message);
+    return TD_OK;
+}
 
 int td_count_host(td_handle *h, const void *fastq, uint64_t nbytes, uint64_t first_line, uint64_t max_reads,
                   int weights, uint64_t *lines_out) {
@@ -1420,8 +1502,37 @@ int td_count_host(td_handle *h, const void *fastq, uint64_t nbytes, uint64_t fir
     return pump(h, reader, nbytes + 1, first_line, max_reads, weights, lines_out);
 }
 
+static int gunzip_fast(const char *path, void *dst, uint64_t capacity, uint64_t chunk, uint64_t *n_out);
 int td_gunzip_file(const char *path, void *dst, uint64_t capacity, uint64_t chunk, uint64_t *n_out) {
     if (!path || !dst || !n_out) return fail(TD_E_ARG, "NULL argument");
+    {
+        struct stat sb0;
+        if (stat(path, &sb0) == 0 && S_ISREG(sb0.st_mode) && sb0.st_size == 0) { *n_out = 0; return TD_OK; }     // (gzip.open: no data)
+    }
+    const int rc = gunzip_fast(path, dst, capacity, chunk, n_out);
+    if (rc != TD_E_IO) return rc;
+    // a decoder has refused the file: the reference's reading rules say how this ends (gz_pyrules.hpp)
+    const std::string refusal = g_err;
+    MappedFile mf(path);
+    if (!mf.ok) return fail(rc, refusal);
+    tdhost::PyGzipReader pr(mf.p, mf.n);
+    uint64_t n = 0;
+    uint8_t extra[tdhost::PyGzipReader::CHUNK];
+    for (;;) {
+        const bool full = n + tdhost::PyGzipReader::CHUNK > capacity;      // (a request's bytes may not fit any more: aside, then copied)
+        const long got = pr.read(full ? extra : (uint8_t *)dst + n, tdhost::PyGzipReader::CHUNK);
+        if (got < 0) return fail(gz_code(pr.kind), pr.message);
+        if (got == 0) break;
+        if (full) {
+            if (n + (uint64_t)got > capacity) return fail(TD_E_LIMIT, "destination too small");
+            memcpy((uint8_t *)dst + n, extra, (size_t)got);
+        }
+        n += (uint64_t)got;
+    }
+    *n_out = n;
+    return TD_OK;
+}
+static int gunzip_fast(const char *path, void *dst, uint64_t capacity, uint64_t chunk, uint64_t *n_out) {
     if (getenv("TAGDIG_GUNZIP_PIPELINE")) {
         // the decoder as count_gzip_dev drives it (dev_next / dev_release / dev_check), markers resolved by the host: the
         // pipeline can be checked where there is no GPU
@@ -1484,22 +1595,34 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
     const size_t len = strlen(path);
     const bool gz = len >= 2 && (path[len - 2] == 'g' || path[len - 2] == 'G') && (path[len - 1] == 'z' || path[len - 1] == 'Z');
     if (gz) {
-        static const bool env_off = getenv("TAGDIG_GPU_INFLATE") && atoi(getenv("TAGDIG_GPU_INFLATE")) == 0;
-        if (h->gpu_inflate && !env_off && !getenv("TAGDIG_ZLIB")) {          // BGZF: members inflated on the GPU
-            bool not_bgzf = false;
-            const int rc = count_bgzf_gpu(h, path, max_reads, weights, &not_bgzf);
-            if (rc || !not_bgzf) return rc;
-        }
-        static const bool resolve_off = getenv("TAGDIG_GPU_RESOLVE") && atoi(getenv("TAGDIG_GPU_RESOLVE")) == 0;
-        if (h->gpu_resolve && !resolve_off) {                                 // ordinary gzip: decoded on the host threads, resolved on the GPU
-            bool not_applicable = false;
-            const int rc = count_gzip_dev(h, path, max_reads, weights, &not_applicable);
-            if (rc || !not_applicable) return rc;
-        }
-        tdhost::GzSource src;
-        if (!src.open(path)) return fail(TD_E_IO, std::string("cannot open ") + path);
-        auto reader = [&](uint8_t *dst, size_t want) -> long { return src.read(dst, want); };
-        return pump(h, reader, 0, 0, max_reads, weights, nullptr);
+        const bool was_fresh = !h->counted;
+        auto fast = [&]() -> int {
+            {   // (an empty file: gzip.open reads it as no data at all)
+                struct stat sb0;
+                if (stat(path, &sb0) == 0 && S_ISREG(sb0.st_mode) && sb0.st_size == 0) return TD_OK;
+            }
+            static const bool env_off = getenv("TAGDIG_GPU_INFLATE") && atoi(getenv("TAGDIG_GPU_INFLATE")) == 0;
+            if (h->gpu_inflate && !env_off && !getenv("TAGDIG_ZLIB")) {          // BGZF: members inflated on the GPU
+                bool not_bgzf = false;
+                const int rc = count_bgzf_gpu(h, path, max_reads, weights, &not_bgzf);
+                if (rc || !not_bgzf) return rc;
+            }
+            static const bool resolve_off = getenv("TAGDIG_GPU_RESOLVE") && atoi(getenv("TAGDIG_GPU_RESOLVE")) == 0;
+            if (h->gpu_resolve && !resolve_off) {                                 // ordinary gzip: decoded on the host threads, resolved on the GPU
+                bool not_applicable = false;
+                const int rc = count_gzip_dev(h, path, max_reads, weights, &not_applicable);
+                if (rc || !not_applicable) return rc;
+            }
+            tdhost::GzSource src;
+            if (!src.open(path)) return fail(TD_E_IO, std::string("cannot open ") + path);
+            auto reader = [&](uint8_t *dst, size_t want) -> long { return src.read(dst, want); };
+            return pump(h, reader, 0, 0, max_reads, weights, nullptr);
+        };
+        const int rc = fast();
+        // a decoder has refused the file: the reference's own reading rules say how this ends (its exception, or -- the loop
+        // being through before the damage, or the file merely unusual -- its counts)
+        if (gz_refusal(rc)) return count_gz_by_reference_rules(h, path, max_reads, weights, rc, was_fresh);
+        return rc;
     }
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(TD_E_IO, std::string("cannot open ") + path);
@@ -2555,18 +2678,56 @@ int td_count_and_split_device(td_handle *h, const void *d_fastq, uint64_t nbytes
     return split_device_impl(h, d_fastq, nbytes, first_line, d_out, out_capacity, stream, n_terminators, true);
 }
 
+static int split_file_impl(td_handle *h, const char *in_path, const char *const *out_paths, uint64_t max_reads, uint64_t stats[3],
+                           bool by_reference_rules, bool *gz_refused);
 int td_split_file(td_handle *h, const char *in_path, const char *const *out_paths, uint64_t max_reads, uint64_t stats[3]) {
     if (!h || !in_path || !out_paths) return fail(TD_E_ARG, "NULL argument");
     if (!h->have_splitter) return fail(TD_E_STATE, "td_set_splitter has not been called");
+    bool gz_refused = false;
+    const int rc = split_file_impl(h, in_path, out_paths, max_reads, stats, false, &gz_refused);
+    if (!gz_refused) return rc;
+    // a decoder has refused the .gz input: barcodeSplitter reads it through gzip.open too (reference :1318-1319) and leaves
+    // its loop behind the quality line of read number maxreads (:1361-1362) -- its exception, or, where the loop is through
+    // before the damage, the split taken again through the reference's own reading rules (gz_pyrules.hpp)
+    const std::string refusal = g_err;
+    MappedFile mf(in_path);
+    if (!mf.ok) return fail(rc, refusal);
+    const uint64_t r = std::max<uint64_t>(1, max_reads);
+    const tdhost::GzVerdict v = tdhost::gz_verdict_lines(mf.p, mf.n, r >= (1ull << 60) ? ~0ull : 4 * r);
+    if (v.kind != tdhost::GZ_OK) return fail(gz_code(v.kind), v.message);
+    return split_file_impl(h, in_path, out_paths, max_reads, stats, true, &gz_refused);
+}
+static int split_file_impl(td_handle *h, const char *in_path, const char *const *out_paths, uint64_t max_reads, uint64_t stats[3],
+                           bool by_reference_rules, bool *gz_refused) {
     HIPCHK(hipSetDevice(h->device));
     const size_t len = strlen(in_path);
     const bool gz = len >= 2 && (in_path[len - 2] == 'g' || in_path[len - 2] == 'G') && (in_path[len - 1] == 'z' || in_path[len - 1] == 'Z');
     tdhost::GzSource zsrc; FILE *pf = nullptr;
+    std::unique_ptr<MappedFile> rules_map;
+    std::unique_ptr<tdhost::PyGzipReader> rules;
+    bool rules_through = false;
     bool opened = false;
-    if (gz) opened = zsrc.open(in_path); else { pf = fopen(in_path, "rb"); opened = pf != nullptr; }
+    if (gz && by_reference_rules) {
+        rules_map.reset(new MappedFile(in_path));
+        opened = rules_map->ok;
+        if (opened) rules.reset(new tdhost::PyGzipReader(rules_map->p, rules_map->n));
+    } else if (gz) {
+        struct stat sb0;
+        if (stat(in_path, &sb0) == 0 && S_ISREG(sb0.st_mode) && sb0.st_size == 0) { pf = fopen(in_path, "rb"); opened = pf != nullptr; }   // (gzip.open: no data)
+        else opened = zsrc.open(in_path);
+    } else { pf = fopen(in_path, "rb"); opened = pf != nullptr; }
     if (!opened) return fail(TD_E_IO, std::string("cannot open ") + in_path);
     auto reader = [&](uint8_t *dst, size_t want) -> long {
-        if (gz) return zsrc.read(dst, want);
+        if (rules) {
+            size_t done = 0;
+            while (done < want && !rules_through) {
+                const long got = rules->read(dst + done, std::min<size_t>(tdhost::PyGzipReader::CHUNK, want - done));
+                if (got <= 0) { rules_through = true; break; }      // (damage behind the bound: the verdict says the loop never gets there)
+                done += (size_t)got;
+            }
+            return (long)done;
+        }
+        if (gz && !pf) { const long got = zsrc.read(dst, want); if (got < 0) *gz_refused = true; return got; }
         size_t n = fread(dst, 1, want, pf);
         if (n == 0 && ferror(pf)) return -1;
         return (long)n;

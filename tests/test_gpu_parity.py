@@ -380,17 +380,31 @@ def test_bgzf_gpu_inflate_dirty_and_damaged(tmp_path):
         flipped = bytearray(blob)
         flipped[len(blob) // 2] ^= 0x10                                   # somewhere in a member's deflate stream
         bad.write_bytes(bytes(flipped))
+        def as_gzip_open_ends(path):
+            import gzip
+            import zlib
+            try:
+                with gzip.open(path, "rb") as fh:
+                    while fh.read1(8192):
+                        pass
+            except (EOFError, OSError, zlib.error) as exc:
+                return exc
+            raise AssertionError("gzip.open reads this file")
         eng.reset()
-        with pytest.raises(tagdigger_amd.TagdigError):
+        expected = as_gzip_open_ends(str(bad))                           # (reference :240-243: its exception propagates)
+        with pytest.raises(type(expected)) as ei:
             eng.count_file(str(bad))
+        assert str(ei.value) == str(expected)
         import struct
         bsize = struct.unpack("<H", blob[16:18])[0] + 1                  # first member: its CRC-32 sits 8 bytes before its end
         wrong = bytearray(blob)
         wrong[bsize - 8] ^= 0xFF
         bad.write_bytes(bytes(wrong))
         eng.reset()
-        with pytest.raises(tagdigger_amd.TagdigError):
+        expected = as_gzip_open_ends(str(bad))
+        with pytest.raises(type(expected)) as ei:
             eng.count_file(str(bad))
+        assert str(ei.value) == str(expected)
     finally:
         eng.close()
 

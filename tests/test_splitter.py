@@ -254,6 +254,53 @@ def test_gpu_split_fuzz_campaign():
 
 
 @pytest.mark.gpu
+def test_gpu_splitter_on_damaged_gzip_ends_as_gzip_open_does(tmp_path):
+    """barcodeSplitter reads .gz inputs through gzip.open as find_tags_fastq does (reference :1318-1319) and leaves its
+    loop behind the quality line of read number maxreads (:1361-1362): a damaged input ends in gzip.open's exception
+    -- unless the loop is through first, and then the files are the ones the good input gives."""
+    import gzip
+    import zlib
+    from tagdigger_amd import tagdigger_fun as tf
+    rng = random.Random(3)
+    barcodes = ["AACG", "TTGACC", "CGT", "GATTACAG"]
+    ad = adapter_of("PstI-MspI-Hall")
+    data = synth_reads(rng, barcodes, "TGCAG", ad, 4000)
+    good = gzip.compress(data, compresslevel=1, mtime=0)
+    outs = [str(tmp_path / ("o%d.fq" % i)) for i in range(len(barcodes))]
+
+    def ends(blob, lines_needed):
+        """What a loop that takes `lines_needed` complete lines (None: all) out of gzip.open(..., 'rt') meets."""
+        p = tmp_path / "probe.gz"
+        p.write_bytes(blob)
+        try:
+            with gzip.open(str(p), "rt", newline=None) as fh:
+                for k, _ in enumerate(fh):
+                    if lines_needed is not None and k + 1 >= lines_needed:
+                        break
+        except (EOFError, OSError, zlib.error) as exc:
+            return exc
+        return None
+    variants = {"truncated": good[:len(good) // 2], "crc": good[:-8] + bytes([good[-8] ^ 1]) + good[-7:], "junk": good + b"junk",
+                "padding": good + b"\0" * 64, "flip": good[:3000] + bytes([good[3000] ^ 0x20]) + good[3001:]}
+    for name, blob in variants.items():
+        for maxreads in (500000000, 100):
+            src = tmp_path / ("%s.fq.gz" % name)
+            src.write_bytes(blob)
+            expected = ends(blob, None if maxreads > 10 ** 6 else 4 * maxreads)
+            with contextlib.redirect_stdout(io.StringIO()):
+                if expected is None:
+                    tf.barcodeSplitter(str(src), barcodes, outs, cutsite="TGCAG", adapter=ad, maxreads=maxreads)
+                else:
+                    with pytest.raises(type(expected)) as ei:
+                        tf.barcodeSplitter(str(src), barcodes, outs, cutsite="TGCAG", adapter=ad, maxreads=maxreads)
+                    assert type(ei.value) is type(expected) and str(ei.value) == str(expected), (name, maxreads)
+                    continue
+            want, _ = po.barcode_splitter_bytes(data, barcodes, "TGCAG", ad, maxreads=maxreads)
+            for o, w in zip(outs, want):
+                assert open(o, "rb").read() == w, (name, maxreads)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("newline,threads", [(b"\r\n", None), (b"\n", None), (b"\n", "3"), (b"\n", "1")])
 def test_gpu_split_file_large(tmp_path, monkeypatch, newline, threads):
     """More than one 32 MiB piece through td_split_file (records straddle the pieces): files equal the
