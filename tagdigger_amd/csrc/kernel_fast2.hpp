@@ -28,6 +28,14 @@
 
 namespace tdk {
 
+// timing-only ablations (td_set_option "debug_ablate") are compiled into k_fast2 only with -DTD_ABLATE: in the shipped
+// kernel they would be branches on a kernel argument inside the tile loop
+#ifdef TD_ABLATE
+#define TD_DBG(p) ((p).dbg)
+#else
+#define TD_DBG(p) 0u
+#endif
+
 constexpr int HC_SLOTS = 128;                   // hot-cell cache: slots per wave (direct mapped)
 constexpr uint32_t HC_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t HC_AGE_TILES = 64;           // every so many tiles the cache is written out and cleared
@@ -203,7 +211,7 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
     }
     constexpr int BUCKET_U4_ = W <= 3 ? 4 : 8;
     pd.nr = min(nrem, 0x7FFFu) | (row << 16);
-    if (nrem >= p.m_bases && !(p.dbg & DBG_NO_PROBE)) {
+    if (nrem >= p.m_bases && !(TD_DBG(p) & DBG_NO_PROBE)) {
         pd.nr |= PD_PROBE;
         const uint32_t hk = hash_key(pd.R[0] >> (64u - 2u * p.m_bases));
         const uint32_t bk = hk & p.bucket_mask;
@@ -228,6 +236,9 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
 #endif
 #ifndef TD_P_A
 #define TD_P_A 0
+#endif
+#ifndef TD_P_B
+#define TD_P_B 1
 #endif
 #ifndef TD_FAST2_WAVES
 #define TD_FAST2_WAVES 0        // 0: derived from the tile size (LDS decides how many workgroups share a CU)
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         if (kind >= 1) st_bar += 1;
         if (kind == 2) st_tag += 1;
         phit_tag = kind == 2;
-        hit = kind == 2 && !(p.dbg & DBG_NO_ATOMIC);
+        hit = kind == 2 && !(TD_DBG(p) & DBG_NO_ATOMIC);
         cell = (uint32_t)res;
     };
 
@@ -400,8 +411,38 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                 if (hiacc & 0x80808080u) L_misc[1] = 1;
             }
         }
+        TD_STAMP(1);   // A: wait for the tile's bytes, raw + masks -> LDS (stores issued)
+        // (the stores of raw bytes and masks are on their way: the pending line, the next tile's loads and the count go
+        // here, between them and the read-back of the masks -- none of it touches those bytes)
+        // ---------------- the pending line of the previous tile, the next tile's loads, the pending count
+        __builtin_amdgcn_s_setprio(TD_P_PEND);
+        const uint32_t nit = run_pos + 1u < RUN ? t + 1u : t + 1u + (gridDim.x - 1u) * RUN;      // next tile of this workgroup
+        bool phit = false;
+        uint32_t pcell = 0;
+        {
+            bool tagged = false;
+            if (PIPE && pd_valid) { finish_pending(phit, pcell); pd_valid = false; tagged = phit_tag; }
+            if (prog) sums_add(parity ^ 1u, (uint32_t)__builtin_popcountll(__ballot(tagged)) << 16);
+        }
+        TD_STAMP(3);   // pending line: wait for its bucket, compares
+        vm_settled();                                       // (the halo: requested at the tile's top, a phase A ago)
+        if (has_halo) {
+            *reinterpret_cast<uint4 *>(L_raw + TILE + (size_t)tid * 16u) = make_uint4(vhq.x, vhq.y, vhq.z, vhq.w);
+            // (lines that begin in this tile are packed from these bytes with the ASCII forms)
+            if ((vhq.x | vhq.y | vhq.z | vhq.w) & 0x80808080u) L_misc[3] = 1;
+        }
+        if (nit < nwork) fetch_tile(nit);
+        if (PIPE) {
+            if (hc_on) {
+                // (cache hits of this step, for the hit-rate watch: lanes whose cell is already cached)
+                const uint32_t h = hc_hash(pcell);
+                hc_hits += (uint32_t)__builtin_popcountll(__ballot(phit && hcS[h].x == pcell));
+            }
+            hc_commit(p.counts, hcS, hcE, phit, pcell, (uint32_t)lane, hc_on);
+        }
+        TD_STAMP(4);   // next tile's loads issued, pending count committed
+        __builtin_amdgcn_s_setprio(TD_P_B);
         wave_lds_fence();          // this wave's masks and raw bytes are in LDS (nothing of another wave is read before the barrier)
-        TD_STAMP(1);   // A: wait for the tile's bytes, raw + masks -> LDS
 
         // ---------------- B: terminators of this thread's CPT consecutive chunks, wave scan, vote, list of line starts
         uint32_t mm[CPT / 2];
@@ -500,33 +541,6 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
             }
         }
         TD_STAMP(2);   // B: masks, scan, vote, list
-        // ---------------- the pending line of the previous tile, the next tile's loads, the pending count
-        __builtin_amdgcn_s_setprio(TD_P_PEND);
-        const uint32_t nit = run_pos + 1u < RUN ? t + 1u : t + 1u + (gridDim.x - 1u) * RUN;      // next tile of this workgroup
-        bool phit = false;
-        uint32_t pcell = 0;
-        {
-            bool tagged = false;
-            if (PIPE && pd_valid) { finish_pending(phit, pcell); pd_valid = false; tagged = phit_tag; }
-            if (prog) sums_add(parity ^ 1u, (uint32_t)__builtin_popcountll(__ballot(tagged)) << 16);
-        }
-        TD_STAMP(3);   // pending line: wait for its bucket, compares
-        vm_settled();                                       // (the halo: requested a phase A and a phase B ago)
-        if (has_halo) {
-            *reinterpret_cast<uint4 *>(L_raw + TILE + (size_t)tid * 16u) = make_uint4(vhq.x, vhq.y, vhq.z, vhq.w);
-            // (lines that begin in this tile are packed from these bytes with the ASCII forms)
-            if ((vhq.x | vhq.y | vhq.z | vhq.w) & 0x80808080u) L_misc[3] = 1;
-        }
-        if (nit < nwork) fetch_tile(nit);
-        if (PIPE) {
-            if (hc_on) {
-                // (cache hits of this step, for the hit-rate watch: lanes whose cell is already cached)
-                const uint32_t h = hc_hash(pcell);
-                hc_hits += (uint32_t)__builtin_popcountll(__ballot(phit && hcS[h].x == pcell));
-            }
-            hc_commit(p.counts, hcS, hcE, phit, pcell, (uint32_t)lane, hc_on);
-        }
-        TD_STAMP(4);   // next tile's loads issued, pending count committed
         lds_barrier();
         TD_STAMP(5);   // barrier 1
         __builtin_amdgcn_s_setprio(TD_P_D);
@@ -575,7 +589,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
         TD_STAMP(6);   // C: phase
 
         // ---------------- D: wanted line j follows the terminator with in-tile ordinal r0 + 4 j
-        if (regular && !(p.dbg & DBG_NO_PHASE2)) {
+        if (regular && !(TD_DBG(p) & DBG_NO_PHASE2)) {
             const uint32_t j0 = ((uint32_t)tid + 64u * (t & 3u)) & (uint32_t)(FBLOCK - 1);
 #pragma nounroll
             for (uint32_t j = j0; j < nwant; j += FBLOCK) {
@@ -614,7 +628,7 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                         if (kind == 2) {
                             st_tag += 1;
                             tagged = true;
-                            if (!(p.dbg & DBG_NO_ATOMIC))
+                            if (!(TD_DBG(p) & DBG_NO_ATOMIC))
                                 __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }

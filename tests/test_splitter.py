@@ -295,7 +295,18 @@ def test_gpu_splitter_on_damaged_gzip_ends_as_gzip_open_does(tmp_path):
                         tf.barcodeSplitter(str(src), barcodes, outs, cutsite="TGCAG", adapter=ad, maxreads=maxreads)
                     assert type(ei.value) is type(expected) and str(ei.value) == str(expected), (name, maxreads)
                     continue
-            want, _ = po.barcode_splitter_bytes(data, barcodes, "TGCAG", ad, maxreads=maxreads)
+            # (what the loop saw: a flipped bit may decode -- to other text -- long before the member's CRC-32 says so)
+            seen = b""
+            with gzip.open(str(src), "rb") as fh:
+                try:
+                    while seen.count(b"\n") < 4 * maxreads:
+                        piece = fh.read1(8192)
+                        if not piece:
+                            break
+                        seen += piece
+                except (EOFError, OSError, zlib.error):
+                    pass
+            want, _ = po.barcode_splitter_bytes(seen, barcodes, "TGCAG", ad, maxreads=maxreads)
             for o, w in zip(outs, want):
                 assert open(o, "rb").read() == w, (name, maxreads)
 
