@@ -74,9 +74,12 @@ __device__ __forceinline__ void set_prio(uint32_t level) {
 #define TD_FAST_WAVES_PER_SIMD TD_WAVES_PER_SIMD
 #endif
 constexpr int FBLOCK = TD_FAST_BLOCK;
-template <int CPT, int W, bool FIX>
-__global__ __launch_bounds__(FBLOCK, TD_FAST_WAVES_PER_SIMD) void k_fast(const FParams fp) {
+// (FB: threads per workgroup -- 128 x 6 chunks is the 12 KiB tile of k_fast4's fix-up pass)
+template <int CPT, int W, bool FIX, int FB = TD_FAST_BLOCK>
+__global__ __launch_bounds__(FB, TD_FAST_WAVES_PER_SIMD) void k_fast(const FParams fp) {
     const KParams &p = fp.k;
+    constexpr int FBLOCK = FB;
+    static_assert(FB == 128 || FB == 256, "k_fast: 128 or 256 threads");
     constexpr int TILE_CH = CPT * FBLOCK;
     constexpr uint32_t TILE = TILE_CH * 16;
 

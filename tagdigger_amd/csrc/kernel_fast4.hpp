@@ -1,0 +1,479 @@
+// k_fast4: the main pass of the free-running path with the workgroup's waves in TWO ROLES and no workgroup barrier
+// in the tile loop.
+//
+// k_fast2 (kernel_fast2.hpp) takes every tile through phases A-B (all four waves: terminators, lists of line starts),
+// a barrier, phases C-D (the wanted lines matched by the two waves whose lanes they fill) and a second barrier: per
+// tile the four waves can issue 4 x (A-B + D) instructions' worth of time but only have 4 x A-B + 2 x D to issue --
+// 72 % at best -- and every wave stands at two barriers behind the slowest.  Here a workgroup is five waves:
+//
+//   producers (waves 0-2)  stream the FASTQ.  A tile is 12 KiB, one third per producer; the next TWO tiles' bytes are in
+//                          flight in registers.  Per tile: raw bytes -> the tile's slot in LDS (a ring of three slots),
+//                          terminator masks, the list of the wave's line starts (k_fast2's phases A and B, nothing
+//                          shared between the producers).  The last of them to finish a tile ("closer": the wave whose
+//                          arrival makes three) adds up the three terminator counts, carries the line phase inside a
+//                          run or takes the vote at its start, writes the tile's word for k_resolve and opens the slot
+//                          to the consumers.
+//   consumers (waves 3-4)  match.  Each takes every other tile: the wanted lines (every fourth line start, by the phase the
+//                          closer left) with full lanes -- 56 lines of 100 bp reads on 64 lanes -- through
+//                          line_prepare (kernel_fast2.hpp: pack from the line's first byte, barcode directory, tag hash,
+//                          bucket loads left in flight), gives the slot back as soon as the lines' bytes have been read,
+//                          and finishes the pending lines (compares, count) before it takes its next tile.
+//
+// Hand-offs are words in LDS: per slot a count of producers that are through with it, the sequence number of the tile
+// that is ready in it, the number of times it has been given back.  A wave's LDS operations execute in order, so a wave
+// that drains its stores (s_waitcnt lgkmcnt(0)) before it touches the hand-off word has published them.  Every wait
+// is bounded: a wave that waits too long raises ERR_SPIN and sets an abort word that ends every loop of the workgroup
+// (the host then reports TD_E_INTERNAL; it cannot happen: tile k's production needs only tile k - 3 matched, which
+// needs tile k - 3 produced).  Instruction count per byte equals k_fast2's; what changes is who waits for whom: three
+// producers carry ~200 instructions a tile each and two consumers ~400 per own tile -- 97 % of the five waves' issue
+// time has an instruction to issue -- and nobody waits for a wave of the other role unless the ring is full or empty.
+// Tiles that are not "regular" (the buffer's first and last, bytes >= 0x80, '\r' at the end of a chunk next to another
+// wave's bytes, more line starts than a list holds) are only counted here (terminators) and flagged TI_SKIP for the
+// fix-up pass (k_fast<6, W, true, 128>: 128 threads x 6 chunks = the same 12 KiB tile), as in k_fast2.
+#pragma once
+#include "kernel_fast2.hpp"
+
+namespace tdk {
+
+constexpr int F4_PROD = 3, F4_CONS = 2, F4_WAVES = F4_PROD + F4_CONS, F4_BLOCK = 64 * F4_WAVES;
+constexpr int F4_CPT = 4;                                   // 16-byte chunks per producer lane and tile
+constexpr uint32_t F4_WCH = F4_CPT * 64;                    // chunks per producer and tile
+constexpr uint32_t F4_WBYTES = F4_WCH * 16;
+constexpr uint32_t F4_TILE = F4_PROD * F4_WBYTES;           // 12 KiB
+constexpr int F4_SLOTS = 3;
+constexpr uint32_t F4_SPIN_LIMIT = 1u << 18;
+// hand-off words of a slot (dwords in LDS)
+enum { F4_DONE = 0, F4_READY = 1, F4_FREE = 2, F4_FLAGS = 3, F4_TOT = 4 /* 3 */, F4_VOTE = 7 /* 3 */, F4_R0 = 10, F4_WB1 = 11, F4_WB2 = 12,
+       F4_TOTAL = 13, F4_REGULAR = 14, F4_CTRL_DW = 16 };
+constexpr uint32_t F4_FLAG_HI = 1, F4_FLAG_OVER = 2, F4_FLAG_HALO_HI = 4;
+constexpr uint32_t F4_ABORT_DW = F4_SLOTS * F4_CTRL_DW;     // one word behind the slots' hand-off words
+
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// waits until *p >= need (a word only ever grows); false: gave up -- the abort word is set and ERR_SPIN raised
+__device__ __forceinline__ bool f4_wait(uint32_t *p, uint32_t need, uint32_t *abort_word, unsigned long long *stats) {
+    for (uint32_t spins = 0;; spins++) {
+        const uint32_t v = lds_ld(p);
+        if (v >= need) break;
+        if (spins > F4_SPIN_LIMIT || lds_ld(abort_word)) {
+            lds_st(abort_word, 1u);
+            if ((threadIdx.x & 63) == 0) atomicOr(stats + ST_ERR, ERR_SPIN);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (nothing behind the wait is read before it)
+    return true;
+}
+
+template <int W, int NQ>
+__global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
+    const KParams &p = fp.k;
+    constexpr uint32_t TILE = F4_TILE, WCH = F4_WCH, WBYTES = F4_WBYTES;
+    constexpr int CPT = F4_CPT;
+    static_assert(W <= 3, "k_fast4 has the pipelined probe of the 64-byte buckets only");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t halo = p.halo;                                            // bytes staged behind a tile (multiple of 64, >= 16 * NQ + 16)
+    const uint32_t slot_bytes = TILE + halo;
+    uint8_t *L_raw0 = lds;
+    uint16_t *L_list0 = reinterpret_cast<uint16_t *>(lds + F4_SLOTS * slot_bytes);          // [slot][producer][WCH]: masks, then line starts
+    uint32_t *L_ctrl = reinterpret_cast<uint32_t *>(lds + F4_SLOTS * slot_bytes + F4_SLOTS * F4_PROD * WCH * 2u);
+    uint32_t *L_abort = L_ctrl + F4_ABORT_DW;
+    uint8_t *L_hc = reinterpret_cast<uint8_t *>(L_ctrl + 64);
+    uint8_t *L_bidx = L_hc + F4_CONS * HC_BYTES_PER_WAVE;
+    TileCtx cx{nullptr, 0u, reinterpret_cast<const unsigned long long *>(L_bidx),
+               reinterpret_cast<const uint32_t *>(L_bidx + p.off_bmeta),
+               reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir)};
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t i = tid; i < p.bblob_bytes / 4; i += F4_BLOCK)
+        reinterpret_cast<uint32_t *>(L_bidx)[i] = p.bblob[i];
+    if (tid < 64) L_ctrl[tid] = 0;
+    __syncthreads();
+
+    const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
+    const uint64_t first_line = p.first_line + carried;
+    const uint32_t nwork = p.ntiles;
+    const uint32_t RUN = p.run ? p.run : 1u;
+    const uint32_t jump = (gridDim.x - 1u) * RUN;                          // from a run's last tile to the next run's first
+    auto tile_base = [&](uint32_t tile) -> const uint8_t * {
+        return tile >= p.tail_tile ? p.tail_buf + (uint64_t)(tile - p.tail_tile) * TILE : p.buf + (uint64_t)tile * TILE;
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto tile_rsrc = [&](uint32_t tile) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base(tile)), 0, (int)(TILE + 4096u), 0x00020000);
+    };
+
+    if (wave < F4_PROD) {
+        // ================================================================ producer
+        const uint32_t voff = (uint32_t)wave * WBYTES + (uint32_t)lane * 16u;     // this lane's first chunk; chunk j is 1 KiB further
+        const bool has_halo = wave == F4_PROD - 1 && (uint32_t)lane < halo / 16u;   // (the halo is the last producer's)
+        const uint32_t hoff = has_halo ? (uint32_t)lane * 16u : 0x40000000u;       // (beyond every descriptor's range: reads as zero)
+        // a tile's bytes in registers: this lane's CPT chunks, and -- the last producer's first lanes -- the halo behind the
+        // tile (every lane asks: the others for an offset beyond the descriptor's range, which returns zeros without touching
+        // memory, so that the loads are unconditional straight-line code the wait counts can leave in flight)
+        uint4 va[CPT], vb[CPT];
+        u32x4 vha, vhb;
+        auto fetch_tile = [&](uint4 (&v)[CPT], u32x4 &vh, uint32_t tile) {
+            const __amdgpu_buffer_rsrc_t rs = tile_rsrc(tile);
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * 1024, 2 /* nt */);
+                v[j] = make_uint4(q.x, q.y, q.z, q.w);
+            }
+            vh = __builtin_amdgcn_raw_buffer_load_b128(rs, hoff, (int)TILE, 0);
+        };
+        auto next_tile = [&](uint32_t t, uint32_t &run_pos) -> uint32_t {
+            const uint32_t n = run_pos + 1u < RUN ? t + 1u : t + 1u + jump;
+            run_pos = run_pos + 1u < RUN ? run_pos + 1u : 0u;
+            return n;
+        };
+        uint32_t t = blockIdx.x * RUN, run_pos = 0, k = 0;
+        uint32_t carry_r0 = 0;                                              // (kept by every producer: any of them may close a tile)
+        bool carry_ok = false;
+        // the tiles after this one and after that (their bytes in flight)
+        uint32_t rp1 = 0, t1 = next_tile(t, rp1), rp2 = rp1, t2 = next_tile(t1, rp2);
+        if (t < nwork) fetch_tile(va, vha, t);
+        if (t1 < nwork) fetch_tile(vb, vhb, t1);
+
+        // one tile from the registers v (its bytes were requested two tiles ago); afterwards v holds the tile after next
+        auto produce = [&](uint4 (&v)[CPT], u32x4 &vh) -> bool {
+            const uint32_t slot = k % (uint32_t)F4_SLOTS, use = k / (uint32_t)F4_SLOTS;
+            uint8_t *L_raw = L_raw0 + slot * slot_bytes;
+            uint16_t *Ll = L_list0 + (slot * F4_PROD + (uint32_t)wave) * WCH;
+            uint32_t *ctrl = L_ctrl + slot * F4_CTRL_DW;
+            const uint64_t tbase = (uint64_t)t * TILE;
+            // the slot must have been given back as often as it has been used
+            if (!f4_wait(ctrl + F4_FREE, use, L_abort, p.stats)) return false;
+            // ---------------- A: raw bytes and terminator masks -> LDS
+            bool wave_crb = false;
+            uint32_t myflags = 0;
+            {
+                uint32_t hiacc = 0;
+#pragma unroll
+                for (int j = 0; j < CPT; j++) hiacc |= v[j].x | v[j].y | v[j].z | v[j].w;
+#pragma unroll
+                for (int j = 0; j < CPT; j++) *reinterpret_cast<uint4 *>(L_raw + voff + j * 1024) = v[j];
+                uint16_t *Lm = Ll + lane;
+                const bool general = __any((hiacc & 0x80808080u) != 0);
+                if (__builtin_expect(!general, 1)) {
+                    uint32_t cr_absent = 0x80808080u;
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) cr_absent_ascii(v[j], cr_absent);
+                    const bool has_cr = __any((cr_absent & 0x80808080u) != 0x80808080u);
+                    if (__builtin_expect(!has_cr, 1)) {
+#pragma unroll
+                        for (int j = 0; j < CPT; j++) Lm[j * 64] = (uint16_t)nl_mask16_ascii(v[j]);
+                    } else {
+                        uint32_t crs = 0;
+#pragma unroll
+                        for (int j = 0; j < CPT; j++) {
+                            const uint32_t nl = eq_mask16_ascii(v[j], 0x0A0A0A0Au, 0x7F7F7F7Fu), cr = eq_mask16_ascii(v[j], 0x0D0D0D0Du, 0x7F7F7F7Fu);
+                            Lm[j * 64] = (uint16_t)(nl | (cr & ~(nl >> 1)));      // (a '\r' in the chunk's last byte: settled below)
+                            crs |= cr;
+                        }
+                        wave_crb = __any((crs & 0x8000u) != 0);
+                    }
+                } else {
+                    uint32_t crs = 0;
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        const uint32_t nl = eq_mask16(v[j], 0x0A0A0A0Au), cr = eq_mask16(v[j], 0x0D0D0D0Du);
+                        Lm[j * 64] = (uint16_t)(nl | (cr & ~(nl >> 1)));
+                        crs |= cr;
+                    }
+                    wave_crb = __any((crs & 0x8000u) != 0);
+                    myflags |= F4_FLAG_HI;                          // (wave-uniform: some lane of this wave holds a byte >= 0x80)
+                }
+            }
+            // the halo, then the tile after next: its bytes take this tile's registers
+            if (has_halo) *reinterpret_cast<uint4 *>(L_raw + TILE + (uint32_t)lane * 16u) = make_uint4(vh.x, vh.y, vh.z, vh.w);
+            // (lines that begin in this tile are packed from these bytes with the ASCII forms)
+            if (wave == F4_PROD - 1 && __any(has_halo && ((vh.x | vh.y | vh.z | vh.w) & 0x80808080u) != 0)) myflags |= F4_FLAG_HALO_HI;
+            if (t2 < nwork) fetch_tile(v, vh, t2);
+            wave_lds_fence();          // this wave's masks and raw bytes are in LDS
+
+            // ---------------- B: terminators of this lane's CPT consecutive chunks, wave scan, vote, list of line starts
+            uint32_t mm[CPT / 2];
+#pragma unroll
+            for (int i = 0; i < CPT / 2; i++) mm[i] = reinterpret_cast<const uint32_t *>(Ll)[lane * (CPT / 2) + i];
+            const uint32_t span0 = (uint32_t)wave * WBYTES + (uint32_t)lane * (CPT * 16u);
+            const uint32_t wend = ((uint32_t)wave + 1u) * WBYTES;               // end of this wave's third
+            if (__builtin_expect(wave_crb, 0)) {
+                // a chunk whose last byte is '\r' (bit 15 of its mask is set for it -- or for a '\n' there): one terminator
+                // with the '\n' that opens the next chunk, if there is one
+#pragma unroll
+                for (int i = 0; i < CPT / 2; i++) {
+#pragma unroll
+                    for (int hbit = 15; hbit < 32; hbit += 16) {
+                        if ((mm[i] >> hbit) & 1u) {
+                            const uint32_t at = span0 + 32u * i + (uint32_t)hbit;
+                            if (L_raw[at] == 0x0Du) {
+                                // (the next byte may belong to another wave's third, or to the halo: not in LDS yet)
+                                const uint32_t nx = at + 1u < wend ? (uint32_t)L_raw[at + 1u] : (uint32_t)tile_base(t)[at + 1u];
+                                if (nx == 0x0Au) mm[i] &= ~(1u << hbit);
+                            }
+                        }
+                    }
+                }
+            }
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int i = 0; i < CPT / 2; i++) cnt += __builtin_popcount(mm[i]);
+            const uint32_t incl = wave_incl_scan(cnt, lane);
+            const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t packed = 0;
+            if (!carry_ok) {
+                // the first line that starts in this lane's span: do its first eight bytes (inside this wave's third) read as bases?
+                uint32_t fpos = 0;
+                bool found = false;
+#pragma unroll
+                for (int q = CPT / 2 - 1; q >= 0; q--) {
+                    if (mm[q]) { fpos = 32u * q + __builtin_ctz(mm[q]); found = true; }
+                }
+                const uint32_t ls = span0 + fpos + 1u;
+                uint2 q8 = make_uint2(0u, 0u);
+                if (found && ls + 8u <= wend) __builtin_memcpy(&q8, L_raw + ls, 8);
+                const uint32_t c0 = (q8.x >> 1) & 0x03030303u, c1 = (q8.y >> 1) & 0x03030303u;
+                const uint32_t d0 = (q8.x & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, c0);
+                const uint32_t d1 = (q8.y & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, c1);
+                const bool vote_good = (d0 | d1) == 0;
+                const uint32_t lclass = (incl - cnt) & 3u;
+                const uint64_t bg = __ballot(vote_good), b0 = __ballot((lclass & 1u) != 0), b1 = __ballot((lclass & 2u) != 0);
+                packed = (uint32_t)__builtin_popcountll(bg & ~b0 & ~b1) | ((uint32_t)__builtin_popcountll(bg & b0 & ~b1) << 8) |
+                         ((uint32_t)__builtin_popcountll(bg & ~b0 & b1) << 16) | ((uint32_t)__builtin_popcountll(bg & b0 & b1) << 24);
+            }
+            // the lines behind this wave's terminators, by wave-local ordinal, into the space of its masks (every lane holds its
+            // masks in registers by now: the fence below the read-back is the wave's own order of LDS operations)
+            if (__builtin_expect(wtot <= WCH, 1)) {
+                uint16_t *spare = reinterpret_cast<uint16_t *>(L_ctrl + 60) + (uint32_t)wave;      // (a word nobody reads)
+                uint32_t kk = incl - cnt, rest = 0;
+#pragma unroll
+                for (int i = 0; i < CPT / 2; i++) {
+                    const uint32_t m = mm[i], m1 = m & (m - 1u);
+                    const uint32_t base = span0 + 32u * i + 1u;
+                    uint16_t *d0 = m ? Ll + kk : spare;
+                    *d0 = (uint16_t)(base + (uint32_t)__builtin_ctz(m | 0x80000000u));
+                    kk += m ? 1u : 0u;
+                    uint16_t *d1 = m1 ? Ll + kk : spare;
+                    *d1 = (uint16_t)(base + (uint32_t)__builtin_ctz(m1 | 0x80000000u));
+                    kk += m1 ? 1u : 0u;
+                    rest |= m1 & (m1 - 1u);
+                }
+                if (__builtin_expect(__any(rest != 0), 0)) {
+                    kk = incl - cnt;
+#pragma unroll
+                    for (int i = 0; i < CPT / 2; i++) {
+                        uint32_t m = mm[i];
+                        while (m) {
+                            const uint32_t bit = __builtin_ctz(m);
+                            m &= m - 1;
+                            Ll[kk] = (uint16_t)(span0 + 32u * i + bit + 1u);
+                            kk++;
+                        }
+                    }
+                }
+            } else {
+                myflags |= F4_FLAG_OVER;
+            }
+            if (lane == 0) {
+                lds_st(ctrl + F4_TOT + wave, wtot);
+                lds_st(ctrl + F4_VOTE + wave, packed);
+                if (myflags) __hip_atomic_fetch_or(ctrl + F4_FLAGS, myflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            wave_lds_fence();          // raw bytes, halo, lists, totals: stored
+            // ---------------- the producer that arrives last closes the tile
+            uint32_t arrived = 0;
+            if (lane == 0) arrived = __hip_atomic_fetch_add(ctrl + F4_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+            arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+            // (every producer keeps the phase it would carry: it needs the tile's total, which only the closer has for sure --
+            // the others wait for READY, which the closer sets; that wait is short and ends before their next tile's slot
+            // could be given back anyway)
+            if (arrived == (uint32_t)F4_PROD * (use + 1u)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const uint32_t t_x = lds_ld(ctrl + F4_TOT + 0), t_y = lds_ld(ctrl + F4_TOT + 1), t_z = lds_ld(ctrl + F4_TOT + 2);
+                const uint32_t flags = lds_ld(ctrl + F4_FLAGS);
+                const uint32_t wb1 = t_x, wb2 = wb1 + t_y, total = wb2 + t_z;
+                uint32_t r0;
+                if (carry_ok) {
+                    r0 = carry_r0;
+                } else if (t != 0) {
+                    auto rot = [](uint32_t pk, uint32_t by) { const uint32_t r = 8u * (by & 3u); return r ? ((pk << r) | (pk >> (32u - r))) : pk; };
+                    const uint32_t a = lds_ld(ctrl + F4_VOTE + 0), b = rot(lds_ld(ctrl + F4_VOTE + 1), wb1), c = rot(lds_ld(ctrl + F4_VOTE + 2), wb2);
+                    const uint32_t v02 = (a & 0x00FF00FFu) + (b & 0x00FF00FFu) + (c & 0x00FF00FFu);
+                    const uint32_t v13 = ((a >> 8) & 0x00FF00FFu) + ((b >> 8) & 0x00FF00FFu) + ((c >> 8) & 0x00FF00FFu);
+                    const uint32_t votes[4] = {v02 & 0xFFFFu, v13 & 0xFFFFu, v02 >> 16, v13 >> 16};
+                    uint32_t best = votes[0]; r0 = 0;
+                    if (votes[1] > best) { best = votes[1]; r0 = 1; }
+                    if (votes[2] > best) { best = votes[2]; r0 = 2; }
+                    if (votes[3] > best) { best = votes[3]; r0 = 3; }
+                } else {
+                    r0 = (4u - (uint32_t)(first_line & 3)) & 3u;
+                }
+                const bool regular = t != 0 && flags == 0 && tbase + TILE + halo <= p.nbytes;
+                if (lane == 0) {
+                    fp.tile_info[t] = total | (r0 << TI_R0_SHIFT) | ((flags & F4_FLAG_HI) ? TI_HI : 0u) | (regular ? 0u : TI_SKIP);
+                    lds_st(ctrl + F4_R0, r0); lds_st(ctrl + F4_WB1, wb1); lds_st(ctrl + F4_WB2, wb2); lds_st(ctrl + F4_TOTAL, total);
+                    lds_st(ctrl + F4_REGULAR, regular ? 1u : 0u);
+                    lds_st(ctrl + F4_FLAGS, 0u);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) lds_st(ctrl + F4_READY, k + 1u);
+            }
+            // the phase the next tile of the run is counted under: r0 - total (mod 4), from what the closer published
+            if (!f4_wait(ctrl + F4_READY, k + 1u, L_abort, p.stats)) return false;
+            {
+                const uint32_t r0 = lds_ld(ctrl + F4_R0), total = lds_ld(ctrl + F4_TOTAL);
+                carry_r0 = (r0 - total) & 3u;
+            }
+            return true;
+        };
+        // (two tiles per turn of the loop: the registers a tile comes from are named at compile time)
+        for (;;) {
+            if (!(t < nwork)) break;
+            if (!produce(va, vha)) break;
+            { const uint32_t nit = t1; carry_ok = nit == t + 1u && t != 0u; t = t1; run_pos = rp1; t1 = t2; rp1 = rp2; t2 = next_tile(t1, rp2); k++; }
+            if (!(t < nwork)) break;
+            if (!produce(vb, vhb)) break;
+            { const uint32_t nit = t1; carry_ok = nit == t + 1u && t != 0u; t = t1; run_pos = rp1; t1 = t2; rp1 = rp2; t2 = next_tile(t1, rp2); k++; }
+        }
+        (void)run_pos;
+        return;
+    }
+
+    // ==================================================================== consumer
+    const int cons = wave - F4_PROD;
+    uint2 *hcS = reinterpret_cast<uint2 *>(L_hc + cons * HC_BYTES_PER_WAVE);
+    uint8_t *hcE = L_hc + cons * HC_BYTES_PER_WAVE + HC_SLOTS * 8;
+#pragma unroll
+    for (int q = 0; q < HC_SLOTS / 64; q++) hcS[q * 64 + lane] = make_uint2(HC_EMPTY, 0u);
+    wave_lds_fence();
+    bool hc_on = p.hot_cache != 0;
+    uint32_t hc_hits = 0, hc_rest = 0, aged = 0;
+    int st_reads = 0, st_bar = 0, st_tag = 0;
+    Pending<W> pd;
+    bool pd_valid = false;
+    auto finish_pending = [&](bool &hit, uint32_t &cell) {
+        vm_settled();
+        const uint64_t res = match_finish<W>(p, pd);
+        const uint32_t kind = (uint32_t)(res >> 62);
+        st_reads += 1;
+        if (kind >= 1) st_bar += 1;
+        if (kind == 2) st_tag += 1;
+        hit = kind == 2 && !(TD_DBG(p) & DBG_NO_ATOMIC);
+        cell = (uint32_t)res;
+    };
+    uint32_t t = blockIdx.x * RUN, run_pos = 0;
+    for (uint32_t k = 0; t < nwork; k++) {
+        if ((k & 1u) == (uint32_t)cons) {
+            const uint32_t slot = k % (uint32_t)F4_SLOTS, use = k / (uint32_t)F4_SLOTS;
+            uint8_t *L_raw = L_raw0 + slot * slot_bytes;
+            const uint16_t *Ll = L_list0 + slot * F4_PROD * WCH;
+            uint32_t *ctrl = L_ctrl + slot * F4_CTRL_DW;
+            const uint64_t tbase = (uint64_t)t * TILE;
+            // the lines the last own tile left pending: their buckets have had the other consumer's tile to arrive
+            if (pd_valid) {
+                bool phit; uint32_t pcell;
+                finish_pending(phit, pcell);
+                pd_valid = false;
+                if (hc_on) {
+                    const uint32_t h = hc_hash(pcell);
+                    hc_hits += (uint32_t)__builtin_popcountll(__ballot(phit && hcS[h].x == pcell));
+                }
+                hc_commit(p.counts, hcS, hcE, phit, pcell, (uint32_t)lane, hc_on);
+            }
+            if (!f4_wait(ctrl + F4_READY, k + 1u, L_abort, p.stats)) break;
+            const uint32_t r0 = lds_ld(ctrl + F4_R0), wb1 = lds_ld(ctrl + F4_WB1), wb2 = lds_ld(ctrl + F4_WB2), total = lds_ld(ctrl + F4_TOTAL);
+            const bool regular = lds_ld(ctrl + F4_REGULAR) != 0;
+            if (regular && !(TD_DBG(p) & DBG_NO_PHASE2)) {
+                const uint32_t nwant = (total + 3u - r0) >> 2;
+#pragma nounroll
+                for (uint32_t jb = 0; jb < nwant; jb += 64u) {
+                    const uint32_t j = jb + (uint32_t)lane;
+                    const bool keep = jb + 64u >= nwant;                             // the last pass: its lines are left pending
+                    uint32_t kres = 7u;                                              // (7: no line for this lane)
+                    uint32_t srel = 0;
+                    if (j < nwant) {
+                        // (the producer whose list holds ordinal o, and o's place in it: selects, no branches)
+                        const uint32_t o = r0 + 4u * j;
+                        uint32_t sel = 0u;
+                        sel = o >= wb1 ? 1u * WCH - wb1 : sel;
+                        sel = o >= wb2 ? 2u * WCH - wb2 : sel;
+                        srel = Ll[o + sel];
+                        // (a line that starts in the tile's last bytes is still whole in the staged window: the halo holds 16 NQ bytes and more)
+                        kres = line_prepare<W, NQ>(p, cx, L_raw, srel, pd);
+                    }
+                    // kres: 0 no barcode, 2 barcode only, 1 pending (bucket in flight), 6 leading blank (rare: raw bytes re-read)
+                    st_reads += kres == 0u || kres == 2u ? 1 : 0;
+                    st_bar += kres == 2u ? 1 : 0;
+                    if (keep) {
+                        // the tile's bytes have been read (line_prepare waits for its pieces before it packs them): the slot goes back
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (lane == 0) lds_st(ctrl + F4_FREE, use + 1u);
+                    }
+                    if (kres == 1u) {
+                        if (keep) pd_valid = true;
+                        else {
+                            bool h; uint32_t c;
+                            finish_pending(h, c);
+                            hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
+                            vm_settled();
+                        }
+                    }
+                    if (__builtin_expect(__any(kres == 6u), 0)) {
+                        if (kres == 6u) {
+                            const uint64_t res = match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true);
+                            const uint32_t kind = (uint32_t)(res >> 62);
+                            st_reads += 1;
+                            if (kind >= 1) st_bar += 1;
+                            if (kind == 2) {
+                                st_tag += 1;
+                                if (!(TD_DBG(p) & DBG_NO_ATOMIC))
+                                    __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                        vm_settled();
+                    }
+                }
+                if (nwant == 0) { if (lane == 0) lds_st(ctrl + F4_FREE, use + 1u); }
+            } else {
+                if (lane == 0) lds_st(ctrl + F4_FREE, use + 1u);
+            }
+            if (p.hot_cache && ++aged == HC_AGE_TILES) {
+                aged = 0;
+                if (hc_on) {
+                    hc_flush(p.counts, hcS, (uint32_t)lane);
+                    // a consumer commits ~TILE / 300 hits a tile: below ~3 % of them cached, the cache is only overhead
+                    if (p.hot_cache != 2u && hc_hits * 32u < HC_AGE_TILES * (TILE / 300u)) { hc_on = false; hc_rest = HC_REST; }
+                    hc_hits = 0;
+                } else if (--hc_rest == 0) hc_on = true;
+            }
+        }
+        const uint32_t n = run_pos + 1u < RUN ? t + 1u : t + 1u + jump;
+        run_pos = run_pos + 1u < RUN ? run_pos + 1u : 0u;
+        t = n;
+    }
+    if (pd_valid) {
+        bool h; uint32_t c;
+        finish_pending(h, c);
+        hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
+    }
+    if (p.hot_cache) hc_flush(p.counts, hcS, (uint32_t)lane);
+    unsigned long long r = wave_sum64((unsigned long long)(long long)st_reads), b = wave_sum64((unsigned long long)(long long)st_bar),
+                       g = wave_sum64((unsigned long long)(long long)st_tag);
+    if (lane == 0) {
+        if (r) atomicAdd(p.stats + ST_READS, r);
+        if (b) atomicAdd(p.stats + ST_BARCUT, b);
+        if (g) atomicAdd(p.stats + ST_TAG, g);
+    }
+}
+
+}  // namespace tdk
+
+#ifdef TD_FAST4_EXTERN
+#define TD_X4(W, NQ) extern template __global__ void tdk::k_fast4<W, NQ>(const tdk::FParams);
+TD_FAST2_COMBOS(TD_X4)
+#undef TD_X4
+#endif

@@ -24,6 +24,8 @@
 #include "kernel_fast.hpp"
 #define TD_FAST2_EXTERN 1           // the instantiations of k_fast2 live in inst_fast2.hip (six translation units)
 #include "kernel_fast2.hpp"
+#define TD_FAST4_EXTERN 1           // ... those of k_fast4 in inst_fast4.hip
+#include "kernel_fast4.hpp"
 #include "kernel_splitter.hpp"
 #include "kernel_splitter2.hpp"
 #include "gz_source.hpp"
@@ -317,7 +319,21 @@ FFn pick_fast2(int tile_kb, int W, uint32_t nq, bool prog) {
 }
 FFn pick_fix(int tile_kb, int W) {          // the fix-up pass shares the main pass's tile size
     if (tile_kb == 24) return pick_fast_w<6, true>(W);
+    if (tile_kb == 12) return W == 1 ? tdk::k_fast<6, 1, true, 128> : W == 2 ? tdk::k_fast<6, 2, true, 128> : tdk::k_fast<6, 3, true, 128>;   // (k_fast4's tile: 128 threads)
     return pick_fast(tile_kb, W, true);
+}
+// k_fast4: producer and consumer waves, 12 KiB tiles (kernel_fast4.hpp)
+FFn pick_fast4(int W, uint32_t nq) {
+    switch (W) {
+    case 1: return nq == 3 ? tdk::k_fast4<1, 3> : nq == 4 ? tdk::k_fast4<1, 4> : tdk::k_fast4<1, 6>;
+    case 2: return nq == 5 ? tdk::k_fast4<2, 5> : nq == 6 ? tdk::k_fast4<2, 6> : tdk::k_fast4<2, 8>;
+    default: return nq == 7 ? tdk::k_fast4<3, 7> : nq == 8 ? tdk::k_fast4<3, 8> : tdk::k_fast4<3, 10>;
+    }
+}
+size_t lds_bytes_fast4(const td_handle *h) {
+    // three slots of raw tile + halo | per slot and producer the masks / line starts | hand-off words | the consumers' hot-cell caches | barcode index
+    return (size_t)tdk::F4_SLOTS * (tdk::F4_TILE + h->halo) + (size_t)tdk::F4_SLOTS * tdk::F4_PROD * tdk::F4_WCH * 2 + 256 +
+           (size_t)tdk::F4_CONS * tdk::HC_BYTES_PER_WAVE + h->bblob_bytes;
 }
 // k_fast2's tile: four workgroups must share a CU's 160 KiB of LDS (measured: three cost a fifth of the throughput),
 // so a large barcode index (many barcodes x several concrete cut sites) takes the smaller tile
@@ -402,10 +418,14 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     // the pipelined probe and the tile fits the LDS budget, else k_fast -- which keeps no progress records: with
     // progress on and no k_fast2 (wide tags, or a barcode index too large for its LDS layout) the exact kernel counts
     const int tkb2 = h->tile_kb2 ? h->tile_kb2 : fast2_auto_tile(h);
-    const bool gen2_fits = h->kernel_gen == 2 && h->W <= 3 && lds_bytes_fast2(h, tkb2) <= LDS_BUDGET;
+    // k_fast4 (producer and consumer waves) where three of its workgroups share a CU's LDS and no progress windows are wanted
+    // (it keeps no per-tile sums); else k_fast2
+    const bool gen4_fits = h->kernel_gen == 4 && h->W <= 3 && !h->progress && lds_bytes_fast4(h) <= LDS_BUDGET;
+    const bool gen2_fits = (h->kernel_gen == 2 || (h->kernel_gen == 4 && !gen4_fits)) && h->W <= 3 && lds_bytes_fast2(h, tkb2) <= LDS_BUDGET;
     const bool use_fast = h->fastpath && !tassel && !h->prescan && limit_far && counts32 && !(h->progress && !gen2_fits);
-    const bool gen2 = use_fast && gen2_fits;
-    const int tile_kb = tassel ? 16 : gen2 ? tkb2 : h->tile_kb;
+    const bool gen4 = use_fast && gen4_fits;
+    const bool gen2 = use_fast && gen2_fits && !gen4;
+    const int tile_kb = tassel ? 16 : gen4 ? 12 : gen2 ? tkb2 : h->tile_kb;
     const uint64_t tile = (uint64_t)tile_kb * 1024;
     const uint64_t ntiles64 = (nbytes + tile - 1) / tile;
     if (ntiles64 > 0x7FFFFFFFull) return fail(TD_E_LIMIT, "buffer too large for one launch; split it");
@@ -485,15 +505,16 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
             fp.tile_sums = h->d_tilesums.p;
         }
         HIPCHK(hipMemsetAsync(h->d_nfix.p, 0, 4, stream));
-        FFn ffn = gen2 ? pick_fast2(tile_kb, h->W, h->nch2, h->progress != 0) : pick_fast(tile_kb, h->W, false), fixfn = pick_fix(tile_kb, h->W);
-        const size_t flds = gen2 ? lds_bytes_fast2(h, tile_kb) : lds_bytes_fast(h, tile_kb), fixlds = lds_bytes_fast(h, tile_kb);
+        FFn ffn = gen4 ? pick_fast4(h->W, h->nch2) : gen2 ? pick_fast2(tile_kb, h->W, h->nch2, h->progress != 0) : pick_fast(tile_kb, h->W, false), fixfn = pick_fix(tile_kb, h->W);
+        const size_t flds = gen4 ? lds_bytes_fast4(h) : gen2 ? lds_bytes_fast2(h, tile_kb) : lds_bytes_fast(h, tile_kb), fixlds = lds_bytes_fast(h, tile_kb);
+        const unsigned main_threads = gen4 ? (unsigned)tdk::F4_BLOCK : (unsigned)tdk::FBLOCK, fix_threads = gen4 ? 128u : (unsigned)tdk::FBLOCK;
         if (flds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
         if (fixlds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)fixfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fixlds));
         int bpc = h->blocks_per_cu;
         if (bpc <= 0) {
             if (h->occ_fn != (const void *)ffn || h->occ_lds != flds) {
                 int occ = 0;
-                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)ffn, tdk::FBLOCK, flds));
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)ffn, (int)main_threads, flds));
                 h->occ_fn = (const void *)ffn; h->occ_lds = flds; h->occ_val = std::max(1, occ);
             }
             bpc = h->occ_val;
@@ -509,14 +530,14 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
             e0 = h->ev_pool[h->ev_used].first; e1 = h->ev_pool[h->ev_used].second; h->ev_used++;
             HIPCHK(hipEventRecord(e0, stream));
         }
-        hipLaunchKernelGGL(ffn, dim3(grid), dim3(tdk::FBLOCK), flds, stream, fp);
+        hipLaunchKernelGGL(ffn, dim3(grid), dim3(main_threads), flds, stream, fp);
         {   // exact line phase of every tile (d_state is free on this path: it holds the block sums)
             const uint32_t rblocks = (ntiles + tdk::RESOLVE_SPAN - 1) / tdk::RESOLVE_SPAN;
             unsigned long long *super = reinterpret_cast<unsigned long long *>(h->d_state.p);
             hipLaunchKernelGGL(tdk::k_resolve_sums, dim3(rblocks), dim3(256), 0, stream, fp, super);
             hipLaunchKernelGGL(tdk::k_resolve, dim3(rblocks), dim3(1024), 0, stream, fp, super);
         }
-        hipLaunchKernelGGL(fixfn, dim3(std::min<uint32_t>(grid, (uint32_t)h->num_cu * 2)), dim3(tdk::FBLOCK), fixlds, stream, fp);
+        hipLaunchKernelGGL(fixfn, dim3(std::min<uint32_t>(grid, (uint32_t)h->num_cu * 2)), dim3(fix_threads), fixlds, stream, fp);
         HIPCHK(hipGetLastError());
         if (h->timing) HIPCHK(hipEventRecord(e1, stream));
         return TD_OK;
@@ -1886,7 +1907,7 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     else if (n == "timing") h->timing = value ? 1 : 0;
     else if (n == "fastpath") h->fastpath = value ? 1 : 0;
     else if (n == "kernel") {
-        if (value != 1 && value != 2) return fail(TD_E_ARG, "kernel must be 1 (k_fast) or 2 (k_fast2)");
+        if (value != 1 && value != 2 && value != 4) return fail(TD_E_ARG, "kernel must be 1 (k_fast), 2 (k_fast2) or 4 (k_fast4)");
         h->kernel_gen = (int)value;
     } else if (n == "tile_kb2") {
         if (value != 0 && value != 16 && value != 24 && value != 32) return fail(TD_E_ARG, "tile_kb2 must be 0 (automatic), 16, 24 or 32");

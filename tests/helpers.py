@@ -9,7 +9,7 @@ from oracle import c_oracle
 
 
 # Every way the count can be computed on the device (td_set_option names): the free-running path with its
-# second-generation main pass (k_fast2, 24 and 32 KiB tiles) and its first (k_fast, 32 and 16 KiB tiles), and
+# producer / consumer main pass (k_fast4, 12 KiB tiles), its second-generation main pass (k_fast2, 24 and 32 KiB tiles) and its first (k_fast, 32 and 16 KiB tiles), and
 # the exact look-back kernel.  All give the same counts.
 KERNEL_MODES = [
     dict(fastpath=1, kernel=2, tile_kb2=24),
@@ -18,6 +18,7 @@ KERNEL_MODES = [
     dict(fastpath=1, kernel=1, tile_kb=32),
     dict(fastpath=1, kernel=1, tile_kb=16),
     dict(fastpath=0, tile_kb=32),
+    dict(fastpath=1, kernel=4),
 ]
 DEFAULT_MODE = dict(fastpath=1, kernel=2, tile_kb2=0, tile_kb=32)
 

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 SHAPES = {
     "C2_96x10k": (2, 1_000_000, KERNEL_MODES),
     "C3_384x100k": (3, 2_000_000, KERNEL_MODES),
-    "C4_384x500k": (4, 1_000_000, [KERNEL_MODES[0], KERNEL_MODES[3], KERNEL_MODES[5]]),
+    "C4_384x500k": (4, 1_000_000, [KERNEL_MODES[0], KERNEL_MODES[3], KERNEL_MODES[5], KERNEL_MODES[6]]),
     "C5_CWGC_384x100k": (5, 1_000_000, KERNEL_MODES),
 }
 
