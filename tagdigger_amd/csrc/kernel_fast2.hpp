@@ -135,7 +135,9 @@ __device__ __forceinline__ uint4 lds_read16(const uint8_t *p) {
 // 16 * NQ bytes are staged behind it).  Returns 0 no barcode, 2 barcode+site only, 1 pending (pd filled,
 // bucket loads in flight), 6 the line opens with a blank (str.strip, reference :256): the caller re-reads it
 // from global memory.
-template <int W, int NQ>
+// ISSUE false: everything but the bucket loads (pd.R, pd.nr, pd.boff are filled; bucket_issue asks for the bucket later --
+// k_fast4's consumers finish the lines of their last tile in between).
+template <int W, int NQ, bool ISSUE = true>
 __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx &cx, const uint8_t *L_raw, uint32_t srel,
                                                  Pending<W> &pd) {
     // NQ: 16-byte pieces packed from the line's first byte (compile time: all reads are issued before the
@@ -218,13 +220,25 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
         pd.boff = bk * (uint32_t)(BUCKET_U4_ * 16);
         const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(p.buckets) + pd.boff);
         pd.boff |= hk >> 27;                                // (the key's bit in the buckets' overflow filters)
+        if (ISSUE) {
 #pragma unroll
-        for (int q = 0; q < BUCKET_U4_; q++) pd.b[q] = bp[q];   // in flight: first used by match_finish
+            for (int q = 0; q < BUCKET_U4_; q++) pd.b[q] = bp[q];   // in flight: first used by match_finish
+        }
     } else if (p.nshort == 0) {
         return 2u;
     }
     TD_MSTAMP(cx, 12, 0);    // D: tag words, hash, bucket loads issued
     return 1u;
+}
+// the loads line_prepare<W, NQ, false> left out
+template <int W>
+__device__ __forceinline__ void bucket_issue(const KParams &p, Pending<W> &pd) {
+    constexpr int BUCKET_U4_ = W <= 3 ? 4 : 8;
+    if (pd.nr & PD_PROBE) {
+        const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(p.buckets) + (pd.boff & ~(uint32_t)(BUCKET_U4_ * 16 - 1)));
+#pragma unroll
+        for (int q = 0; q < BUCKET_U4_; q++) pd.b[q] = bp[q];
+    }
 }
 
 // wave priority per phase (s_setprio): the pending line + next tile's loads, phases C-D, phases A-B of the next tile

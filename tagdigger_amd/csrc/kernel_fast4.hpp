@@ -42,6 +42,9 @@ constexpr uint32_t F4_WBYTES = F4_WCH * 16;
 constexpr uint32_t F4_TILE = F4_PROD * F4_WBYTES;           // 12 KiB
 constexpr int F4_SLOTS = 3;
 constexpr uint32_t F4_SPIN_LIMIT = 1u << 18;
+#ifndef TD_F4_P_CONS
+#define TD_F4_P_CONS 2              // wave priority of the consumers (the producers run at 0)
+#endif
 // hand-off words of a slot (dwords in LDS)
 enum { F4_DONE = 0, F4_READY = 1, F4_FREE = 2, F4_FLAGS = 3, F4_TOT = 4 /* 3 */, F4_VOTE = 7 /* 3 */, F4_R0 = 10, F4_WB1 = 11, F4_WB2 = 12,
        F4_TOTAL = 13, F4_REGULAR = 14, F4_CTRL_DW = 16 };
@@ -66,9 +69,21 @@ __device__ __forceinline__ bool f4_wait(uint32_t *p, uint32_t need, uint32_t *ab
     return true;
 }
 
+// diagnostic build only (-DTD_PHASE_PROF): lane 0 of every wave adds the shader-clock cycles between stamps to stats[8 + i]
+// (producers 0-4: waiting for the slot, A, B + lists, closing a tile, -; consumers 5-8: pending lines, waiting for a tile, matching, rest)
+#ifdef TD_PHASE_PROF
+#define F4_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); f4acc[i] += now_ - f4last; f4last = now_; } while (0)
+#else
+#define F4_STAMP(i) do {} while (0)
+#endif
+
 template <int W, int NQ>
 __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
     const KParams &p = fp.k;
+#ifdef TD_PHASE_PROF
+    unsigned long long f4acc[12] = {};
+    unsigned long long f4last = __builtin_amdgcn_s_memtime();
+#endif
     constexpr uint32_t TILE = F4_TILE, WCH = F4_WCH, WBYTES = F4_WBYTES;
     constexpr int CPT = F4_CPT;
     static_assert(W <= 3, "k_fast4 has the pipelined probe of the 64-byte buckets only");
@@ -131,8 +146,7 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
             return n;
         };
         uint32_t t = blockIdx.x * RUN, run_pos = 0, k = 0;
-        uint32_t carry_r0 = 0;                                              // (kept by every producer: any of them may close a tile)
-        bool carry_ok = false;
+        bool carry_ok = false;                                              // the tile continues its predecessor's run: the phase is carried
         // the tiles after this one and after that (their bytes in flight)
         uint32_t rp1 = 0, t1 = next_tile(t, rp1), rp2 = rp1, t2 = next_tile(t1, rp2);
         if (t < nwork) fetch_tile(va, vha, t);
@@ -146,7 +160,9 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
             uint32_t *ctrl = L_ctrl + slot * F4_CTRL_DW;
             const uint64_t tbase = (uint64_t)t * TILE;
             // the slot must have been given back as often as it has been used
+            F4_STAMP(4);
             if (!f4_wait(ctrl + F4_FREE, use, L_abort, p.stats)) return false;
+            F4_STAMP(0);
             // ---------------- A: raw bytes and terminator masks -> LDS
             bool wave_crb = false;
             uint32_t myflags = 0;
@@ -194,6 +210,7 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
             if (wave == F4_PROD - 1 && __any(has_halo && ((vh.x | vh.y | vh.z | vh.w) & 0x80808080u) != 0)) myflags |= F4_FLAG_HALO_HI;
             if (t2 < nwork) fetch_tile(v, vh, t2);
             wave_lds_fence();          // this wave's masks and raw bytes are in LDS
+            F4_STAMP(1);
 
             // ---------------- B: terminators of this lane's CPT consecutive chunks, wave scan, vote, list of line starts
             uint32_t mm[CPT / 2];
@@ -284,13 +301,11 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
                 if (myflags) __hip_atomic_fetch_or(ctrl + F4_FLAGS, myflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             wave_lds_fence();          // raw bytes, halo, lists, totals: stored
+            F4_STAMP(2);
             // ---------------- the producer that arrives last closes the tile
             uint32_t arrived = 0;
             if (lane == 0) arrived = __hip_atomic_fetch_add(ctrl + F4_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
             arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
-            // (every producer keeps the phase it would carry: it needs the tile's total, which only the closer has for sure --
-            // the others wait for READY, which the closer sets; that wait is short and ends before their next tile's slot
-            // could be given back anyway)
             if (arrived == (uint32_t)F4_PROD * (use + 1u)) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const uint32_t t_x = lds_ld(ctrl + F4_TOT + 0), t_y = lds_ld(ctrl + F4_TOT + 1), t_z = lds_ld(ctrl + F4_TOT + 2);
@@ -298,7 +313,11 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
                 const uint32_t wb1 = t_x, wb2 = wb1 + t_y, total = wb2 + t_z;
                 uint32_t r0;
                 if (carry_ok) {
-                    r0 = carry_r0;
+                    // (the tile before this one in the run: closed before its closer arrived here -- every producer arrives at
+                    // tile k before it arrives at tile k + 1 -- and its slot is not closed again before this producer has
+                    // been through it once more)
+                    const uint32_t *prev = L_ctrl + ((k + (uint32_t)F4_SLOTS - 1u) % (uint32_t)F4_SLOTS) * F4_CTRL_DW;
+                    r0 = (lds_ld(prev + F4_R0) - lds_ld(prev + F4_TOTAL)) & 3u;
                 } else if (t != 0) {
                     auto rot = [](uint32_t pk, uint32_t by) { const uint32_t r = 8u * (by & 3u); return r ? ((pk << r) | (pk >> (32u - r))) : pk; };
                     const uint32_t a = lds_ld(ctrl + F4_VOTE + 0), b = rot(lds_ld(ctrl + F4_VOTE + 1), wb1), c = rot(lds_ld(ctrl + F4_VOTE + 2), wb2);
@@ -321,12 +340,7 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) lds_st(ctrl + F4_READY, k + 1u);
-            }
-            // the phase the next tile of the run is counted under: r0 - total (mod 4), from what the closer published
-            if (!f4_wait(ctrl + F4_READY, k + 1u, L_abort, p.stats)) return false;
-            {
-                const uint32_t r0 = lds_ld(ctrl + F4_R0), total = lds_ld(ctrl + F4_TOTAL);
-                carry_r0 = (r0 - total) & 3u;
+                F4_STAMP(3);
             }
             return true;
         };
@@ -340,6 +354,9 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
             { const uint32_t nit = t1; carry_ok = nit == t + 1u && t != 0u; t = t1; run_pos = rp1; t1 = t2; rp1 = rp2; t2 = next_tile(t1, rp2); k++; }
         }
         (void)run_pos;
+#ifdef TD_PHASE_PROF
+        if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(p.stats + 8 + i, f4acc[i]);
+#endif
         return;
     }
 
@@ -365,6 +382,22 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
         hit = kind == 2 && !(TD_DBG(p) & DBG_NO_ATOMIC);
         cell = (uint32_t)res;
     };
+    // (the consumers are the narrow place of the pipeline: their instructions go first)
+    __builtin_amdgcn_s_setprio(TD_F4_P_CONS);
+    Pending<W> nx;                                          // a line whose bucket has not been asked for yet (R, nr, boff only)
+    // the pending lines of the tile before: compares and count
+    auto settle = [&]() {
+        if (__any(pd_valid)) {
+            bool phit = false; uint32_t pcell = 0;
+            if (pd_valid) finish_pending(phit, pcell);
+            pd_valid = false;
+            if (hc_on) {
+                const uint32_t h = hc_hash(pcell);
+                hc_hits += (uint32_t)__builtin_popcountll(__ballot(phit && hcS[h].x == pcell));
+            }
+            hc_commit(p.counts, hcS, hcE, phit, pcell, (uint32_t)lane, hc_on);
+        }
+    };
     uint32_t t = blockIdx.x * RUN, run_pos = 0;
     for (uint32_t k = 0; t < nwork; k++) {
         if ((k & 1u) == (uint32_t)cons) {
@@ -373,18 +406,10 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
             const uint16_t *Ll = L_list0 + slot * F4_PROD * WCH;
             uint32_t *ctrl = L_ctrl + slot * F4_CTRL_DW;
             const uint64_t tbase = (uint64_t)t * TILE;
-            // the lines the last own tile left pending: their buckets have had the other consumer's tile to arrive
-            if (pd_valid) {
-                bool phit; uint32_t pcell;
-                finish_pending(phit, pcell);
-                pd_valid = false;
-                if (hc_on) {
-                    const uint32_t h = hc_hash(pcell);
-                    hc_hits += (uint32_t)__builtin_popcountll(__ballot(phit && hcS[h].x == pcell));
-                }
-                hc_commit(p.counts, hcS, hcE, phit, pcell, (uint32_t)lane, hc_on);
-            }
+            F4_STAMP(8);
+            F4_STAMP(5);
             if (!f4_wait(ctrl + F4_READY, k + 1u, L_abort, p.stats)) break;
+            F4_STAMP(6);
             const uint32_t r0 = lds_ld(ctrl + F4_R0), wb1 = lds_ld(ctrl + F4_WB1), wb2 = lds_ld(ctrl + F4_WB2), total = lds_ld(ctrl + F4_TOTAL);
             const bool regular = lds_ld(ctrl + F4_REGULAR) != 0;
             if (regular && !(TD_DBG(p) & DBG_NO_PHASE2)) {
@@ -403,9 +428,9 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
                         sel = o >= wb2 ? 2u * WCH - wb2 : sel;
                         srel = Ll[o + sel];
                         // (a line that starts in the tile's last bytes is still whole in the staged window: the halo holds 16 NQ bytes and more)
-                        kres = line_prepare<W, NQ>(p, cx, L_raw, srel, pd);
+                        kres = line_prepare<W, NQ, false>(p, cx, L_raw, srel, nx);
                     }
-                    // kres: 0 no barcode, 2 barcode only, 1 pending (bucket in flight), 6 leading blank (rare: raw bytes re-read)
+                    // kres: 0 no barcode, 2 barcode only, 1 the tag is to be looked up, 6 leading blank (rare: raw bytes re-read)
                     st_reads += kres == 0u || kres == 2u ? 1 : 0;
                     st_bar += kres == 2u ? 1 : 0;
                     if (keep) {
@@ -413,14 +438,17 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         if (lane == 0) lds_st(ctrl + F4_FREE, use + 1u);
                     }
+                    F4_STAMP(7);
+                    // the lines that have been pending since the tile (or pass) before: their buckets were asked for a whole
+                    // line_prepare ago -- then this pass's buckets, which stay in flight
+                    settle();
+                    F4_STAMP(5);
                     if (kres == 1u) {
-                        if (keep) pd_valid = true;
-                        else {
-                            bool h; uint32_t c;
-                            finish_pending(h, c);
-                            hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
-                            vm_settled();
-                        }
+#pragma unroll
+                        for (int w = 0; w < W; w++) pd.R[w] = nx.R[w];
+                        pd.nr = nx.nr; pd.boff = nx.boff;
+                        bucket_issue<W>(p, pd);
+                        pd_valid = true;
                     }
                     if (__builtin_expect(__any(kres == 6u), 0)) {
                         if (kres == 6u) {
@@ -441,6 +469,7 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
             } else {
                 if (lane == 0) lds_st(ctrl + F4_FREE, use + 1u);
             }
+            F4_STAMP(7);
             if (p.hot_cache && ++aged == HC_AGE_TILES) {
                 aged = 0;
                 if (hc_on) {
@@ -455,12 +484,11 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
         run_pos = run_pos + 1u < RUN ? run_pos + 1u : 0u;
         t = n;
     }
-    if (pd_valid) {
-        bool h; uint32_t c;
-        finish_pending(h, c);
-        hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
-    }
+    settle();
     if (p.hot_cache) hc_flush(p.counts, hcS, (uint32_t)lane);
+#ifdef TD_PHASE_PROF
+    if (lane == 0) for (int i = 5; i < 9; i++) atomicAdd(p.stats + 8 + i, f4acc[i]);
+#endif
     unsigned long long r = wave_sum64((unsigned long long)(long long)st_reads), b = wave_sum64((unsigned long long)(long long)st_bar),
                        g = wave_sum64((unsigned long long)(long long)st_tag);
     if (lane == 0) {

@@ -28,6 +28,11 @@ NAMES2 = ["loop head", "A: wait bytes, raw + masks -> LDS (own quarter)", "B: ma
           "  D: list + pieces from LDS", "  D: pack + nvalid", "  D: barcode walk", "  D: tag words, hash, bucket loads", "-", "-", "-", "-", "-", "-", "-"]
 
 
+NAMES4 = ["producer: waiting for the slot", "producer: A (wait bytes, raw + masks -> LDS, next loads)", "producer: B (scan, vote, lists)",
+          "producer: closing a tile", "producer: loop", "consumer: pending lines", "consumer: waiting for a tile", "consumer: matching",
+          "consumer: loop", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=50_000_000)
@@ -50,7 +55,8 @@ def main():
     eng.set_option("tile_kb", a.tile_kb)
     eng.set_option("prescan", a.prescan)
     eng.set_option("kernel", a.kernel)
-    eng.set_option("tile_kb2", a.tile_kb2)
+    if a.kernel == 2:
+        eng.set_option("tile_kb2", a.tile_kb2)
     for kv in a.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v, 0))
@@ -63,11 +69,11 @@ def main():
     ms, _ = eng.kernel_time_ms()
     c = list(eng.debug_counters()[:20]); c[11] = 0
     tot = float(sum(c[:20])) or 1.0
-    tkb = a.tile_kb2 if a.kernel == 2 else a.tile_kb
+    tkb = 12 if a.kernel == 4 else a.tile_kb2 if a.kernel == 2 else a.tile_kb
     ntiles = (cfg.nbytes() + tkb * 1024 - 1) // (tkb * 1024)
     print("kernel=%d tile_kb=%d blocks_per_cu=%s prescan=%d  kernel %.2f ms (stamped build)  tiles=%d" % (
         a.kernel, tkb, a.blocks_per_cu or "auto", a.prescan, ms, ntiles))
-    for n, v in zip(NAMES2 if a.kernel == 2 else NAMES, c):
+    for n, v in zip(NAMES4 if a.kernel == 4 else NAMES2 if a.kernel == 2 else NAMES, c):
         print("  %-24s %6.2f %%   %8.0f cycles/tile" % (n, 100.0 * v / tot, v / ntiles))
     print("  %-24s            %8.0f cycles/tile" % ("total", tot / ntiles))
     eng.dev_free(d)
