@@ -137,9 +137,24 @@ __device__ __forceinline__ uint4 lds_read16(const uint8_t *p) {
 // from global memory.
 // ISSUE false: everything but the bucket loads (pd.R, pd.nr, pd.boff are filled; bucket_issue asks for the bucket later --
 // k_fast4's consumers finish the lines of their last tile in between).
+// the NQ 16-byte pieces of the line whose first byte sits at L_raw[srel], requested together (line_prepare_q takes them on)
+template <int NQ>
+__device__ __forceinline__ void line_read(const uint8_t *L_raw, uint32_t srel, uint4 (&q)[NQ]) {
+    const uint8_t *src = L_raw + srel;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) q[i] = lds_read16(src + 16 * i);
+}
+template <int W, int NQ, bool ISSUE = true>
+__device__ __forceinline__ uint32_t line_prepare_q(const KParams &p, const TileCtx &cx, const uint4 (&q)[NQ], Pending<W> &pd);
 template <int W, int NQ, bool ISSUE = true>
 __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx &cx, const uint8_t *L_raw, uint32_t srel,
                                                  Pending<W> &pd) {
+    uint4 q[NQ];
+    line_read<NQ>(L_raw, srel, q);
+    return line_prepare_q<W, NQ, ISSUE>(p, cx, q, pd);
+}
+template <int W, int NQ, bool ISSUE>
+__device__ __forceinline__ uint32_t line_prepare_q(const KParams &p, const TileCtx &cx, const uint4 (&q)[NQ], Pending<W> &pd) {
     // NQ: 16-byte pieces packed from the line's first byte (compile time: all reads are issued before the
     // first piece is packed, and the pieces' dependent chains interleave)
     static_assert(NQ >= 2 && NQ <= 2 * W + 4, "pieces per line");
@@ -147,10 +162,6 @@ __device__ __forceinline__ uint32_t line_prepare(const KParams &p, const TileCtx
     uint32_t inv[(NQ + 1) / 2];
 #pragma unroll
     for (int i = 0; i < (NQ + 1) / 2; i++) inv[i] = 0;
-    const uint8_t *src = L_raw + srel;
-    uint4 q[NQ];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) q[i] = lds_read16(src + 16 * i);
     TD_MSTAMP(cx, 9, 1);     // D: line start from the list + the line's pieces from LDS (waited for)
     const uint32_t first = q[0].x & 0xFFu;
 #pragma unroll

@@ -4,52 +4,59 @@
 // k_fast2 (kernel_fast2.hpp) takes every tile through phases A-B (all four waves: terminators, lists of line starts),
 // a barrier, phases C-D (the wanted lines matched by the two waves whose lanes they fill) and a second barrier: per
 // tile the four waves can issue 4 x (A-B + D) instructions' worth of time but only have 4 x A-B + 2 x D to issue --
-// 72 % at best -- and every wave stands at two barriers behind the slowest.  Here a workgroup is five waves:
+// 72 % at best -- and every wave stands at two barriers behind the slowest.  Here a workgroup is eight waves:
 //
-//   producers (waves 0-2)  stream the FASTQ.  A tile is 12 KiB, one third per producer; the next TWO tiles' bytes are in
+//   producers (waves 0-3)  stream the FASTQ.  A tile is 16 KiB, a quarter per producer; the next TWO tiles' bytes are in
 //                          flight in registers.  Per tile: raw bytes -> the tile's slot in LDS (a ring of three slots),
 //                          terminator masks, the list of the wave's line starts (k_fast2's phases A and B, nothing
 //                          shared between the producers).  The last of them to finish a tile ("closer": the wave whose
-//                          arrival makes three) adds up the three terminator counts, carries the line phase inside a
-//                          run or takes the vote at its start, writes the tile's word for k_resolve and opens the slot
-//                          to the consumers.
-//   consumers (waves 3-4)  match.  Each takes every other tile: the wanted lines (every fourth line start, by the phase the
-//                          closer left) with full lanes -- 56 lines of 100 bp reads on 64 lanes -- through
-//                          line_prepare (kernel_fast2.hpp: pack from the line's first byte, barcode directory, tag hash,
-//                          bucket loads left in flight), gives the slot back as soon as the lines' bytes have been read,
-//                          and finishes the pending lines (compares, count) before it takes its next tile.
+//                          arrival makes four) adds up the terminator counts, carries the line phase inside a run or
+//                          takes the vote at its start, writes the tile's word for k_resolve, and publishes how many wanted
+//                          lines (every fourth line start) the tile holds and how many the workgroup's tiles held before it.
+//   consumers (waves 4-7)  match.  The wanted lines of the workgroup's tiles form ONE sequence; a consumer claims the next 64
+//                          of it (a compare-and-swap on a cursor in LDS) whatever tiles they lie in -- always full lanes,
+//                          whatever the read length -- finds each lane's tile among the ring's slots, runs line_prepare
+//                          (kernel_fast2.hpp: pack from the line's first byte, barcode directory, tag hash), takes the
+//                          lines off their tiles' counts (the consumer that takes a tile's last line gives the slot back),
+//                          finishes the lines it left pending a pass ago (compares, count) and only then asks for this
+//                          pass's tag buckets, which stay in flight until the next pass.
 //
-// Hand-offs are words in LDS: per slot a count of producers that are through with it, the sequence number of the tile
-// that is ready in it, the number of times it has been given back.  A wave's LDS operations execute in order, so a wave
-// that drains its stores (s_waitcnt lgkmcnt(0)) before it touches the hand-off word has published them.  Every wait
-// is bounded: a wave that waits too long raises ERR_SPIN and sets an abort word that ends every loop of the workgroup
-// (the host then reports TD_E_INTERNAL; it cannot happen: tile k's production needs only tile k - 3 matched, which
-// needs tile k - 3 produced).  Instruction count per byte equals k_fast2's; what changes is who waits for whom: three
-// producers carry ~200 instructions a tile each and two consumers ~400 per own tile -- 97 % of the five waves' issue
-// time has an instruction to issue -- and nobody waits for a wave of the other role unless the ring is full or empty.
+// Hand-offs are words in LDS.  A wave's LDS operations execute in order, so a wave that drains its stores (s_waitcnt
+// lgkmcnt(0)) before it touches a hand-off word has published them.  Every wait is bounded: a wave that waits too long
+// raises ERR_SPIN and sets an abort word that ends every loop of the workgroup (the host then reports TD_E_INTERNAL).
+// No wait can last: a tile's production needs its slot's previous tile matched, which needs that tile produced -- an
+// earlier one; and a consumer that finds fewer than 64 lines takes what there is as soon as the next tile cannot be
+// produced before lines are matched (its slot has not been given back), or the workgroup's tiles are through.
+// Eight waves: two per SIMD and workgroup, two workgroups per CU (a five-wave workgroup -- three producers, two
+// consumers, the first form of this kernel -- is admitted only two to a CU: ten waves).
 // Tiles that are not "regular" (the buffer's first and last, bytes >= 0x80, '\r' at the end of a chunk next to another
 // wave's bytes, more line starts than a list holds) are only counted here (terminators) and flagged TI_SKIP for the
-// fix-up pass (k_fast<6, W, true, 128>: 128 threads x 6 chunks = the same 12 KiB tile), as in k_fast2.
+// fix-up pass (k_fast<4, W, true>: the same 16 KiB tile), as in k_fast2.
 #pragma once
 #include "kernel_fast2.hpp"
 
 namespace tdk {
 
-constexpr int F4_PROD = 3, F4_CONS = 2, F4_WAVES = F4_PROD + F4_CONS, F4_BLOCK = 64 * F4_WAVES;
+constexpr int F4_PROD = 4, F4_CONS = 4, F4_WAVES = F4_PROD + F4_CONS, F4_BLOCK = 64 * F4_WAVES;
 constexpr int F4_CPT = 4;                                   // 16-byte chunks per producer lane and tile
 constexpr uint32_t F4_WCH = F4_CPT * 64;                    // chunks per producer and tile
 constexpr uint32_t F4_WBYTES = F4_WCH * 16;
-constexpr uint32_t F4_TILE = F4_PROD * F4_WBYTES;           // 12 KiB
+constexpr uint32_t F4_TILE = F4_PROD * F4_WBYTES;           // 16 KiB
 constexpr int F4_SLOTS = 3;
 constexpr uint32_t F4_SPIN_LIMIT = 1u << 18;
 #ifndef TD_F4_P_CONS
-#define TD_F4_P_CONS 2              // wave priority of the consumers (the producers run at 0)
+#define TD_F4_P_CONS 1              // wave priority of the consumers (the producers run at 0)
 #endif
-// hand-off words of a slot (dwords in LDS)
-enum { F4_DONE = 0, F4_READY = 1, F4_FREE = 2, F4_FLAGS = 3, F4_TOT = 4 /* 3 */, F4_VOTE = 7 /* 3 */, F4_R0 = 10, F4_WB1 = 11, F4_WB2 = 12,
-       F4_TOTAL = 13, F4_REGULAR = 14, F4_CTRL_DW = 16 };
+#ifndef TD_F4_NPROD
+#define TD_F4_NPROD 5               // producer waves of the eight (they take the quarter-tile jobs in turn); the others match
+#endif
+// hand-off words of a slot (dwords in LDS; F4_R0..F4_WB3 are read as one 16-byte word, F4_NCUM + F4_NWANT as one 8-byte word)
+enum { F4_DONE = 0, F4_FREE = 1, F4_REMAIN = 2, F4_FLAGS = 3, F4_TOT = 4 /* 4 */, F4_VOTE = 8 /* 4 */, F4_R0 = 12, F4_WB1 = 13, F4_WB2 = 14,
+       F4_WB3 = 15, F4_TOTAL = 16, F4_SEQ = 17, F4_NCUM = 18, F4_NWANT = 19, F4_TIDX = 20, F4_CTRL_DW = 24 };
 constexpr uint32_t F4_FLAG_HI = 1, F4_FLAG_OVER = 2, F4_FLAG_HALO_HI = 4;
-constexpr uint32_t F4_ABORT_DW = F4_SLOTS * F4_CTRL_DW;     // one word behind the slots' hand-off words
+// the workgroup's words behind the slots': abort, tiles closed, wanted lines in them, wanted lines claimed
+constexpr uint32_t F4_ABORT_DW = F4_SLOTS * F4_CTRL_DW, F4_READY_DW = F4_ABORT_DW + 1, F4_AVAIL_DW = F4_ABORT_DW + 2, F4_CLAIMED_DW = F4_ABORT_DW + 3;
+constexpr uint32_t F4_CTRL_BYTES = 512;
 
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
     uint16_t *L_list0 = reinterpret_cast<uint16_t *>(lds + F4_SLOTS * slot_bytes);          // [slot][producer][WCH]: masks, then line starts
     uint32_t *L_ctrl = reinterpret_cast<uint32_t *>(lds + F4_SLOTS * slot_bytes + F4_SLOTS * F4_PROD * WCH * 2u);
     uint32_t *L_abort = L_ctrl + F4_ABORT_DW;
-    uint8_t *L_hc = reinterpret_cast<uint8_t *>(L_ctrl + 64);
+    uint8_t *L_hc = reinterpret_cast<uint8_t *>(L_ctrl) + F4_CTRL_BYTES;
     uint8_t *L_bidx = L_hc + F4_CONS * HC_BYTES_PER_WAVE;
     TileCtx cx{nullptr, 0u, reinterpret_cast<const unsigned long long *>(L_bidx),
                reinterpret_cast<const uint32_t *>(L_bidx + p.off_bmeta),
@@ -105,14 +112,13 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (uint32_t i = tid; i < p.bblob_bytes / 4; i += F4_BLOCK)
         reinterpret_cast<uint32_t *>(L_bidx)[i] = p.bblob[i];
-    if (tid < 64) L_ctrl[tid] = 0;
+    if (tid < (int)(F4_CTRL_BYTES / 4)) L_ctrl[tid] = 0;
     __syncthreads();
 
     const unsigned long long carried = p.cursor_in ? *p.cursor_in : 0ull;
     const uint64_t first_line = p.first_line + carried;
     const uint32_t nwork = p.ntiles;
     const uint32_t RUN = p.run ? p.run : 1u;
-    const uint32_t jump = (gridDim.x - 1u) * RUN;                          // from a run's last tile to the next run's first
     auto tile_base = [&](uint32_t tile) -> const uint8_t * {
         return tile >= p.tail_tile ? p.tail_buf + (uint64_t)(tile - p.tail_tile) * TILE : p.buf + (uint64_t)tile * TILE;
     };
@@ -121,46 +127,60 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base(tile)), 0, (int)(TILE + 4096u), 0x00020000);
     };
 
-    if (wave < F4_PROD) {
-        // ================================================================ producer
-        const uint32_t voff = (uint32_t)wave * WBYTES + (uint32_t)lane * 16u;     // this lane's first chunk; chunk j is 1 KiB further
-        const bool has_halo = wave == F4_PROD - 1 && (uint32_t)lane < halo / 16u;   // (the halo is the last producer's)
-        const uint32_t hoff = has_halo ? (uint32_t)lane * 16u : 0x40000000u;       // (beyond every descriptor's range: reads as zero)
-        // a tile's bytes in registers: this lane's CPT chunks, and -- the last producer's first lanes -- the halo behind the
+    // ---------------------------------------------------------------- producing: a job is a quarter of a tile; job 4 k + q goes
+    // to producer (4 k + q) mod NPROD
+    constexpr uint32_t NPROD = TD_F4_NPROD;
+    static_assert(TD_F4_NPROD >= 1 && TD_F4_NPROD < F4_WAVES, "producers and consumers");
+    {
+        // a job's bytes in registers: this lane's CPT chunks, and -- the last quarter's first lanes -- the halo behind the
         // tile (every lane asks: the others for an offset beyond the descriptor's range, which returns zeros without touching
-        // memory, so that the loads are unconditional straight-line code the wait counts can leave in flight)
+        // memory, so that the loads are unconditional straight-line code the wait counts can leave in flight).  A producer
+        // has its next TWO jobs' bytes in flight.
         uint4 va[CPT], vb[CPT];
         u32x4 vha, vhb;
-        auto fetch_tile = [&](uint4 (&v)[CPT], u32x4 &vh, uint32_t tile) {
+        auto fetch_job = [&](uint4 (&v)[CPT], u32x4 &vh, uint32_t tile, uint32_t q) {
+            const uint32_t voff = q * WBYTES + (uint32_t)lane * 16u;               // this lane's first chunk; chunk j is 1 KiB further
+            const bool hh = q == (uint32_t)F4_PROD - 1u && (uint32_t)lane < halo / 16u;   // (the halo is the last quarter's)
+            const uint32_t hoff = hh ? (uint32_t)lane * 16u : 0x40000000u;         // (beyond every descriptor's range: reads as zero)
             const __amdgpu_buffer_rsrc_t rs = tile_rsrc(tile);
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
-                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * 1024, 2 /* nt */);
-                v[j] = make_uint4(q.x, q.y, q.z, q.w);
+                const u32x4 qq = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * 1024, 2 /* nt */);
+                v[j] = make_uint4(qq.x, qq.y, qq.z, qq.w);
             }
             vh = __builtin_amdgcn_raw_buffer_load_b128(rs, hoff, (int)TILE, 0);
         };
-        auto next_tile = [&](uint32_t t, uint32_t &run_pos) -> uint32_t {
-            const uint32_t n = run_pos + 1u < RUN ? t + 1u : t + 1u + jump;
-            run_pos = run_pos + 1u < RUN ? run_pos + 1u : 0u;
-            return n;
-        };
-        uint32_t t = blockIdx.x * RUN, run_pos = 0, k = 0;
-        bool carry_ok = false;                                              // the tile continues its predecessor's run: the phase is carried
-        // the tiles after this one and after that (their bytes in flight)
-        uint32_t rp1 = 0, t1 = next_tile(t, rp1), rp2 = rp1, t2 = next_tile(t1, rp2);
-        if (t < nwork) fetch_tile(va, vha, t);
-        if (t1 < nwork) fetch_tile(vb, vhb, t1);
+        // the workgroup's tiles in the order it takes them: runs of RUN consecutive tiles, run r of the buffer to workgroup r mod grid
+        auto tile_of = [&](uint32_t k) -> uint32_t { return (k / RUN) * (gridDim.x * RUN) + blockIdx.x * RUN + k % RUN; };
+        uint32_t n_local = 0;
+        for (uint32_t first = blockIdx.x * RUN; first < nwork; first += gridDim.x * RUN) n_local += min(RUN, nwork - first);
+        // this producer's next job (its bytes in flight)
+        uint32_t my_job = (uint32_t)wave;
+        if (wave < (int)NPROD) {
+            if (my_job < 4u * n_local) fetch_job(va, vha, tile_of(my_job >> 2), my_job & 3u);
+            if (my_job + NPROD < 4u * n_local) fetch_job(vb, vhb, tile_of((my_job + NPROD) >> 2), (my_job + NPROD) & 3u);
+        }
+        uint32_t *g_ready = L_ctrl + F4_READY_DW, *g_avail = L_ctrl + F4_AVAIL_DW, *g_claimed = L_ctrl + F4_CLAIMED_DW;
 
         // one tile from the registers v (its bytes were requested two tiles ago); afterwards v holds the tile after next
-        auto produce = [&](uint4 (&v)[CPT], u32x4 &vh) -> bool {
+        if (wave < (int)NPROD) {
+        // quarter qtr of tile number k of the workgroup (tile t of the buffer) from the registers v -- its bytes were requested
+        // a job ago; afterwards v holds the bytes of the producer's next job
+        auto produce = [&](uint4 (&v)[CPT], u32x4 &vh, const uint32_t k, const uint32_t t) -> bool {
+            const uint32_t qtr = my_job & 3u;
+            const uint32_t voff = qtr * WBYTES + (uint32_t)lane * 16u;
+            const bool has_halo = qtr == (uint32_t)F4_PROD - 1u && (uint32_t)lane < halo / 16u;
             const uint32_t slot = k % (uint32_t)F4_SLOTS, use = k / (uint32_t)F4_SLOTS;
             uint8_t *L_raw = L_raw0 + slot * slot_bytes;
-            uint16_t *Ll = L_list0 + (slot * F4_PROD + (uint32_t)wave) * WCH;
+            uint16_t *Ll = L_list0 + (slot * F4_PROD + qtr) * WCH;
             uint32_t *ctrl = L_ctrl + slot * F4_CTRL_DW;
             const uint64_t tbase = (uint64_t)t * TILE;
-            // the slot must have been given back as often as it has been used
+            const bool carry_ok = k % RUN != 0u && t != 1u;                       // the tile continues its predecessor's run: the phase is carried
+            const uint32_t job2 = my_job + 2u * NPROD;                            // (the job whose bytes take these registers)
+            const bool more = job2 < 4u * n_local;
+            const uint32_t t2 = more ? tile_of(job2 >> 2) : 0u;
             F4_STAMP(4);
+            // the slot must have been given back as often as it has been used
             if (!f4_wait(ctrl + F4_FREE, use, L_abort, p.stats)) return false;
             F4_STAMP(0);
             // ---------------- A: raw bytes and terminator masks -> LDS
@@ -207,8 +227,9 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
             // the halo, then the tile after next: its bytes take this tile's registers
             if (has_halo) *reinterpret_cast<uint4 *>(L_raw + TILE + (uint32_t)lane * 16u) = make_uint4(vh.x, vh.y, vh.z, vh.w);
             // (lines that begin in this tile are packed from these bytes with the ASCII forms)
-            if (wave == F4_PROD - 1 && __any(has_halo && ((vh.x | vh.y | vh.z | vh.w) & 0x80808080u) != 0)) myflags |= F4_FLAG_HALO_HI;
-            if (t2 < nwork) fetch_tile(v, vh, t2);
+            if (qtr == (uint32_t)F4_PROD - 1u && __any(has_halo && ((vh.x | vh.y | vh.z | vh.w) & 0x80808080u) != 0)) myflags |= F4_FLAG_HALO_HI;
+            const uint32_t my_qtr = qtr;
+            if (more) fetch_job(v, vh, t2, job2 & 3u);
             wave_lds_fence();          // this wave's masks and raw bytes are in LDS
             F4_STAMP(1);
 
@@ -216,8 +237,8 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
             uint32_t mm[CPT / 2];
 #pragma unroll
             for (int i = 0; i < CPT / 2; i++) mm[i] = reinterpret_cast<const uint32_t *>(Ll)[lane * (CPT / 2) + i];
-            const uint32_t span0 = (uint32_t)wave * WBYTES + (uint32_t)lane * (CPT * 16u);
-            const uint32_t wend = ((uint32_t)wave + 1u) * WBYTES;               // end of this wave's third
+            const uint32_t span0 = my_qtr * WBYTES + (uint32_t)lane * (CPT * 16u);
+            const uint32_t wend = (my_qtr + 1u) * WBYTES;                          // end of this wave's quarter
             if (__builtin_expect(wave_crb, 0)) {
                 // a chunk whose last byte is '\r' (bit 15 of its mask is set for it -- or for a '\n' there): one terminator
                 // with the '\n' that opens the next chunk, if there is one
@@ -265,7 +286,7 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
             // the lines behind this wave's terminators, by wave-local ordinal, into the space of its masks (every lane holds its
             // masks in registers by now: the fence below the read-back is the wave's own order of LDS operations)
             if (__builtin_expect(wtot <= WCH, 1)) {
-                uint16_t *spare = reinterpret_cast<uint16_t *>(L_ctrl + 60) + (uint32_t)wave;      // (a word nobody reads)
+                uint16_t *spare = reinterpret_cast<uint16_t *>(L_ctrl + 120 + (uint32_t)wave);     // (a word nobody reads)
                 uint32_t kk = incl - cnt, rest = 0;
 #pragma unroll
                 for (int i = 0; i < CPT / 2; i++) {
@@ -296,8 +317,8 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
                 myflags |= F4_FLAG_OVER;
             }
             if (lane == 0) {
-                lds_st(ctrl + F4_TOT + wave, wtot);
-                lds_st(ctrl + F4_VOTE + wave, packed);
+                lds_st(ctrl + F4_TOT + my_qtr, wtot);
+                lds_st(ctrl + F4_VOTE + my_qtr, packed);
                 if (myflags) __hip_atomic_fetch_or(ctrl + F4_FLAGS, myflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             wave_lds_fence();          // raw bytes, halo, lists, totals: stored
@@ -307,22 +328,22 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
             if (lane == 0) arrived = __hip_atomic_fetch_add(ctrl + F4_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
             arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
             if (arrived == (uint32_t)F4_PROD * (use + 1u)) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const uint32_t t_x = lds_ld(ctrl + F4_TOT + 0), t_y = lds_ld(ctrl + F4_TOT + 1), t_z = lds_ld(ctrl + F4_TOT + 2);
+                // (tiles are closed in their order: the one before this is produced by the workgroup's other four waves)
+                if (!f4_wait(g_ready, k, L_abort, p.stats)) return false;
+                const uint32_t t_x = lds_ld(ctrl + F4_TOT + 0), t_y = lds_ld(ctrl + F4_TOT + 1), t_z = lds_ld(ctrl + F4_TOT + 2), t_w = lds_ld(ctrl + F4_TOT + 3);
                 const uint32_t flags = lds_ld(ctrl + F4_FLAGS);
-                const uint32_t wb1 = t_x, wb2 = wb1 + t_y, total = wb2 + t_z;
+                const uint32_t wb1 = t_x, wb2 = wb1 + t_y, wb3 = wb2 + t_z, total = wb3 + t_w;
+                // (the tile before this one is closed, and its slot is not closed again before this tile has been matched)
+                const uint32_t *prev = L_ctrl + ((k + (uint32_t)F4_SLOTS - 1u) % (uint32_t)F4_SLOTS) * F4_CTRL_DW;
                 uint32_t r0;
                 if (carry_ok) {
-                    // (the tile before this one in the run: closed before its closer arrived here -- every producer arrives at
-                    // tile k before it arrives at tile k + 1 -- and its slot is not closed again before this producer has
-                    // been through it once more)
-                    const uint32_t *prev = L_ctrl + ((k + (uint32_t)F4_SLOTS - 1u) % (uint32_t)F4_SLOTS) * F4_CTRL_DW;
                     r0 = (lds_ld(prev + F4_R0) - lds_ld(prev + F4_TOTAL)) & 3u;
                 } else if (t != 0) {
                     auto rot = [](uint32_t pk, uint32_t by) { const uint32_t r = 8u * (by & 3u); return r ? ((pk << r) | (pk >> (32u - r))) : pk; };
-                    const uint32_t a = lds_ld(ctrl + F4_VOTE + 0), b = rot(lds_ld(ctrl + F4_VOTE + 1), wb1), c = rot(lds_ld(ctrl + F4_VOTE + 2), wb2);
-                    const uint32_t v02 = (a & 0x00FF00FFu) + (b & 0x00FF00FFu) + (c & 0x00FF00FFu);
-                    const uint32_t v13 = ((a >> 8) & 0x00FF00FFu) + ((b >> 8) & 0x00FF00FFu) + ((c >> 8) & 0x00FF00FFu);
+                    const uint32_t a = lds_ld(ctrl + F4_VOTE + 0), b = rot(lds_ld(ctrl + F4_VOTE + 1), wb1), c = rot(lds_ld(ctrl + F4_VOTE + 2), wb2),
+                                   d = rot(lds_ld(ctrl + F4_VOTE + 3), wb3);
+                    const uint32_t v02 = (a & 0x00FF00FFu) + (b & 0x00FF00FFu) + (c & 0x00FF00FFu) + (d & 0x00FF00FFu);
+                    const uint32_t v13 = ((a >> 8) & 0x00FF00FFu) + ((b >> 8) & 0x00FF00FFu) + ((c >> 8) & 0x00FF00FFu) + ((d >> 8) & 0x00FF00FFu);
                     const uint32_t votes[4] = {v02 & 0xFFFFu, v13 & 0xFFFFu, v02 >> 16, v13 >> 16};
                     uint32_t best = votes[0]; r0 = 0;
                     if (votes[1] > best) { best = votes[1]; r0 = 1; }
@@ -331,170 +352,221 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
                 } else {
                     r0 = (4u - (uint32_t)(first_line & 3)) & 3u;
                 }
-                const bool regular = t != 0 && flags == 0 && tbase + TILE + halo <= p.nbytes;
+                const bool regular = t != 0 && flags == 0 && tbase + TILE + halo <= p.nbytes && !(TD_DBG(p) & DBG_NO_PHASE2);
+                const uint32_t nwant = regular ? (total + 3u - r0) >> 2 : 0u;
+                const uint32_t ncum = k ? lds_ld(prev + F4_NCUM) + lds_ld(prev + F4_NWANT) : 0u;      // the wanted lines of the workgroup's tiles before this one
                 if (lane == 0) {
                     fp.tile_info[t] = total | (r0 << TI_R0_SHIFT) | ((flags & F4_FLAG_HI) ? TI_HI : 0u) | (regular ? 0u : TI_SKIP);
-                    lds_st(ctrl + F4_R0, r0); lds_st(ctrl + F4_WB1, wb1); lds_st(ctrl + F4_WB2, wb2); lds_st(ctrl + F4_TOTAL, total);
-                    lds_st(ctrl + F4_REGULAR, regular ? 1u : 0u);
+                    lds_st(ctrl + F4_R0, r0); lds_st(ctrl + F4_WB1, wb1); lds_st(ctrl + F4_WB2, wb2); lds_st(ctrl + F4_WB3, wb3);
+                    lds_st(ctrl + F4_TOTAL, total); lds_st(ctrl + F4_SEQ, k); lds_st(ctrl + F4_TIDX, t);
+                    lds_st(ctrl + F4_REMAIN, nwant);
                     lds_st(ctrl + F4_FLAGS, 0u);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) lds_st(ctrl + F4_READY, k + 1u);
+                // (one 8-byte store: a consumer never sees the new tile's line count beside the old tile's first line)
+                if (lane == 0)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(ctrl + F4_NCUM), (unsigned long long)ncum | ((unsigned long long)nwant << 32),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    lds_st(g_avail, ncum + nwant);
+                    if (nwant == 0u) lds_st(ctrl + F4_FREE, use + 1u);          // (nothing to match in it: the slot goes straight back)
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) lds_st(g_ready, k + 1u);
                 F4_STAMP(3);
             }
             return true;
         };
-        // (two tiles per turn of the loop: the registers a tile comes from are named at compile time)
-        for (;;) {
-            if (!(t < nwork)) break;
-            if (!produce(va, vha)) break;
-            { const uint32_t nit = t1; carry_ok = nit == t + 1u && t != 0u; t = t1; run_pos = rp1; t1 = t2; rp1 = rp2; t2 = next_tile(t1, rp2); k++; }
-            if (!(t < nwork)) break;
-            if (!produce(vb, vhb)) break;
-            { const uint32_t nit = t1; carry_ok = nit == t + 1u && t != 0u; t = t1; run_pos = rp1; t1 = t2; rp1 = rp2; t2 = next_tile(t1, rp2); k++; }
-        }
-        (void)run_pos;
-#ifdef TD_PHASE_PROF
-        if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(p.stats + 8 + i, f4acc[i]);
-#endif
-        return;
-    }
-
-    // ==================================================================== consumer
-    const int cons = wave - F4_PROD;
-    uint2 *hcS = reinterpret_cast<uint2 *>(L_hc + cons * HC_BYTES_PER_WAVE);
-    uint8_t *hcE = L_hc + cons * HC_BYTES_PER_WAVE + HC_SLOTS * 8;
-#pragma unroll
-    for (int q = 0; q < HC_SLOTS / 64; q++) hcS[q * 64 + lane] = make_uint2(HC_EMPTY, 0u);
-    wave_lds_fence();
-    bool hc_on = p.hot_cache != 0;
-    uint32_t hc_hits = 0, hc_rest = 0, aged = 0;
-    int st_reads = 0, st_bar = 0, st_tag = 0;
-    Pending<W> pd;
-    bool pd_valid = false;
-    auto finish_pending = [&](bool &hit, uint32_t &cell) {
-        vm_settled();
-        const uint64_t res = match_finish<W>(p, pd);
-        const uint32_t kind = (uint32_t)(res >> 62);
-        st_reads += 1;
-        if (kind >= 1) st_bar += 1;
-        if (kind == 2) st_tag += 1;
-        hit = kind == 2 && !(TD_DBG(p) & DBG_NO_ATOMIC);
-        cell = (uint32_t)res;
-    };
-    // (the consumers are the narrow place of the pipeline: their instructions go first)
-    __builtin_amdgcn_s_setprio(TD_F4_P_CONS);
-    Pending<W> nx;                                          // a line whose bucket has not been asked for yet (R, nr, boff only)
-    // the pending lines of the tile before: compares and count
-    auto settle = [&]() {
-        if (__any(pd_valid)) {
-            bool phit = false; uint32_t pcell = 0;
-            if (pd_valid) finish_pending(phit, pcell);
-            pd_valid = false;
-            if (hc_on) {
-                const uint32_t h = hc_hash(pcell);
-                hc_hits += (uint32_t)__builtin_popcountll(__ballot(phit && hcS[h].x == pcell));
+            // ------------------------------------------------------------ a producer: its jobs in turn
+            // (two jobs per turn of the loop: the registers a job's bytes come from are named at compile time)
+            for (;;) {
+                if (!(my_job < 4u * n_local)) break;
+                if (!produce(va, vha, my_job >> 2, tile_of(my_job >> 2))) break;
+                my_job += NPROD;
+                if (!(my_job < 4u * n_local)) break;
+                if (!produce(vb, vhb, my_job >> 2, tile_of(my_job >> 2))) break;
+                my_job += NPROD;
             }
-            hc_commit(p.counts, hcS, hcE, phit, pcell, (uint32_t)lane, hc_on);
-        }
-    };
-    uint32_t t = blockIdx.x * RUN, run_pos = 0;
-    for (uint32_t k = 0; t < nwork; k++) {
-        if ((k & 1u) == (uint32_t)cons) {
-            const uint32_t slot = k % (uint32_t)F4_SLOTS, use = k / (uint32_t)F4_SLOTS;
-            uint8_t *L_raw = L_raw0 + slot * slot_bytes;
-            const uint16_t *Ll = L_list0 + slot * F4_PROD * WCH;
-            uint32_t *ctrl = L_ctrl + slot * F4_CTRL_DW;
-            const uint64_t tbase = (uint64_t)t * TILE;
-            F4_STAMP(8);
-            F4_STAMP(5);
-            if (!f4_wait(ctrl + F4_READY, k + 1u, L_abort, p.stats)) break;
-            F4_STAMP(6);
-            const uint32_t r0 = lds_ld(ctrl + F4_R0), wb1 = lds_ld(ctrl + F4_WB1), wb2 = lds_ld(ctrl + F4_WB2), total = lds_ld(ctrl + F4_TOTAL);
-            const bool regular = lds_ld(ctrl + F4_REGULAR) != 0;
-            if (regular && !(TD_DBG(p) & DBG_NO_PHASE2)) {
-                const uint32_t nwant = (total + 3u - r0) >> 2;
-#pragma nounroll
-                for (uint32_t jb = 0; jb < nwant; jb += 64u) {
-                    const uint32_t j = jb + (uint32_t)lane;
-                    const bool keep = jb + 64u >= nwant;                             // the last pass: its lines are left pending
-                    uint32_t kres = 7u;                                              // (7: no line for this lane)
-                    uint32_t srel = 0;
-                    if (j < nwant) {
-                        // (the producer whose list holds ordinal o, and o's place in it: selects, no branches)
-                        const uint32_t o = r0 + 4u * j;
-                        uint32_t sel = 0u;
-                        sel = o >= wb1 ? 1u * WCH - wb1 : sel;
-                        sel = o >= wb2 ? 2u * WCH - wb2 : sel;
-                        srel = Ll[o + sel];
-                        // (a line that starts in the tile's last bytes is still whole in the staged window: the halo holds 16 NQ bytes and more)
-                        kres = line_prepare<W, NQ, false>(p, cx, L_raw, srel, nx);
-                    }
-                    // kres: 0 no barcode, 2 barcode only, 1 the tag is to be looked up, 6 leading blank (rare: raw bytes re-read)
-                    st_reads += kres == 0u || kres == 2u ? 1 : 0;
-                    st_bar += kres == 2u ? 1 : 0;
-                    if (keep) {
-                        // the tile's bytes have been read (line_prepare waits for its pieces before it packs them): the slot goes back
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (lane == 0) lds_st(ctrl + F4_FREE, use + 1u);
-                    }
-                    F4_STAMP(7);
-                    // the lines that have been pending since the tile (or pass) before: their buckets were asked for a whole
-                    // line_prepare ago -- then this pass's buckets, which stay in flight
-                    settle();
-                    F4_STAMP(5);
-                    if (kres == 1u) {
+        } else {
+        // ---- the state of the wave's matching (every wave matches whenever it cannot produce): the lines of its last pass,
+        // whose tag buckets are in flight
+        const int cons = wave < (int)NPROD ? 0 : wave - (int)NPROD;
+        uint2 *hcS = reinterpret_cast<uint2 *>(L_hc + cons * HC_BYTES_PER_WAVE);
+        uint8_t *hcE = L_hc + cons * HC_BYTES_PER_WAVE + HC_SLOTS * 8;
+        if (wave >= (int)NPROD) {
 #pragma unroll
-                        for (int w = 0; w < W; w++) pd.R[w] = nx.R[w];
-                        pd.nr = nx.nr; pd.boff = nx.boff;
-                        bucket_issue<W>(p, pd);
-                        pd_valid = true;
-                    }
-                    if (__builtin_expect(__any(kres == 6u), 0)) {
-                        if (kres == 6u) {
-                            const uint64_t res = match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true);
-                            const uint32_t kind = (uint32_t)(res >> 62);
-                            st_reads += 1;
-                            if (kind >= 1) st_bar += 1;
-                            if (kind == 2) {
-                                st_tag += 1;
-                                if (!(TD_DBG(p) & DBG_NO_ATOMIC))
-                                    __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                        }
-                        vm_settled();
-                    }
-                }
-                if (nwant == 0) { if (lane == 0) lds_st(ctrl + F4_FREE, use + 1u); }
-            } else {
-                if (lane == 0) lds_st(ctrl + F4_FREE, use + 1u);
-            }
-            F4_STAMP(7);
-            if (p.hot_cache && ++aged == HC_AGE_TILES) {
-                aged = 0;
+            for (int q = 0; q < HC_SLOTS / 64; q++) hcS[q * 64 + lane] = make_uint2(HC_EMPTY, 0u);
+            wave_lds_fence();
+        }
+        bool hc_on = p.hot_cache != 0;
+        uint32_t hc_hits = 0, hc_rest = 0, aged = 0;
+        int st_reads = 0, st_bar = 0, st_tag = 0;
+        Pending<W> pd;                                          // lines whose buckets are in flight
+        Pending<W> nx;                                          // a line whose bucket has not been asked for yet (R, nr, boff only)
+        bool pd_valid = false;
+        auto finish_pending = [&](bool &hit, uint32_t &cell) {
+            vm_settled();
+            const uint64_t res = match_finish<W>(p, pd);
+            const uint32_t kind = (uint32_t)(res >> 62);
+            st_reads += 1;
+            if (kind >= 1) st_bar += 1;
+            if (kind == 2) st_tag += 1;
+            hit = kind == 2 && !(TD_DBG(p) & DBG_NO_ATOMIC);
+            cell = (uint32_t)res;
+        };
+        // the pending lines of the pass before: compares and count
+        auto settle = [&]() {
+            if (__any(pd_valid)) {
+                bool phit = false; uint32_t pcell = 0;
+                if (pd_valid) finish_pending(phit, pcell);
+                pd_valid = false;
                 if (hc_on) {
-                    hc_flush(p.counts, hcS, (uint32_t)lane);
-                    // a consumer commits ~TILE / 300 hits a tile: below ~3 % of them cached, the cache is only overhead
-                    if (p.hot_cache != 2u && hc_hits * 32u < HC_AGE_TILES * (TILE / 300u)) { hc_on = false; hc_rest = HC_REST; }
-                    hc_hits = 0;
-                } else if (--hc_rest == 0) hc_on = true;
+                    const uint32_t h = hc_hash(pcell);
+                    hc_hits += (uint32_t)__builtin_popcountll(__ballot(phit && hcS[h].x == pcell));
+                }
+                hc_commit(p.counts, hcS, hcE, phit, pcell, (uint32_t)lane, hc_on);
+            }
+        };
+
+        // ---------------------------------------------------------------- matching
+        // 64 wanted lines of the workgroup's sequence from number cur on (n of them: the last lanes idle)
+        auto match = [&](const uint32_t cur, const uint32_t n) {
+        // ---------------- each lane's line: its tile is the slot whose lines [ncum, ncum + nwant) hold the line's number
+        const uint32_t g = cur + (uint32_t)lane;
+        const bool active = (uint32_t)lane < n;
+        uint32_t myslot = F4_SLOTS, jl = 0;
+        uint32_t seq_of[F4_SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < F4_SLOTS; sl++) {
+            const unsigned long long cw = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(L_ctrl + sl * F4_CTRL_DW + F4_NCUM),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            seq_of[sl] = lds_ld(L_ctrl + sl * F4_CTRL_DW + F4_SEQ);
+            const uint32_t nc = (uint32_t)cw, nw = (uint32_t)(cw >> 32);
+            if (active && g - nc < nw) { myslot = (uint32_t)sl; jl = g - nc; }
+        }
+        uint32_t kres = 7u, srel = 0;                        // (7: no line for this lane)
+        uint4 q[NQ];
+        const bool mine = active && myslot < (uint32_t)F4_SLOTS;
+        if (mine) {
+            const uint32_t *cs = L_ctrl + myslot * F4_CTRL_DW;
+            const uint4 ph = *reinterpret_cast<const uint4 *>(cs + F4_R0);        // r0, wb1, wb2, wb3
+            // (the producer whose list holds ordinal o, and o's place in it: selects, no branches)
+            const uint32_t o = ph.x + 4u * jl;
+            uint32_t sel = 0u;
+            sel = o >= ph.y ? 1u * WCH - ph.y : sel;
+            sel = o >= ph.z ? 2u * WCH - ph.z : sel;
+            sel = o >= ph.w ? 3u * WCH - ph.w : sel;
+            srel = (L_list0 + myslot * F4_PROD * WCH)[o + sel];
+            // (a line that starts in the tile's last bytes is still whole in the staged window: the halo holds 16 NQ bytes and more)
+            line_read<NQ>(L_raw0 + myslot * slot_bytes, srel, q);
+        }
+        // the lines' bytes are in registers: off their tiles' counts -- who takes a tile's last line gives its slot back, long
+        // before the pass is through (packing, the barcode walk and the pending lines take ten times as long as the reads)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int sl = 0; sl < F4_SLOTS; sl++) {
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(__ballot(myslot == (uint32_t)sl));
+            if (cnt && lane == 0) {
+                uint32_t *cs = L_ctrl + sl * F4_CTRL_DW;
+                const uint32_t before = __hip_atomic_fetch_sub(cs + F4_REMAIN, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (before == cnt) lds_st(cs + F4_FREE, seq_of[sl] / (uint32_t)F4_SLOTS + 1u);
             }
         }
-        const uint32_t n = run_pos + 1u < RUN ? t + 1u : t + 1u + jump;
-        run_pos = run_pos + 1u < RUN ? run_pos + 1u : 0u;
-        t = n;
-    }
-    settle();
-    if (p.hot_cache) hc_flush(p.counts, hcS, (uint32_t)lane);
+        if (mine) kres = line_prepare_q<W, NQ, false>(p, cx, q, nx);
+        // kres: 0 no barcode, 2 barcode only, 1 the tag is to be looked up, 6 leading blank (rare: raw bytes re-read)
+        st_reads += kres == 0u || kres == 2u ? 1 : 0;
+        st_bar += kres == 2u ? 1 : 0;
+        F4_STAMP(7);
+        // the lines that have been pending since the pass before: their buckets were asked for a whole line_prepare ago -- then
+        // this pass's buckets, which stay in flight
+        settle();
+        F4_STAMP(5);
+        // (rare: a line that opens with a blank -- str.strip, reference :256 -- is matched from its raw bytes in global memory;
+        // here, where no bucket is in flight and the pending registers are free)
+        if (__builtin_expect(__any(kres == 6u), 0)) {
+            if (kres == 6u) {
+                const uint64_t tb = (uint64_t)lds_ld(L_ctrl + myslot * F4_CTRL_DW + F4_TIDX) * TILE;
+                const uint64_t res = match_line<W, ML_SLOW>(p, cx, tb + srel, srel, true);
+                const uint32_t kind = (uint32_t)(res >> 62);
+                st_reads += 1;
+                if (kind >= 1) st_bar += 1;
+                if (kind == 2) {
+                    st_tag += 1;
+                    if (!(TD_DBG(p) & DBG_NO_ATOMIC))
+                        __hip_atomic_fetch_add(p.counts + (size_t)(res & R_CELL), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            vm_settled();
+        }
+        if (kres == 1u) {
+#pragma unroll
+            for (int w = 0; w < W; w++) pd.R[w] = nx.R[w];
+            pd.nr = nx.nr; pd.boff = nx.boff;
+            bucket_issue<W>(p, pd);
+            pd_valid = true;
+        }
+        if (p.hot_cache && ++aged == HC_AGE_TILES) {
+            aged = 0;
+            if (hc_on) {
+                hc_flush(p.counts, hcS, (uint32_t)lane);
+                // a consumer commits ~45 hits a pass: below ~3 % of them cached, the cache is only overhead
+                if (p.hot_cache != 2u && hc_hits * 32u < HC_AGE_TILES * 45u) { hc_on = false; hc_rest = HC_REST; }
+                hc_hits = 0;
+            } else if (--hc_rest == 0) hc_on = true;
+        }
+        };
+
+            // ------------------------------------------------------------ a consumer: 64 lines at a time
+            __builtin_amdgcn_s_setprio(TD_F4_P_CONS);
+            for (uint32_t idle = 0;;) {
+                F4_STAMP(8);
+                // claim the next wanted lines of the workgroup's sequence: 64, or what there is when no more can come
+                const uint32_t cur = lds_ld(g_claimed);
+                const uint32_t R = lds_ld(g_ready);
+                const uint32_t A = lds_ld(g_avail);              // (read last: it counts every line claimed before `cur` was read)
+                const uint32_t have = A - cur;
+                uint32_t n = 0;
+                if (have >= 64u) n = 64u;
+                else if (R == n_local) {
+                    if (have == 0u) break;                          // the workgroup's tiles are through and matched
+                    n = have;
+                } else if (have != 0u && lds_ld(L_ctrl + (R % (uint32_t)F4_SLOTS) * F4_CTRL_DW + F4_FREE) < R / (uint32_t)F4_SLOTS) {
+                    n = have;                                    // (the next tile's slot has not been given back: these lines first)
+                }
+                if (n) {
+                    uint32_t won = 0;
+                    if (lane == 0) {
+                        uint32_t expected = cur;
+                        won = __hip_atomic_compare_exchange_strong(g_claimed, &expected, cur + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+                    }
+                    if (__builtin_amdgcn_readfirstlane((int)won)) {
+                        F4_STAMP(6);
+                        match(cur, n);
+                        idle = 0;
+                    }
+                    continue;                                    // (or another consumer took them: look again)
+                }
+                if (++idle > F4_SPIN_LIMIT || lds_ld(L_abort)) {
+                    lds_st(L_abort, 1u);
+                    if (lane == 0) atomicOr(p.stats + ST_ERR, ERR_SPIN);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            settle();
+            if (p.hot_cache) hc_flush(p.counts, hcS, (uint32_t)lane);
+            unsigned long long r = wave_sum64((unsigned long long)(long long)st_reads), b = wave_sum64((unsigned long long)(long long)st_bar),
+                               g = wave_sum64((unsigned long long)(long long)st_tag);
+            if (lane == 0) {
+                if (r) atomicAdd(p.stats + ST_READS, r);
+                if (b) atomicAdd(p.stats + ST_BARCUT, b);
+                if (g) atomicAdd(p.stats + ST_TAG, g);
+            }
+        }
 #ifdef TD_PHASE_PROF
-    if (lane == 0) for (int i = 5; i < 9; i++) atomicAdd(p.stats + 8 + i, f4acc[i]);
+        if (lane == 0) for (int i = 0; i < 9; i++) atomicAdd(p.stats + 8 + i, f4acc[i]);
 #endif
-    unsigned long long r = wave_sum64((unsigned long long)(long long)st_reads), b = wave_sum64((unsigned long long)(long long)st_bar),
-                       g = wave_sum64((unsigned long long)(long long)st_tag);
-    if (lane == 0) {
-        if (r) atomicAdd(p.stats + ST_READS, r);
-        if (b) atomicAdd(p.stats + ST_BARCUT, b);
-        if (g) atomicAdd(p.stats + ST_TAG, g);
     }
 }
 

@@ -322,7 +322,7 @@ FFn pick_fix(int tile_kb, int W) {          // the fix-up pass shares the main p
     if (tile_kb == 12) return W == 1 ? tdk::k_fast<6, 1, true, 128> : W == 2 ? tdk::k_fast<6, 2, true, 128> : tdk::k_fast<6, 3, true, 128>;   // (k_fast4's tile: 128 threads)
     return pick_fast(tile_kb, W, true);
 }
-// k_fast4: producer and consumer waves, 12 KiB tiles (kernel_fast4.hpp)
+// k_fast4: producer and consumer waves, 16 KiB tiles (kernel_fast4.hpp)
 FFn pick_fast4(int W, uint32_t nq) {
     switch (W) {
     case 1: return nq == 3 ? tdk::k_fast4<1, 3> : nq == 4 ? tdk::k_fast4<1, 4> : tdk::k_fast4<1, 6>;
@@ -332,7 +332,7 @@ FFn pick_fast4(int W, uint32_t nq) {
 }
 size_t lds_bytes_fast4(const td_handle *h) {
     // three slots of raw tile + halo | per slot and producer the masks / line starts | hand-off words | the consumers' hot-cell caches | barcode index
-    return (size_t)tdk::F4_SLOTS * (tdk::F4_TILE + h->halo) + (size_t)tdk::F4_SLOTS * tdk::F4_PROD * tdk::F4_WCH * 2 + 256 +
+    return (size_t)tdk::F4_SLOTS * (tdk::F4_TILE + h->halo) + (size_t)tdk::F4_SLOTS * tdk::F4_PROD * tdk::F4_WCH * 2 + tdk::F4_CTRL_BYTES +
            (size_t)tdk::F4_CONS * tdk::HC_BYTES_PER_WAVE + h->bblob_bytes;
 }
 // k_fast2's tile: four workgroups must share a CU's 160 KiB of LDS (measured: three cost a fifth of the throughput),
@@ -420,12 +420,12 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     const int tkb2 = h->tile_kb2 ? h->tile_kb2 : fast2_auto_tile(h);
     // k_fast4 (producer and consumer waves) where three of its workgroups share a CU's LDS and no progress windows are wanted
     // (it keeps no per-tile sums); else k_fast2
-    const bool gen4_fits = h->kernel_gen == 4 && h->W <= 3 && !h->progress && lds_bytes_fast4(h) <= LDS_BUDGET;
+    const bool gen4_fits = h->kernel_gen == 4 && h->W <= 3 && !h->progress && lds_bytes_fast4(h) <= 80 * 1024;      // (two workgroups of eight waves a CU)
     const bool gen2_fits = (h->kernel_gen == 2 || (h->kernel_gen == 4 && !gen4_fits)) && h->W <= 3 && lds_bytes_fast2(h, tkb2) <= LDS_BUDGET;
     const bool use_fast = h->fastpath && !tassel && !h->prescan && limit_far && counts32 && !(h->progress && !gen2_fits);
     const bool gen4 = use_fast && gen4_fits;
     const bool gen2 = use_fast && gen2_fits && !gen4;
-    const int tile_kb = tassel ? 16 : gen4 ? 12 : gen2 ? tkb2 : h->tile_kb;
+    const int tile_kb = tassel ? 16 : gen4 ? (int)(tdk::F4_TILE / 1024) : gen2 ? tkb2 : h->tile_kb;
     const uint64_t tile = (uint64_t)tile_kb * 1024;
     const uint64_t ntiles64 = (nbytes + tile - 1) / tile;
     if (ntiles64 > 0x7FFFFFFFull) return fail(TD_E_LIMIT, "buffer too large for one launch; split it");
@@ -507,7 +507,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
         HIPCHK(hipMemsetAsync(h->d_nfix.p, 0, 4, stream));
         FFn ffn = gen4 ? pick_fast4(h->W, h->nch2) : gen2 ? pick_fast2(tile_kb, h->W, h->nch2, h->progress != 0) : pick_fast(tile_kb, h->W, false), fixfn = pick_fix(tile_kb, h->W);
         const size_t flds = gen4 ? lds_bytes_fast4(h) : gen2 ? lds_bytes_fast2(h, tile_kb) : lds_bytes_fast(h, tile_kb), fixlds = lds_bytes_fast(h, tile_kb);
-        const unsigned main_threads = gen4 ? (unsigned)tdk::F4_BLOCK : (unsigned)tdk::FBLOCK, fix_threads = gen4 ? 128u : (unsigned)tdk::FBLOCK;
+        const unsigned main_threads = gen4 ? (unsigned)tdk::F4_BLOCK : (unsigned)tdk::FBLOCK, fix_threads = tile_kb == 12 ? 128u : (unsigned)tdk::FBLOCK;
         if (flds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
         if (fixlds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)fixfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fixlds));
         int bpc = h->blocks_per_cu;

@@ -29,7 +29,7 @@ NAMES2 = ["loop head", "A: wait bytes, raw + masks -> LDS (own quarter)", "B: ma
 
 
 NAMES4 = ["producer: waiting for the slot", "producer: A (wait bytes, raw + masks -> LDS, next loads)", "producer: B (scan, vote, lists)",
-          "producer: closing a tile", "producer: loop", "consumer: pending lines", "consumer: waiting for a tile", "consumer: matching",
+          "producer: closing a tile", "producer: loop", "consumer: pending lines", "consumer: waiting for lines", "consumer: matching",
           "consumer: loop", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-"]
 
 
@@ -69,7 +69,7 @@ def main():
     ms, _ = eng.kernel_time_ms()
     c = list(eng.debug_counters()[:20]); c[11] = 0
     tot = float(sum(c[:20])) or 1.0
-    tkb = 12 if a.kernel == 4 else a.tile_kb2 if a.kernel == 2 else a.tile_kb
+    tkb = 16 if a.kernel == 4 else a.tile_kb2 if a.kernel == 2 else a.tile_kb
     ntiles = (cfg.nbytes() + tkb * 1024 - 1) // (tkb * 1024)
     print("kernel=%d tile_kb=%d blocks_per_cu=%s prescan=%d  kernel %.2f ms (stamped build)  tiles=%d" % (
         a.kernel, tkb, a.blocks_per_cu or "auto", a.prescan, ms, ntiles))
