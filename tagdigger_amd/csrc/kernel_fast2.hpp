@@ -627,23 +627,14 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                 const uint32_t srel = L_mask[o + sel];
                 // (a line that starts in the tile's last bytes is still whole in the staged window: the halo
                 // holds 16 NQ bytes and more)
-                const uint32_t k = line_prepare<W, NQ>(p, cx, L_raw, srel, pd);
-                // k: 0 no barcode, 2 barcode only, 1 pending (bucket in flight), 6 leading blank (rare: raw bytes re-read)
+                const uint32_t k = line_prepare<W, NQ, false>(p, cx, L_raw, srel, pd);
+                // k: 0 no barcode, 2 barcode only, 1 the tag is to be looked up, 6 leading blank (rare: raw bytes re-read)
                 st_reads += k != 6u ? 1 : 0;
                 st_bar += k == 2u ? 1 : 0;
                 bool barred = k == 1u || k == 2u, tagged = false;
                 const bool keep = PIPE && j + FBLOCK >= nwant;                   // (the same for every lane of the wave)
-                if (k == 1u) {
-                    if (keep) { pd_valid = true; st_reads -= 1; }               // (counted when it is finished)
-                    else {
-                        bool h; uint32_t c;
-                        st_reads -= 1;
-                        finish_pending(h, c);
-                        tagged = phit_tag;
-                        hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
-                        vm_settled();
-                    }
-                }
+                // (the rare line that opens with a blank, here -- before this pass's buckets are asked for: their sixteen
+                // registers are free for the slow matcher, and nothing it waits for is in flight)
                 if (__builtin_expect(__any(k == 6u), 0)) {
                     if (k == 6u) {
                         const uint64_t res = match_line<W, ML_SLOW>(p, cx, tbase + srel, srel, true);
@@ -658,6 +649,18 @@ __global__ __launch_bounds__(FBLOCK, Fast2Waves<CPT>::value) void k_fast2(const 
                         }
                     }
                     vm_settled();
+                }
+                if (k == 1u) {
+                    bucket_issue<W>(p, pd);
+                    if (keep) { pd_valid = true; st_reads -= 1; }               // (counted when it is finished)
+                    else {
+                        bool h; uint32_t c;
+                        st_reads -= 1;
+                        finish_pending(h, c);
+                        tagged = phit_tag;
+                        hc_commit(p.counts, hcS, hcE, h, c, (uint32_t)lane, false);
+                        vm_settled();
+                    }
                 }
                 if (prog) {
                     // (the wave's first lane holds its smallest j, so it is here whenever any lane is; a pending line's

@@ -1,25 +1,29 @@
 // k_fast4: the main pass of the free-running path with the workgroup's waves in TWO ROLES and no workgroup barrier
-// in the tile loop.
+// in the tile loop.  An experiment that is kept -- parity-green in every kernel-mode test, td_set_option("kernel", 4) --
+// and that LOSES to k_fast2 by 9 % at the bench shape (profiles/r04/k_fast4_*.txt); the default stays
+// k_fast2.
 //
 // k_fast2 (kernel_fast2.hpp) takes every tile through phases A-B (all four waves: terminators, lists of line starts),
 // a barrier, phases C-D (the wanted lines matched by the two waves whose lanes they fill) and a second barrier: per
 // tile the four waves can issue 4 x (A-B + D) instructions' worth of time but only have 4 x A-B + 2 x D to issue --
-// 72 % at best -- and every wave stands at two barriers behind the slowest.  Here a workgroup is eight waves:
+// 72 % at best -- and every wave stands at two barriers behind the slowest.  Here a workgroup is sixteen waves, one
+// workgroup per CU, all of the CU's LDS one ring of seven 16 KiB tiles:
 //
-//   producers (waves 0-3)  stream the FASTQ.  A tile is 16 KiB, a quarter per producer; the next TWO tiles' bytes are in
-//                          flight in registers.  Per tile: raw bytes -> the tile's slot in LDS (a ring of three slots),
-//                          terminator masks, the list of the wave's line starts (k_fast2's phases A and B, nothing
-//                          shared between the producers).  The last of them to finish a tile ("closer": the wave whose
-//                          arrival makes four) adds up the terminator counts, carries the line phase inside a run or
-//                          takes the vote at its start, writes the tile's word for k_resolve, and publishes how many wanted
-//                          lines (every fourth line start) the tile holds and how many the workgroup's tiles held before it.
-//   consumers (waves 4-7)  match.  The wanted lines of the workgroup's tiles form ONE sequence; a consumer claims the next 64
+//   producers (11 waves)   stream the FASTQ.  A job is a quarter of a tile; job 4 k + q goes to producer (4 k + q) mod 11;
+//                          a producer's next TWO jobs' bytes are in flight in registers.  Per job: raw bytes -> the tile's
+//                          slot in LDS, terminator masks, the list of the quarter's line starts (k_fast2's phases A and B,
+//                          nothing shared between the producers).  The producer whose arrival makes four ("closer") waits
+//                          for the tile before to be closed, adds up the terminator counts, carries the line phase inside a
+//                          run or takes the vote at its start, writes the tile's word for k_resolve, and publishes how many
+//                          wanted lines (every fourth line start) the tile holds and how many the workgroup's tiles held
+//                          before it.
+//   consumers (5 waves)    match.  The wanted lines of the workgroup's tiles form ONE sequence; a consumer claims the next 64
 //                          of it (a compare-and-swap on a cursor in LDS) whatever tiles they lie in -- always full lanes,
-//                          whatever the read length -- finds each lane's tile among the ring's slots, runs line_prepare
-//                          (kernel_fast2.hpp: pack from the line's first byte, barcode directory, tag hash), takes the
-//                          lines off their tiles' counts (the consumer that takes a tile's last line gives the slot back),
-//                          finishes the lines it left pending a pass ago (compares, count) and only then asks for this
-//                          pass's tag buckets, which stay in flight until the next pass.
+//                          whatever the read length -- finds each lane's tile among the ring's slots, reads the lines'
+//                          pieces into registers, takes the lines off their tiles' counts (the consumer that takes a tile's
+//                          last line gives the slot back: long before its pass is through), packs and looks up (line_prepare_q,
+//                          kernel_fast2.hpp), finishes the lines it left pending a pass ago (compares, count) and only then
+//                          asks for this pass's tag buckets, which stay in flight until the next pass.
 //
 // Hand-offs are words in LDS.  A wave's LDS operations execute in order, so a wave that drains its stores (s_waitcnt
 // lgkmcnt(0)) before it touches a hand-off word has published them.  Every wait is bounded: a wave that waits too long
@@ -27,8 +31,12 @@
 // No wait can last: a tile's production needs its slot's previous tile matched, which needs that tile produced -- an
 // earlier one; and a consumer that finds fewer than 64 lines takes what there is as soon as the next tile cannot be
 // produced before lines are matched (its slot has not been given back), or the workgroup's tiles are through.
-// Eight waves: two per SIMD and workgroup, two workgroups per CU (a five-wave workgroup -- three producers, two
-// consumers, the first form of this kernel -- is admitted only two to a CU: ten waves).
+// What was measured on the way (200 M reads x 384 x 100 k, k_fast2 11.1-11.5 ms in the same process): five waves (3 + 2,
+// 12 KiB tiles, three workgroups a CU asked for) 16.7 ms -- a five-wave workgroup is admitted only TWO to a CU, ten
+// waves; eight waves (4 + 4, then 5 + 3 with the quarter-tile jobs) 13.0-13.9 ms -- both roles wait for each other half
+// of their time, a ring of three tiles is too short for a matching pass that lasts two tiles' production; sixteen waves
+// with seven slots 12.5 ms at 11 + 5 (10 + 6: 12.7, 12 + 4: 13.5, 13 + 3: 16.1).  The instruction count per byte equals
+// k_fast2's; what the roles buy in balance they lose again in waiting at the hand-offs.
 // Tiles that are not "regular" (the buffer's first and last, bytes >= 0x80, '\r' at the end of a chunk next to another
 // wave's bytes, more line starts than a list holds) are only counted here (terminators) and flagged TI_SKIP for the
 // fix-up pass (k_fast<4, W, true>: the same 16 KiB tile), as in k_fast2.
@@ -37,26 +45,34 @@
 
 namespace tdk {
 
-constexpr int F4_PROD = 4, F4_CONS = 4, F4_WAVES = F4_PROD + F4_CONS, F4_BLOCK = 64 * F4_WAVES;
+#ifndef TD_F4_WAVES
+#define TD_F4_WAVES 16              // waves of a workgroup (a multiple of four: the waves go to the four SIMDs in turn)
+#endif
+#ifndef TD_F4_NPROD
+#define TD_F4_NPROD 11              // producer waves among them (they take the quarter-tile jobs in turn); the others match
+#endif
+#ifndef TD_F4_SLOTS
+#define TD_F4_SLOTS 7               // tiles the ring in LDS holds
+#endif
+constexpr int F4_PROD = 4 /* quarters of a tile */, F4_WAVES = TD_F4_WAVES, F4_CONS = F4_WAVES - TD_F4_NPROD, F4_BLOCK = 64 * F4_WAVES;
 constexpr int F4_CPT = 4;                                   // 16-byte chunks per producer lane and tile
 constexpr uint32_t F4_WCH = F4_CPT * 64;                    // chunks per producer and tile
 constexpr uint32_t F4_WBYTES = F4_WCH * 16;
 constexpr uint32_t F4_TILE = F4_PROD * F4_WBYTES;           // 16 KiB
-constexpr int F4_SLOTS = 3;
+constexpr int F4_SLOTS = TD_F4_SLOTS;
 constexpr uint32_t F4_SPIN_LIMIT = 1u << 18;
 #ifndef TD_F4_P_CONS
 #define TD_F4_P_CONS 1              // wave priority of the consumers (the producers run at 0)
 #endif
-#ifndef TD_F4_NPROD
-#define TD_F4_NPROD 5               // producer waves of the eight (they take the quarter-tile jobs in turn); the others match
-#endif
+
 // hand-off words of a slot (dwords in LDS; F4_R0..F4_WB3 are read as one 16-byte word, F4_NCUM + F4_NWANT as one 8-byte word)
 enum { F4_DONE = 0, F4_FREE = 1, F4_REMAIN = 2, F4_FLAGS = 3, F4_TOT = 4 /* 4 */, F4_VOTE = 8 /* 4 */, F4_R0 = 12, F4_WB1 = 13, F4_WB2 = 14,
        F4_WB3 = 15, F4_TOTAL = 16, F4_SEQ = 17, F4_NCUM = 18, F4_NWANT = 19, F4_TIDX = 20, F4_CTRL_DW = 24 };
 constexpr uint32_t F4_FLAG_HI = 1, F4_FLAG_OVER = 2, F4_FLAG_HALO_HI = 4;
 // the workgroup's words behind the slots': abort, tiles closed, wanted lines in them, wanted lines claimed
 constexpr uint32_t F4_ABORT_DW = F4_SLOTS * F4_CTRL_DW, F4_READY_DW = F4_ABORT_DW + 1, F4_AVAIL_DW = F4_ABORT_DW + 2, F4_CLAIMED_DW = F4_ABORT_DW + 3;
-constexpr uint32_t F4_CTRL_BYTES = 512;
+constexpr uint32_t F4_CTRL_BYTES = 1024;                     // (256 dwords: the slots' words, the workgroup's, a spare word per wave at 240)
+static_assert(F4_CLAIMED_DW < 240 && F4_WAVES <= 16, "hand-off words");
 
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -85,7 +101,7 @@ __device__ __forceinline__ bool f4_wait(uint32_t *p, uint32_t need, uint32_t *ab
 #endif
 
 template <int W, int NQ>
-__global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
+__global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams fp) {
     const KParams &p = fp.k;
 #ifdef TD_PHASE_PROF
     unsigned long long f4acc[12] = {};
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(F4_BLOCK, 4) void k_fast4(const FParams fp) {
             // the lines behind this wave's terminators, by wave-local ordinal, into the space of its masks (every lane holds its
             // masks in registers by now: the fence below the read-back is the wave's own order of LDS operations)
             if (__builtin_expect(wtot <= WCH, 1)) {
-                uint16_t *spare = reinterpret_cast<uint16_t *>(L_ctrl + 120 + (uint32_t)wave);     // (a word nobody reads)
+                uint16_t *spare = reinterpret_cast<uint16_t *>(L_ctrl + 240 + (uint32_t)wave);     // (a word nobody reads)
                 uint32_t kk = incl - cnt, rest = 0;
 #pragma unroll
                 for (int i = 0; i < CPT / 2; i++) {

@@ -420,7 +420,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     const int tkb2 = h->tile_kb2 ? h->tile_kb2 : fast2_auto_tile(h);
     // k_fast4 (producer and consumer waves) where three of its workgroups share a CU's LDS and no progress windows are wanted
     // (it keeps no per-tile sums); else k_fast2
-    const bool gen4_fits = h->kernel_gen == 4 && h->W <= 3 && !h->progress && lds_bytes_fast4(h) <= 80 * 1024;      // (two workgroups of eight waves a CU)
+    const bool gen4_fits = h->kernel_gen == 4 && h->W <= 3 && !h->progress && lds_bytes_fast4(h) <= 160 * 1024;     // (one workgroup of sixteen waves a CU)
     const bool gen2_fits = (h->kernel_gen == 2 || (h->kernel_gen == 4 && !gen4_fits)) && h->W <= 3 && lds_bytes_fast2(h, tkb2) <= LDS_BUDGET;
     const bool use_fast = h->fastpath && !tassel && !h->prescan && limit_far && counts32 && !(h->progress && !gen2_fits);
     const bool gen4 = use_fast && gen4_fits;
