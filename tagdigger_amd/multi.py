@@ -188,6 +188,21 @@ def _bgzf_member_bytes(path, off, end):
     return b"".join(out)
 
 
+def _agree(exc, where):
+    """Called by every rank where a rank-local phase ends and a collective follows: a rank that failed raises its own
+    exception, every other rank raises too -- nobody is left waiting in the collective for a rank that is gone."""
+    rank, world = _rank_world()
+    failed = exc is not None
+    if world > 1:
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=where)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed = int(flag[0]) != 0
+    if exc is not None:
+        raise exc
+    if failed:
+        raise RuntimeError("tagdigger_amd: another rank failed on its share of the file; see its message")
+
+
 def _count_one_stream(path, barcodes, tags, cutsite, bound, counter, dev, as_array, progress):
     """An ordinary gzip file (one DEFLATE stream: no place to cut it without decoding everything before) under
     count_file_sharded: the reference reads any .gz by name (:240-241), so it is counted -- by rank 0 alone, through
@@ -201,10 +216,15 @@ def _count_one_stream(path, barcodes, tags, cutsite, bound, counter, dev, as_arr
               "(bgzip-compressed files are sharded by members)" % path, file=sys.stderr)
     if counter is not None:
         out = np.zeros((len(barcodes), len(tags)), dtype=np.int64)
-        if rank == 0:
-            with gzip.open(path, "rb") as fh:
-                data = fh.read()
-            out += np.asarray(counter(data, barcodes, tags, cutsite, 0, bound), dtype=np.int64).reshape(out.shape)
+        err = None
+        try:
+            if rank == 0:
+                with gzip.open(path, "rb") as fh:
+                    data = fh.read()
+                out += np.asarray(counter(data, barcodes, tags, cutsite, 0, bound), dtype=np.int64).reshape(out.shape)
+        except Exception as e:                 # noqa: BLE001 -- raised on every rank by _agree
+            err = e
+        _agree(err, "cpu")
         if world > 1:
             dist.all_reduce(torch.from_numpy(out), op=dist.ReduceOp.SUM)
         return out if as_array else out.tolist()
@@ -215,16 +235,20 @@ def _count_one_stream(path, barcodes, tags, cutsite, bound, counter, dev, as_arr
     total = torch.zeros(len(barcodes) * len(tags), dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)
     eng.bind_counts(total.data_ptr())
+    err = None
     try:
         if rank == 0:
-            eng.count_file(path, maxreads=bound)
+            eng.count_file(path, maxreads=bound)               # (a damaged .gz raises what gzip.open raises: EOFError, gzip.BadGzipFile, zlib.error)
         eng.stats()                                            # (synchronises; raises what a kernel flagged)
         if progress and rank == 0:
             for line in eng.progress_lines(path):
                 print(line)
+    except Exception as e:                     # noqa: BLE001 -- raised on every rank by _agree
+        err = e
     finally:
         eng.bind_counts(0)
         eng.set_option("progress", 0)
+    _agree(err, dev)
     if world > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
     out = total.cpu().numpy().view(np.uint32).astype(np.int64).reshape(len(barcodes), len(tags))
@@ -279,18 +303,30 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
     # ---- this rank's bytes: `shard` (device tensor, 16-byte aligned) or `data` (host bytes, the stand-in), n bytes
     data, shard = None, None
     if not is_gz:
-        start, end = shard_bounds(path, world)[rank]
-        n = end - start
-        if use_gpu:
-            shard = torch.empty(max(16, n), dtype=torch.uint8, device=dev)         # (torch allocations are 256-byte aligned)
-            if n:
-                eng.load_file_range(path, start, n, shard.data_ptr())
-        else:
-            data = np.fromfile(path, dtype=np.uint8, count=n, offset=start).tobytes()
+        err = None
+        try:
+            start, end = shard_bounds(path, world)[rank]
+            n = end - start
+            if use_gpu:
+                shard = torch.empty(max(16, n), dtype=torch.uint8, device=dev)     # (torch allocations are 256-byte aligned)
+                # (the library fills it on its own streams: nothing of torch's may still be pending on a block the
+                # caching allocator hands out again)
+                torch.cuda.current_stream(dev).synchronize()
+                if n:
+                    eng.load_file_range(path, start, n, shard.data_ptr())
+            else:
+                data = np.fromfile(path, dtype=np.uint8, count=n, offset=start).tobytes()
+        except Exception as e:                 # noqa: BLE001 -- raised on every rank by _agree
+            err = e
+        _agree(err, where)
     else:
+        from ._binding import TagdigError
         try:
             moff, misz = bgzf_index(path)
-        except Exception:
+        except TagdigError as e:
+            # only "this is gzip, but not BGZF" sends the file to the one-stream path; an unreadable file is an error
+            if "BGZF" not in e.detail:
+                raise
             moff = None
         if moff is None:
             return _count_one_stream(path, barcodes, tags, cutsite, bound, counter, dev if use_gpu else None, as_array, progress)
@@ -306,24 +342,31 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
             k -= 1
         if k >= 0:
             prev_byte = _bgzf_member_bytes(path, moff[k], ends[k])[-1]
-        if use_gpu:
-            buf = torch.empty(max(16, own_len + (1 << 20)), dtype=torch.uint8, device=dev)
-            got = eng.bgzf_inflate_range(path, int(moff[m0]) if m0 < len(moff) else fsize, int(moff[m1]) if m1 < len(moff) else fsize,
-                                         buf.data_ptr(), own_len) if own_len else 0
-            assert got == own_len
-            # my first line start: the first terminator is looked for in pieces copied back (the first one holds it)
-            a, seen, pb = own_len, 0, prev_byte
-            while seen < own_len:
-                piece = buf[seen:min(own_len, seen + (1 << 20))].cpu().numpy().tobytes()
-                f = first_line_start(piece, pb)
-                if f < len(piece):
-                    a = seen + f
-                    break
-                seen += len(piece)
-                pb = piece[-1]               # (a terminator in the piece's last byte: the next piece's first byte decides)
-        else:
-            own = _bgzf_member_bytes(path, moff[m0], ends[m1 - 1]) if m1 > m0 else b""
-            a = first_line_start(own, prev_byte)
+        err, a = None, 0
+        try:
+            if use_gpu:
+                buf = torch.empty(max(16, own_len + (1 << 20)), dtype=torch.uint8, device=dev)
+                torch.cuda.current_stream(dev).synchronize()      # (the library inflates into it on its own streams)
+                got = eng.bgzf_inflate_range(path, int(moff[m0]) if m0 < len(moff) else fsize, int(moff[m1]) if m1 < len(moff) else fsize,
+                                             buf.data_ptr(), own_len) if own_len else 0
+                if got != own_len:
+                    raise RuntimeError("tagdigger_amd: members %d..%d of %s inflate to %d bytes, their headers say %d" % (m0, m1, path, got, own_len))
+                # my first line start: the first terminator is looked for in pieces copied back (the first one holds it)
+                a, seen, pb = own_len, 0, prev_byte
+                while seen < own_len:
+                    piece = buf[seen:min(own_len, seen + (1 << 20))].cpu().numpy().tobytes()
+                    f = first_line_start(piece, pb)
+                    if f < len(piece):
+                        a = seen + f
+                        break
+                    seen += len(piece)
+                    pb = piece[-1]           # (a terminator in the piece's last byte: the next piece's first byte decides)
+            else:
+                own = _bgzf_member_bytes(path, moff[m0], ends[m1 - 1]) if m1 > m0 else b""
+                a = first_line_start(own, prev_byte)
+        except Exception as e:                 # noqa: BLE001 -- raised on every rank by _agree
+            err = e
+        _agree(err, where)
         # every rank's first line start as an offset into the inflated file; mine end where the next one's begin
         starts = gather_ints(int(gpos[m0]) + a if a < own_len else -1, where) + [int(gpos[-1])]
         for r in range(world - 1, -1, -1):                                         # (a shard without a line start owns nothing)
@@ -331,26 +374,43 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
                 starts[r] = starts[r + 1]
         g0, g1 = starts[rank], starts[rank + 1]
         n = g1 - g0
-        # the part of my lines that lies in the members behind mine
-        tail_len = max(0, g1 - int(gpos[m1]))
-        if use_gpu:
-            if tail_len:
-                mt = int(np.searchsorted(gpos, g1, side="left"))                   # members m1 .. mt - 1 hold it
-                cap = int(gpos[mt] - gpos[m1])
-                if own_len + cap > buf.numel():
-                    bigger = torch.empty(own_len + cap, dtype=torch.uint8, device=dev)
-                    bigger[:own_len].copy_(buf[:own_len])
-                    buf = bigger
-                eng.bgzf_inflate_range(path, int(moff[m1]), int(moff[mt]) if mt < len(moff) else fsize, buf.data_ptr() + own_len, cap)
-            lo = g0 - int(gpos[m0])
-            shard = buf[lo:lo + n].clone() if n else torch.empty(16, dtype=torch.uint8, device=dev)   # (a 256-byte aligned copy)
-            del buf
-        else:
-            if tail_len:
-                mt = int(np.searchsorted(gpos, g1, side="left"))
-                own = own + _bgzf_member_bytes(path, moff[m1], ends[mt - 1])
-            lo = g0 - int(gpos[m0])
-            data = own[lo:lo + n]
+        # the part of my lines that lies in the members behind mine (a rank that owns no line has no such part)
+        tail_len = max(0, g1 - int(gpos[m1])) if n else 0
+        err = None
+        try:
+            if use_gpu:
+                if tail_len:
+                    mt = int(np.searchsorted(gpos, g1, side="left"))               # members m1 .. mt - 1 hold it
+                    cap = int(gpos[mt] - gpos[m1])
+                    if own_len + cap > buf.numel():
+                        bigger = torch.empty(own_len + cap, dtype=torch.uint8, device=dev)
+                        bigger[:own_len].copy_(buf[:own_len])
+                        buf = bigger
+                    torch.cuda.current_stream(dev).synchronize()  # (the copy above, before the library writes behind it)
+                    eng.bgzf_inflate_range(path, int(moff[m1]), int(moff[mt]) if mt < len(moff) else fsize, buf.data_ptr() + own_len, cap)
+                lo = g0 - int(gpos[m0])
+                if n == 0:
+                    shard = torch.empty(16, dtype=torch.uint8, device=dev)
+                elif lo % 16 == 0:
+                    shard = buf[lo:lo + n]                        # (where it lies: the kernels want 16-byte alignment, no more)
+                else:
+                    # moved down inside the buffer to the next lower multiple of 16, front to back through a 64 MiB piece
+                    # (a copy of the whole shard would hold it twice; a piece's destination ends before the next piece's source)
+                    al = lo - lo % 16
+                    step = 64 << 20
+                    for o in range(0, n, step):
+                        m = min(step, n - o)
+                        buf[al + o:al + o + m].copy_(buf[lo + o:lo + o + m].clone())
+                    shard = buf[al:al + n]
+            else:
+                if tail_len:
+                    mt = int(np.searchsorted(gpos, g1, side="left"))
+                    own = own + _bgzf_member_bytes(path, moff[m1], ends[mt - 1])
+                lo = g0 - int(gpos[m0])
+                data = own[lo:lo + n]
+        except Exception as e:                 # noqa: BLE001 -- raised on every rank by _agree
+            err = e
+        _agree(err, where)
 
     if use_gpu:
         eng.set_index(barcodes, tags, cutsite)
@@ -360,10 +420,15 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
         terms = eng.count_lines_device(shard.data_ptr(), int(n)) if n else 0
         first_line = first_line_of(terms, dev)
         eng.bind_counts(total.data_ptr())
+        err, st = None, None
         try:
-            if n and (first_line + 2) // 4 < bound:
-                eng.count_device(shard.data_ptr(), int(n), first_line=first_line, maxreads=bound)
-            st = eng.stats()                                   # (synchronises; raises what a kernel flagged)
+            try:
+                if n and (first_line + 2) // 4 < bound:
+                    eng.count_device(shard.data_ptr(), int(n), first_line=first_line, maxreads=bound)
+                st = eng.stats()                               # (synchronises; raises what a kernel flagged)
+            except Exception as e:             # noqa: BLE001 -- raised on every rank by _agree
+                err = e
+            _agree(err, dev)
             if progress:
                 # reads of the whole file, then every rank's windows laid over the same axis and summed
                 # (before the matrix is unbound: unbinding resets the handle's results, the windows with them)
@@ -393,8 +458,13 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
     else:
         first_line = first_line_of(count_terminators(data), "cpu")
         out = np.zeros((len(barcodes), len(tags)), dtype=np.int64)
-        if n and (first_line + 2) // 4 < bound:     # sequence lines (index 1 mod 4) below first_line: (first_line + 2) // 4
-            out += np.asarray(counter(bytes(data), barcodes, tags, cutsite, first_line, bound), dtype=np.int64).reshape(out.shape)
+        err = None
+        try:
+            if n and (first_line + 2) // 4 < bound:     # sequence lines (index 1 mod 4) below first_line: (first_line + 2) // 4
+                out += np.asarray(counter(bytes(data), barcodes, tags, cutsite, first_line, bound), dtype=np.int64).reshape(out.shape)
+        except Exception as e:                 # noqa: BLE001 -- raised on every rank by _agree
+            err = e
+        _agree(err, "cpu")
         if world > 1:
             dist.all_reduce(torch.from_numpy(out), op=dist.ReduceOp.SUM)
     return out if as_array else out.tolist()
