@@ -85,7 +85,14 @@ int td_set_index(td_handle *h,
 
 /* Use caller-provided device memory (barnum*ntags uint32, zeroed by the
  * caller) for the count matrix, e.g. a torch tensor that is later all-reduced
- * over RCCL.  NULL returns to the internal buffer. */
+ * over RCCL.  NULL returns to the internal buffer.
+ * A bound matrix is the caller's: the library never moves it into its 64-bit host
+ * accumulator (the internal matrix is flushed there before a cell could wrap), so a
+ * cell wraps silently past 2^32 - 1 hits -- of ONE (barcode, tag) pair, summed over every
+ * file counted into the matrix and, after an all-reduce, over every rank.  The reference's
+ * default maxreads is 5e9 reads per file; BASELINE's largest job is 1.6e9 reads over
+ * 384 x 500 000 cells.  A caller whose single cell may pass 4.29e9 must flush the
+ * matrix into wider cells itself (or use the internal matrix and td_get_counts). */
 int td_bind_counts(td_handle *h, void *d_counts);
 
 /* Zero the count matrix, the statistics and the host-side accumulators. */

@@ -89,6 +89,16 @@ struct GzSource {
     size_t spill_pos = 0;
     bool bad = false;
 
+    // decoder threads when TAGDIG_INFLATE_THREADS does not say: the host's cores shared out over the ranks of this node
+    // (LOCAL_WORLD_SIZE, set by torch.distributed.run: eight ranks on one host each starting sixteen threads would be 128
+    // threads on its cores), at most 16
+    static int default_threads() {
+        unsigned hw = std::max<unsigned>(1, std::thread::hardware_concurrency());
+        const char *lw = getenv("LOCAL_WORLD_SIZE");
+        const int ranks = lw ? atoi(lw) : 1;
+        if (ranks > 1) hw = std::max<unsigned>(2, hw / (unsigned)ranks);
+        return (int)std::min<unsigned>(16, hw);
+    }
     static bool only_zeros(const uint8_t *p, size_t n) {
         for (size_t i = 0; i < n; i++) if (p[i]) return false;
         return true;
@@ -116,7 +126,7 @@ struct GzSource {
         const size_t n = fread(head, 1, sizeof(head), f);
         uint32_t bs = 0, hs = 0;
         const char *env = getenv("TAGDIG_INFLATE_THREADS");
-        int want = env ? atoi(env) : (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+        int want = env ? atoi(env) : default_threads();
         fclose(f);
         if (want > 1 && bgzf_header(head, n, &bs, &hs) && map_only(path)) {
             bgzf = true; bpos = 0; threads = want;
@@ -151,7 +161,7 @@ struct GzSource {
     // 8 MiB and more, several threads; false: open() the file the usual way.
     bool open_dev(const char *path, const ParInflate::Allocator *al) {
         const char *env = getenv("TAGDIG_INFLATE_THREADS");
-        const int want = env ? atoi(env) : (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+        const int want = env ? atoi(env) : default_threads();
         const char *par = getenv("TAGDIG_PAR_INFLATE");
         if (want <= 1 || getenv("TAGDIG_ZLIB") || (par && atoi(par) <= 0) || !map_only(path)) return false;
         uint32_t bs = 0, hs = 0;

@@ -67,6 +67,7 @@ class ParInflate {
     void open(const uint8_t *data, size_t n, int threads, size_t chunk_bytes) {
         close();
         data_ = data; n_ = n;
+        device_ = false; al_ = nullptr;                          // (dev_open sets them again)
         threads_ = std::max(1, std::min(threads, MAX_CHUNKS / 4));
         const char *ov = getenv("TAGDIG_INFLATE_OVERSUB");          // (more chunks than threads: they take unequal time)
         max_chunks_ = std::min(MAX_CHUNKS, std::max(1, ov ? atoi(ov) : 2) * threads_);
