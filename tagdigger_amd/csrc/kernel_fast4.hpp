@@ -55,7 +55,10 @@ namespace tdk {
 #define TD_F4_SLOTS 7               // tiles the ring in LDS holds
 #endif
 constexpr int F4_PROD = 4 /* quarters of a tile */, F4_WAVES = TD_F4_WAVES, F4_CONS = F4_WAVES - TD_F4_NPROD, F4_BLOCK = 64 * F4_WAVES;
-constexpr int F4_CPT = 4;                                   // 16-byte chunks per producer lane and tile
+#ifndef TD_F4_CPT
+#define TD_F4_CPT 4                 // 16-byte chunks per producer lane and job (4: 16 KiB tiles; 6: 24 KiB)
+#endif
+constexpr int F4_CPT = TD_F4_CPT;                           // 16-byte chunks per producer lane and tile
 constexpr uint32_t F4_WCH = F4_CPT * 64;                    // chunks per producer and tile
 constexpr uint32_t F4_WBYTES = F4_WCH * 16;
 constexpr uint32_t F4_TILE = F4_PROD * F4_WBYTES;           // 16 KiB

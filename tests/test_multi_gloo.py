@@ -416,8 +416,8 @@ def test_bgzf_inflate_range_rejects_what_is_not_a_member_start(tmp_path):
 # ---------------------------------------------------------------- the eight-rank shape (BASELINE configs 4 and 5)
 # Eight ranks of this code before the first real 8-GPU run: the rank arithmetic (libraries dealt out, shard bounds, member
 # ranges, the bound that falls into a late shard, ranks that own nothing) at the world size the driver launches.  Here with
-# the CPU stand-in for the counter (world size 8); on the GPU box with the product's counter at world size 6 -- the pool
-# admits six processes of one job on a card, not eight -- and 8 libraries over those 6 ranks.
+# the CPU stand-in for the counter (world size 8); on the GPU box with the product's counter at world size 5 -- the pool
+# admits six processes of one job on a card, the test runner being one -- and 8 libraries over those 5 ranks.
 def _make_eight_libraries(tmpdir, nrec=120):
     """Config 4's shape in small: 8 libraries, each with its own barcodes, whose samples map onto shared sample names."""
     from helpers import dirty_fastq, small_index
@@ -499,12 +499,12 @@ def test_eight_ranks_shard_the_config5_stream(tmp_path):
     assert torch.load(out) == want
 
 
-GPU_REHEARSAL_RANKS = 6            # (the pool's limit of processes of one job on a card)
+GPU_REHEARSAL_RANKS = 5            # (the pool admits six processes of one job on a card: the test runner itself is one of them)
 
 
 @pytest.mark.gpu
-def test_six_ranks_on_one_gpu_eight_libraries(tmp_path):
-    """Config 4's shape on the device path: 8 libraries over 6 ranks rehearsing on GPU 0 (two ranks take two libraries),
+def test_five_ranks_on_one_gpu_eight_libraries(tmp_path):
+    """Config 4's shape on the device path: 8 libraries over 5 ranks rehearsing on GPU 0 (three ranks take two libraries),
     K3 fold on the device, ONE all-reduce of the [samples x tags] device tensor == combineReadCounts."""
     from tagdigger_amd import tagdigger_fun as tf
     bckeys, tags = _make_eight_libraries(str(tmp_path), nrec=400)
@@ -516,7 +516,7 @@ def test_six_ranks_on_one_gpu_eight_libraries(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("maxreads", [5e9, 700])
-def test_six_ranks_on_one_gpu_byte_sharded_file(tmp_path, maxreads):
+def test_five_ranks_on_one_gpu_byte_sharded_file(tmp_path, maxreads):
     from oracle import c_oracle
     path, data, barcodes, tags = _dirty_file(tmp_path, "mixed", seed=23)
     data = data * 3
@@ -528,7 +528,7 @@ def test_six_ranks_on_one_gpu_byte_sharded_file(tmp_path, maxreads):
 
 
 @pytest.mark.gpu
-def test_six_ranks_on_one_gpu_member_sharded_bgzf_file(tmp_path):
+def test_five_ranks_on_one_gpu_member_sharded_bgzf_file(tmp_path):
     from oracle import c_oracle
     gz, data, barcodes, tags = _bgzf_file(tmp_path, "mixed", 997, seed=23)
     want = c_oracle.COracle(barcodes, tags, "TGCAG").count_bytes(data).tolist()

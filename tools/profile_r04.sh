@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-3 profile set (one gpurun call).  Results: gpurun_out/<tag>/ ; copy what is to be judged into profiles/<tag>/.
+# Round-4 profile set (one gpurun call).  Results: gpurun_out/<tag>/ ; copy what is to be judged into profiles/<tag>/.
 #   1. the default bench under rocprofv3 --kernel-trace --stats (the kernel's average duration beside the bench's own
 #      HIP-event time; the bench's live counter passes are off inside a profiled run)
 #   2. the default bench by itself (with its live FETCH_SIZE / WRITE_SIZE passes): the line the driver would see
 #   3. SQ instruction mix and waits of the main pass (tools/sq2.sh)
 #   4. k_split2's duration (tools/split_kernels.sh)
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 cd /tmp
@@ -27,4 +27,7 @@ echo "[profile] read lengths, CRLF"
 python3 "$ROOT/tools/readlen_sweep.py" > "$OUT/readlen.txt" 2>&1
 python3 "$ROOT/tools/crlf_check.py" 8000000 > "$OUT/crlf.txt" 2>&1
 rm -rf "$OUT/stats"
+ls -la "$OUT"
+echo "[profile] k_fast2 against k_fast4 and against round 3's kernel, passes alternating in one process"
+cd "$ROOT" && python3 tools/ab_inproc.py libtagdig_r3.so libtagdig.so libtagdig.so --arm "" --arm kernel=2 --arm kernel=4 --reads 100000000 --rounds 10 > "$OUT/ab_r3_fast2_fast4.txt" 2>&1
 ls -la "$OUT"
