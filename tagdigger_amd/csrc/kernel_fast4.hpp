@@ -1,15 +1,15 @@
 // k_fast4: the main pass of the free-running path with the workgroup's waves in TWO ROLES and no workgroup barrier
 // in the tile loop.  An experiment that is kept -- parity-green in every kernel-mode test, td_set_option("kernel", 4) --
-// and that LOSES to k_fast2 by 9 % at the bench shape (profiles/r04/k_fast4_*.txt); the default stays
+// and that LOSES to k_fast2 by 5 % at the bench shape (profiles/r04/k_fast4_*.txt); the default stays
 // k_fast2.
 //
 // k_fast2 (kernel_fast2.hpp) takes every tile through phases A-B (all four waves: terminators, lists of line starts),
 // a barrier, phases C-D (the wanted lines matched by the two waves whose lanes they fill) and a second barrier: per
 // tile the four waves can issue 4 x (A-B + D) instructions' worth of time but only have 4 x A-B + 2 x D to issue --
 // 72 % at best -- and every wave stands at two barriers behind the slowest.  Here a workgroup is sixteen waves, one
-// workgroup per CU, all of the CU's LDS one ring of seven 16 KiB tiles:
+// workgroup per CU, all of the CU's LDS one ring of five 24 KiB tiles:
 //
-//   producers (11 waves)   stream the FASTQ.  A job is a quarter of a tile; job 4 k + q goes to producer (4 k + q) mod 11;
+//   producers (11 waves)   stream the FASTQ.  A job is a quarter of a tile (6 KiB); job 4 k + q goes to producer (4 k + q) mod 11;
 //                          a producer's next TWO jobs' bytes are in flight in registers.  Per job: raw bytes -> the tile's
 //                          slot in LDS, terminator masks, the list of the quarter's line starts (k_fast2's phases A and B,
 //                          nothing shared between the producers).  The producer whose arrival makes four ("closer") waits
@@ -35,11 +35,13 @@
 // 12 KiB tiles, three workgroups a CU asked for) 16.7 ms -- a five-wave workgroup is admitted only TWO to a CU, ten
 // waves; eight waves (4 + 4, then 5 + 3 with the quarter-tile jobs) 13.0-13.9 ms -- both roles wait for each other half
 // of their time, a ring of three tiles is too short for a matching pass that lasts two tiles' production; sixteen waves
-// with seven slots 12.5 ms at 11 + 5 (10 + 6: 12.7, 12 + 4: 13.5, 13 + 3: 16.1).  The instruction count per byte equals
+// with seven 16 KiB slots 12.5 ms at 11 + 5 (10 + 6: 12.7, 12 + 4: 13.5, 13 + 3: 16.1); with five 24 KiB slots (fewer, larger
+// jobs) 11.6-11.8 ms against 11.1-11.2 -- the form kept; consumers without their priority 13.1, 32 KiB tiles 20.3
+// (registers), short passes taken eagerly by idle consumers 11.6-11.7.  The instruction count per byte equals
 // k_fast2's; what the roles buy in balance they lose again in waiting at the hand-offs.
 // Tiles that are not "regular" (the buffer's first and last, bytes >= 0x80, '\r' at the end of a chunk next to another
 // wave's bytes, more line starts than a list holds) are only counted here (terminators) and flagged TI_SKIP for the
-// fix-up pass (k_fast<4, W, true>: the same 16 KiB tile), as in k_fast2.
+// fix-up pass (k_fast<6, W, true>: the same 24 KiB tile), as in k_fast2.
 #pragma once
 #include "kernel_fast2.hpp"
 
@@ -52,11 +54,11 @@ namespace tdk {
 #define TD_F4_NPROD 11              // producer waves among them (they take the quarter-tile jobs in turn); the others match
 #endif
 #ifndef TD_F4_SLOTS
-#define TD_F4_SLOTS 7               // tiles the ring in LDS holds
+#define TD_F4_SLOTS 5               // tiles the ring in LDS holds
 #endif
 constexpr int F4_PROD = 4 /* quarters of a tile */, F4_WAVES = TD_F4_WAVES, F4_CONS = F4_WAVES - TD_F4_NPROD, F4_BLOCK = 64 * F4_WAVES;
 #ifndef TD_F4_CPT
-#define TD_F4_CPT 4                 // 16-byte chunks per producer lane and job (4: 16 KiB tiles; 6: 24 KiB)
+#define TD_F4_CPT 6                 // 16-byte chunks per producer lane and job (4: 16 KiB tiles; 6: 24 KiB)
 #endif
 constexpr int F4_CPT = TD_F4_CPT;                           // 16-byte chunks per producer lane and tile
 constexpr uint32_t F4_WCH = F4_CPT * 64;                    // chunks per producer and tile
@@ -64,6 +66,12 @@ constexpr uint32_t F4_WBYTES = F4_WCH * 16;
 constexpr uint32_t F4_TILE = F4_PROD * F4_WBYTES;           // 16 KiB
 constexpr int F4_SLOTS = TD_F4_SLOTS;
 constexpr uint32_t F4_SPIN_LIMIT = 1u << 18;
+#ifndef TD_F4_EAGER_MIN
+#define TD_F4_EAGER_MIN 65          // a consumer that has waited TD_F4_EAGER_SPINS polls takes fewer than 64 lines if there are this many (65: never)
+#endif
+#ifndef TD_F4_EAGER_SPINS
+#define TD_F4_EAGER_SPINS 4
+#endif
 #ifndef TD_F4_P_CONS
 #define TD_F4_P_CONS 1              // wave priority of the consumers (the producers run at 0)
 #endif
@@ -552,6 +560,8 @@ __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams 
                     n = have;
                 } else if (have != 0u && lds_ld(L_ctrl + (R % (uint32_t)F4_SLOTS) * F4_CTRL_DW + F4_FREE) < R / (uint32_t)F4_SLOTS) {
                     n = have;                                    // (the next tile's slot has not been given back: these lines first)
+                } else if (have >= (uint32_t)TD_F4_EAGER_MIN && idle >= (uint32_t)TD_F4_EAGER_SPINS) {
+                    n = have;                                    // (nothing else to do: a short pass now gives slots back sooner)
                 }
                 if (n) {
                     uint32_t won = 0;

@@ -175,7 +175,7 @@ def test_tile_boundary_sweep(eng, mode):
     rec = b"@h\r\nAACGTGCAGAAACTT\r\n+\r\nIIII\r\n"
     eng.set_index(barcodes, tags, "TGCAG")
     ora = c_oracle.COracle(barcodes, tags, "TGCAG")
-    tile = 1024 * (16 if mode.get("kernel") == 4 else mode["tile_kb2"] if mode.get("kernel") == 2 else mode["tile_kb"])
+    tile = 1024 * (24 if mode.get("kernel") == 4 else mode["tile_kb2"] if mode.get("kernel") == 2 else mode["tile_kb"])
 
     def padded(n):          # one record of exactly n bytes
         return b"@p\nGGGG\n+\n" + b"I" * (n - 10 - 1) + b"\n"

@@ -69,7 +69,7 @@ def main():
     ms, _ = eng.kernel_time_ms()
     c = list(eng.debug_counters()[:20]); c[11] = 0
     tot = float(sum(c[:20])) or 1.0
-    tkb = 16 if a.kernel == 4 else a.tile_kb2 if a.kernel == 2 else a.tile_kb
+    tkb = 24 if a.kernel == 4 else a.tile_kb2 if a.kernel == 2 else a.tile_kb
     ntiles = (cfg.nbytes() + tkb * 1024 - 1) // (tkb * 1024)
     print("kernel=%d tile_kb=%d blocks_per_cu=%s prescan=%d  kernel %.2f ms (stamped build)  tiles=%d" % (
         a.kernel, tkb, a.blocks_per_cu or "auto", a.prescan, ms, ntiles))
