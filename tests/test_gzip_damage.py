@@ -186,3 +186,72 @@ def test_damaged_bgzf_files_end_as_gzip_open_ends_them(tmp_path, capsys):
         finally:
             eng.set_option("gpu_inflate", 1)
     capsys.readouterr()
+
+
+def _loop_over_gzip_open(path, lines_needed):
+    """What a loop that takes `lines_needed` complete lines out of gzip.open(path, 'rt') and then breaks (the shape of the
+    reference's loops, :250 with :272-273) ends in: None, or the exception gzip raised on the way."""
+    try:
+        with gzip.open(path, "rt", encoding="latin-1") as fh:
+            for k, _ in enumerate(fh):
+                if lines_needed is not None and k + 1 >= lines_needed:
+                    break
+    except (EOFError, OSError, zlib.error) as exc:
+        return exc
+    return None
+
+
+def test_reading_rules_campaign_against_gzip_open(tmp_path):
+    """Random streams -- members at several levels, members of nothing, zero padding, \\r\\n and bare \\r lines -- with random
+    damage (cuts, flipped bits, junk) and random bounds: td_gzip_check must end as Python's own gzip.open ends under a loop
+    of the reference's shape.  (The 96 goldens pin the reference itself; this pins the restatement on Lib/gzip.py over a
+    few hundred more files.)"""
+    import os
+    import random
+    import time
+    from tagdigger_amd import _binding as B
+    L = B.load()
+    rng = random.Random(int(os.environ.get("TD_FUZZ_SEED", "20261005")))
+    budget = float(os.environ.get("TD_FUZZ_SECONDS", "20"))
+    t0 = time.time()
+    ncase = nraise = 0
+    p = tmp_path / "x.fq.gz"
+    while time.time() - t0 < budget:
+        nl = rng.choice([b"\n", b"\n", b"\r\n", b"\r"])
+        recs = []
+        for i in range(rng.randrange(1, 400)):
+            seq = bytes(rng.choice(b"ACGTN") for _ in range(rng.randrange(0, 120)))
+            recs.append(b"@r%d" % i + nl + seq + nl + b"+" + nl + b"I" * len(seq) + nl)
+        text = b"".join(recs)
+        cuts = sorted(rng.randrange(0, len(text) + 1) for _ in range(rng.randrange(0, 4)))
+        blob = b""
+        for a, b in zip([0] + cuts, cuts + [len(text)]):
+            blob += gzip.compress(text[a:b], compresslevel=rng.choice([0, 1, 6, 9]), mtime=0)
+            if rng.random() < 0.2:
+                blob += b"\0" * rng.randrange(1, 40)
+        kind = rng.random()
+        if kind < 0.25:
+            blob = blob[:rng.randrange(0, len(blob) + 1)]
+        elif kind < 0.55:
+            q = bytearray(blob)
+            for _ in range(rng.randrange(1, 3)):
+                q[rng.randrange(len(q))] ^= 1 << rng.randrange(8)
+            blob = bytes(q)
+        elif kind < 0.65:
+            blob += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 12)))
+        p.write_bytes(blob)
+        nreads = len(recs)
+        maxreads = rng.choice([None, None, rng.randrange(1, nreads + 3), rng.randrange(1, nreads + 3)])
+        need = None if maxreads is None else 4 * (maxreads - 1) + 2
+        expected = _loop_over_gzip_open(str(p), need)
+        rc = L.td_gzip_check(str(p).encode(), maxreads if maxreads is not None else 1 << 62)
+        if expected is None:
+            assert rc == 0, (ncase, maxreads, (L.td_last_error() or b"").decode())
+        else:
+            with pytest.raises(type(expected)) as ei:
+                B.check(rc)
+            assert type(ei.value) is type(expected) and str(ei.value) == str(expected), (ncase, maxreads)
+            nraise += 1
+        ncase += 1
+    print(" [gzip reading rules campaign: %d cases, %d raise] " % (ncase, nraise), end="")
+    assert ncase > 50 and nraise > 10
