@@ -1,6 +1,6 @@
 // k_fast4: the main pass of the free-running path with the workgroup's waves in TWO ROLES and no workgroup barrier
 // in the tile loop.  An experiment that is kept -- parity-green in every kernel-mode test, td_set_option("kernel", 4) --
-// and that LOSES to k_fast2 by 5 % at the bench shape (profiles/r04/k_fast4_*.txt); the default stays
+// and that LOSES to k_fast2 by 5 % at the bench shape (profiles/r04_final/k_fast4_*.txt); the default stays
 // k_fast2.
 //
 // k_fast2 (kernel_fast2.hpp) takes every tile through phases A-B (all four waves: terminators, lists of line starts),
@@ -56,7 +56,7 @@ namespace tdk {
 #ifndef TD_F4_SLOTS
 #define TD_F4_SLOTS 5               // tiles the ring in LDS holds
 #endif
-constexpr int F4_PROD = 4 /* quarters of a tile */, F4_WAVES = TD_F4_WAVES, F4_CONS = F4_WAVES - TD_F4_NPROD, F4_BLOCK = 64 * F4_WAVES;
+constexpr int F4_PROD = 4 /* quarters of a tile */, F4_WAVES = TD_F4_WAVES, F4_BLOCK = 64 * F4_WAVES;
 #ifndef TD_F4_CPT
 #define TD_F4_CPT 6                 // 16-byte chunks per producer lane and job (4: 16 KiB tiles; 6: 24 KiB)
 #endif
@@ -82,6 +82,7 @@ enum { F4_DONE = 0, F4_FREE = 1, F4_REMAIN = 2, F4_FLAGS = 3, F4_TOT = 4 /* 4 */
 constexpr uint32_t F4_FLAG_HI = 1, F4_FLAG_OVER = 2, F4_FLAG_HALO_HI = 4;
 // the workgroup's words behind the slots': abort, tiles closed, wanted lines in them, wanted lines claimed
 constexpr uint32_t F4_ABORT_DW = F4_SLOTS * F4_CTRL_DW, F4_READY_DW = F4_ABORT_DW + 1, F4_AVAIL_DW = F4_ABORT_DW + 2, F4_CLAIMED_DW = F4_ABORT_DW + 3;
+constexpr uint32_t F4_NPROD_MIN = 7, F4_NPROD_MAX = 13;      // producers of the sixteen waves (LDS holds hot-cell caches for 16 - F4_NPROD_MIN consumers)
 constexpr uint32_t F4_CTRL_BYTES = 1024;                     // (256 dwords: the slots' words, the workgroup's, a spare word per wave at 240)
 static_assert(F4_CLAIMED_DW < 240 && F4_WAVES <= 16, "hand-off words");
 
@@ -103,6 +104,28 @@ __device__ __forceinline__ bool f4_wait(uint32_t *p, uint32_t need, uint32_t *ab
     return true;
 }
 
+// The producer count for k_fast4 from the buffer's first bytes: bytes per record = 4 x bytes per line over the first 64 KiB
+// (one workgroup, launched in front of the main pass on its stream: no host round trip).
+#ifndef TD_INST_ONLY
+__global__ __launch_bounds__(256) void k_f4_estimate(const uint8_t *buf, uint64_t nbytes, uint32_t *out) {
+    __shared__ uint32_t total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const uint32_t n = (uint32_t)(nbytes < 65536ull ? nbytes : 65536ull) & ~15u;
+    uint32_t cnt = 0;
+    for (uint32_t i = threadIdx.x * 16u; i < n; i += 256u * 16u) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(buf + i);
+        cnt += (uint32_t)__builtin_popcount(eq_mask16(v, 0x0A0A0A0Au) | eq_mask16(v, 0x0D0D0D0Du));    // ("\r\n" counts twice: such records read as shorter, a consumer more)
+    }
+    atomicAdd(&total, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t rec = total >= 8u ? 4u * n / total : 219u;      // bytes per record
+        *out = rec < 150u ? 8u : rec < 195u ? 9u : rec < 270u ? 10u : rec < 420u ? 11u : 12u;
+    }
+}
+#endif
+
 // diagnostic build only (-DTD_PHASE_PROF): lane 0 of every wave adds the shader-clock cycles between stamps to stats[8 + i]
 // (producers 0-4: waiting for the slot, A, B + lists, closing a tile, -; consumers 5-8: pending lines, waiting for a tile, matching, rest)
 #ifdef TD_PHASE_PROF
@@ -111,7 +134,10 @@ __device__ __forceinline__ bool f4_wait(uint32_t *p, uint32_t need, uint32_t *ab
 #define F4_STAMP(i) do {} while (0)
 #endif
 
-template <int W, int NQ>
+// PROG: the progress windows' per-tile sums (kernel_fast.hpp FParams::tile_sums: how many of a tile's wanted lines had a barcode,
+// low half, and a tag, high half) -- a consumer's lines lie in up to three tiles, so it adds per tile: the barcodes when the lines
+// are packed, the tags a pass later, when the pending lines are settled (each lane remembers its line's tile).
+template <int W, int NQ, bool PROG>
 __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams fp) {
     const KParams &p = fp.k;
 #ifdef TD_PHASE_PROF
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams 
     uint32_t *L_ctrl = reinterpret_cast<uint32_t *>(lds + F4_SLOTS * slot_bytes + F4_SLOTS * F4_PROD * WCH * 2u);
     uint32_t *L_abort = L_ctrl + F4_ABORT_DW;
     uint8_t *L_hc = reinterpret_cast<uint8_t *>(L_ctrl) + F4_CTRL_BYTES;
-    uint8_t *L_bidx = L_hc + F4_CONS * HC_BYTES_PER_WAVE;
+    uint8_t *L_bidx = L_hc + ((uint32_t)F4_WAVES - F4_NPROD_MIN) * HC_BYTES_PER_WAVE;
     TileCtx cx{nullptr, 0u, reinterpret_cast<const unsigned long long *>(L_bidx),
                reinterpret_cast<const uint32_t *>(L_bidx + p.off_bmeta),
                reinterpret_cast<const uint16_t *>(L_bidx + p.off_bdir)};
@@ -156,8 +182,13 @@ __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams 
 
     // ---------------------------------------------------------------- producing: a job is a quarter of a tile; job 4 k + q goes
     // to producer (4 k + q) mod NPROD
-    constexpr uint32_t NPROD = TD_F4_NPROD;
-    static_assert(TD_F4_NPROD >= 1 && TD_F4_NPROD < F4_WAVES, "producers and consumers");
+    // How many of the sixteen waves produce follows the input: short reads put more lines into a tile and want more
+    // consumers, long reads fewer (measured, 96 barcodes x 10 k tags: 36 bp best at 8 producers, 75 bp at 9, 100 bp at 10, 150 bp
+    // at 11, 250 bp at 12 -- each better than k_fast2 there, the fixed 11 + 5 only from 100 bp up).  k_f4_estimate, launched in
+    // front of this kernel, leaves the number in device memory (KParams::f4_nprod_dev); td_set_option "f4_nprod" fixes it.
+    uint32_t np_ = p.f4_nprod ? p.f4_nprod : (p.f4_nprod_dev ? *p.f4_nprod_dev : (uint32_t)TD_F4_NPROD);
+    np_ = np_ < F4_NPROD_MIN ? F4_NPROD_MIN : np_ > F4_NPROD_MAX ? F4_NPROD_MAX : np_;
+    const uint32_t NPROD = (uint32_t)__builtin_amdgcn_readfirstlane((int)np_);
     {
         // a job's bytes in registers: this lane's CPT chunks, and -- the last quarter's first lanes -- the halo behind the
         // tile (every lane asks: the others for an offset beyond the descriptor's range, which returns zeros without touching
@@ -432,6 +463,7 @@ __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams 
         Pending<W> pd;                                          // lines whose buckets are in flight
         Pending<W> nx;                                          // a line whose bucket has not been asked for yet (R, nr, boff only)
         bool pd_valid = false;
+        bool phit_tag = false;                                  // the line finish_pending finished had a tag
         auto finish_pending = [&](bool &hit, uint32_t &cell) {
             vm_settled();
             const uint64_t res = match_finish<W>(p, pd);
@@ -439,14 +471,28 @@ __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams 
             st_reads += 1;
             if (kind >= 1) st_bar += 1;
             if (kind == 2) st_tag += 1;
+            phit_tag = kind == 2;
             hit = kind == 2 && !(TD_DBG(p) & DBG_NO_ATOMIC);
             cell = (uint32_t)res;
         };
         // the pending lines of the pass before: compares and count
+        uint32_t pd_tile = 0;                                   // (PROG) the tile of this lane's pending line
+        // one add per tile the flagged lanes' lines lie in (at most the ring's slots)
+        auto sums_add = [&](bool flag, uint32_t tile, uint32_t unit) {
+            uint64_t left = __ballot(flag);
+            while (left) {
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, (int)__builtin_ctzll(left));
+                const uint64_t m = __ballot(flag && tile == t0);
+                if (lane == (int)__builtin_ctzll(left)) atomicAdd(fp.tile_sums + t0, unit * (uint32_t)__builtin_popcountll(m));
+                left &= ~m;
+            }
+        };
         auto settle = [&]() {
             if (__any(pd_valid)) {
                 bool phit = false; uint32_t pcell = 0;
+                phit_tag = false;
                 if (pd_valid) finish_pending(phit, pcell);
+                if (PROG) sums_add(pd_valid && phit_tag, pd_tile, 1u << 16);
                 pd_valid = false;
                 if (hc_on) {
                     const uint32_t h = hc_hash(pcell);
@@ -475,8 +521,10 @@ __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams 
         uint32_t kres = 7u, srel = 0;                        // (7: no line for this lane)
         uint4 q[NQ];
         const bool mine = active && myslot < (uint32_t)F4_SLOTS;
+        uint32_t my_tile = 0;                                // the line's tile (read now: the slot's words are the next tile's once it is given back)
         if (mine) {
             const uint32_t *cs = L_ctrl + myslot * F4_CTRL_DW;
+            my_tile = lds_ld(cs + F4_TIDX);
             const uint4 ph = *reinterpret_cast<const uint4 *>(cs + F4_R0);        // r0, wb1, wb2, wb3
             // (the producer whose list holds ordinal o, and o's place in it: selects, no branches)
             const uint32_t o = ph.x + 4u * jl;
@@ -504,6 +552,7 @@ __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams 
         // kres: 0 no barcode, 2 barcode only, 1 the tag is to be looked up, 6 leading blank (rare: raw bytes re-read)
         st_reads += kres == 0u || kres == 2u ? 1 : 0;
         st_bar += kres == 2u ? 1 : 0;
+        if (PROG) sums_add(kres == 1u || kres == 2u, my_tile, 1u);
         F4_STAMP(7);
         // the lines that have been pending since the pass before: their buckets were asked for a whole line_prepare ago -- then
         // this pass's buckets, which stay in flight
@@ -513,11 +562,13 @@ __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams 
         // here, where no bucket is in flight and the pending registers are free)
         if (__builtin_expect(__any(kres == 6u), 0)) {
             if (kres == 6u) {
-                const uint64_t tb = (uint64_t)lds_ld(L_ctrl + myslot * F4_CTRL_DW + F4_TIDX) * TILE;
+                const uint32_t tix = my_tile;
+                const uint64_t tb = (uint64_t)tix * TILE;
                 const uint64_t res = match_line<W, ML_SLOW>(p, cx, tb + srel, srel, true);
                 const uint32_t kind = (uint32_t)(res >> 62);
                 st_reads += 1;
                 if (kind >= 1) st_bar += 1;
+                if (PROG && kind >= 1) atomicAdd(fp.tile_sums + tix, 1u + (kind == 2 ? 1u << 16 : 0u));
                 if (kind == 2) {
                     st_tag += 1;
                     if (!(TD_DBG(p) & DBG_NO_ATOMIC))
@@ -532,6 +583,7 @@ __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams 
             pd.nr = nx.nr; pd.boff = nx.boff;
             bucket_issue<W>(p, pd);
             pd_valid = true;
+            if (PROG) pd_tile = my_tile;
         }
         if (p.hot_cache && ++aged == HC_AGE_TILES) {
             aged = 0;
@@ -602,7 +654,7 @@ __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams 
 }  // namespace tdk
 
 #ifdef TD_FAST4_EXTERN
-#define TD_X4(W, NQ) extern template __global__ void tdk::k_fast4<W, NQ>(const tdk::FParams);
+#define TD_X4(W, NQ) extern template __global__ void tdk::k_fast4<W, NQ, false>(const tdk::FParams); extern template __global__ void tdk::k_fast4<W, NQ, true>(const tdk::FParams);
 TD_FAST2_COMBOS(TD_X4)
 #undef TD_X4
 #endif

@@ -105,6 +105,8 @@ struct KParams {
     // null = not wanted
     unsigned long long *win;
     uint32_t win_cap;
+    uint32_t f4_nprod;       // k_fast4: producer waves of the workgroup's sixteen (the others match); 0: *f4_nprod_dev
+    const uint32_t *f4_nprod_dev;   // ... as k_f4_estimate left it in device memory
 };
 constexpr uint32_t PROG_WINDOW = 50000;
 

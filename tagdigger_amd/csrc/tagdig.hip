@@ -179,6 +179,7 @@ struct td_handle {
     uint32_t sp_gcap = 4;                     // entries per (barcode, last two bases) group of entries16
     std::vector<uint64_t> split_win;          // td_split_file's: {with barcode, clipped} per window of 50 000 reads
     DevBuf<unsigned long long> d_win;
+    DevBuf<uint32_t> d_f4np;                  // k_fast4's producer count as k_f4_estimate leaves it
     DevBuf<uint32_t> d_tilesums;              // k_fast2's per-tile sums of what its wanted lines matched (progress windows)
     std::vector<uint64_t> host_acc;           // flushed counts
     uint64_t bytes_since_flush = 0;
@@ -225,10 +226,11 @@ struct td_handle {
     uint32_t max_need = 0;                    // bases from a read's start that the matcher may look at
     // options
     int tile_kb = 32, blocks_per_cu = 0, prescan = 0, timing = 0, fastpath = 1, nt_loads = 1;
-    int kernel_gen = 2;                       // main pass of the free-running path: 2 = k_fast2 (lazy packing), 1 = k_fast
+    int kernel_gen = 4;                       // main pass of the free-running path: 4 = k_fast4 (producer / consumer waves), 2 = k_fast2 (lazy packing), 1 = k_fast
     int tile_kb2 = 0;                         // k_fast2's tile (16 | 24 | 32 KiB; 0 = fast2_auto_tile)
     int run = 8;                              // k_fast2: consecutive tiles per workgroup turn (measured: 4-16 alike, 1 and 64+ slower)
     int hot_cache = 1;                        // k_fast2: count through the per-wave hot-cell cache
+    int f4_nprod = 0;                         // k_fast4: producer waves of sixteen (0: TD_F4_NPROD)
     uint64_t fast_max_matrix = 1ull << 32;    // the free-running kernel addresses cells as base + 32-bit byte offset
     uint32_t debug_ablate = 0;
     double table_load = 0.25;
@@ -323,17 +325,18 @@ FFn pick_fix(int tile_kb, int W) {          // the fix-up pass shares the main p
     return pick_fast(tile_kb, W, true);
 }
 // k_fast4: producer and consumer waves, 16 KiB tiles (kernel_fast4.hpp)
-FFn pick_fast4(int W, uint32_t nq) {
+template <bool PROG> FFn pick_fast4_p(int W, uint32_t nq) {
     switch (W) {
-    case 1: return nq == 3 ? tdk::k_fast4<1, 3> : nq == 4 ? tdk::k_fast4<1, 4> : tdk::k_fast4<1, 6>;
-    case 2: return nq == 5 ? tdk::k_fast4<2, 5> : nq == 6 ? tdk::k_fast4<2, 6> : tdk::k_fast4<2, 8>;
-    default: return nq == 7 ? tdk::k_fast4<3, 7> : nq == 8 ? tdk::k_fast4<3, 8> : tdk::k_fast4<3, 10>;
+    case 1: return nq == 3 ? tdk::k_fast4<1, 3, PROG> : nq == 4 ? tdk::k_fast4<1, 4, PROG> : tdk::k_fast4<1, 6, PROG>;
+    case 2: return nq == 5 ? tdk::k_fast4<2, 5, PROG> : nq == 6 ? tdk::k_fast4<2, 6, PROG> : tdk::k_fast4<2, 8, PROG>;
+    default: return nq == 7 ? tdk::k_fast4<3, 7, PROG> : nq == 8 ? tdk::k_fast4<3, 8, PROG> : tdk::k_fast4<3, 10, PROG>;
     }
 }
+FFn pick_fast4(int W, uint32_t nq, bool prog) { return prog ? pick_fast4_p<true>(W, nq) : pick_fast4_p<false>(W, nq); }
 size_t lds_bytes_fast4(const td_handle *h) {
     // three slots of raw tile + halo | per slot and producer the masks / line starts | hand-off words | the consumers' hot-cell caches | barcode index
     return (size_t)tdk::F4_SLOTS * (tdk::F4_TILE + h->halo) + (size_t)tdk::F4_SLOTS * tdk::F4_PROD * tdk::F4_WCH * 2 + tdk::F4_CTRL_BYTES +
-           (size_t)tdk::F4_CONS * tdk::HC_BYTES_PER_WAVE + h->bblob_bytes;
+           (size_t)(tdk::F4_WAVES - tdk::F4_NPROD_MIN) * tdk::HC_BYTES_PER_WAVE + h->bblob_bytes;
 }
 // k_fast2's tile: four workgroups must share a CU's 160 KiB of LDS (measured: three cost a fifth of the throughput),
 // so a large barcode index (many barcodes x several concrete cut sites) takes the smaller tile
@@ -413,16 +416,16 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
     const uint64_t fl_ub = std::max(first_line, first_line_ub);
     const bool limit_far = limit_line >= ~0ull - 16 || limit_line - std::min(limit_line, fl_ub) >= nbytes / 16;
     const bool counts32 = (uint64_t)h->barnum * h->ntags * 4 < h->fast_max_matrix;
-    // progress windows are recorded by k_fast2 (+ k_resolve, fix-up pass) and by the exact kernel; not by k_fast's main pass
+    // progress windows are recorded by k_fast4 and k_fast2 (+ k_resolve, fix-up pass) and by the exact kernel; not by k_fast's main pass
     // its main pass: k_fast2 (raw tile in LDS, lines packed by the lane that matches them) where the tag width has
     // the pipelined probe and the tile fits the LDS budget, else k_fast -- which keeps no progress records: with
     // progress on and no k_fast2 (wide tags, or a barcode index too large for its LDS layout) the exact kernel counts
     const int tkb2 = h->tile_kb2 ? h->tile_kb2 : fast2_auto_tile(h);
-    // k_fast4 (producer and consumer waves) where three of its workgroups share a CU's LDS and no progress windows are wanted
-    // (it keeps no per-tile sums); else k_fast2
-    const bool gen4_fits = h->kernel_gen == 4 && h->W <= 3 && !h->progress && lds_bytes_fast4(h) <= 160 * 1024;     // (one workgroup of sixteen waves a CU)
+    // k_fast4 (producer and consumer waves, one workgroup of sixteen waves a CU) where its ring fits the CU's LDS beside the
+    // barcode index; else k_fast2
+    const bool gen4_fits = h->kernel_gen == 4 && h->W <= 3 && lds_bytes_fast4(h) <= 160 * 1024;     // (one workgroup of sixteen waves a CU)
     const bool gen2_fits = (h->kernel_gen == 2 || (h->kernel_gen == 4 && !gen4_fits)) && h->W <= 3 && lds_bytes_fast2(h, tkb2) <= LDS_BUDGET;
-    const bool use_fast = h->fastpath && !tassel && !h->prescan && limit_far && counts32 && !(h->progress && !gen2_fits);
+    const bool use_fast = h->fastpath && !tassel && !h->prescan && limit_far && counts32 && !(h->progress && !gen2_fits && !gen4_fits);
     const bool gen4 = use_fast && gen4_fits;
     const bool gen2 = use_fast && gen2_fits && !gen4;
     const int tile_kb = tassel ? 16 : gen4 ? (int)(tdk::F4_TILE / 1024) : gen2 ? tkb2 : h->tile_kb;
@@ -463,6 +466,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
 
     p.hot_cache = (uint32_t)h->hot_cache;
     p.run = (uint32_t)h->run;
+    p.f4_nprod = (uint32_t)h->f4_nprod;                 // (0: k_f4_estimate's, below)
     if (h->progress) {
         // windows are indexed by the read's ordinal in the whole stream: a line holds a byte at least, a read four lines
         const uint64_t need = (fl_ub + nbytes) / 4 / tdk::PROG_WINDOW + 2;
@@ -505,7 +509,7 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
             fp.tile_sums = h->d_tilesums.p;
         }
         HIPCHK(hipMemsetAsync(h->d_nfix.p, 0, 4, stream));
-        FFn ffn = gen4 ? pick_fast4(h->W, h->nch2) : gen2 ? pick_fast2(tile_kb, h->W, h->nch2, h->progress != 0) : pick_fast(tile_kb, h->W, false), fixfn = pick_fix(tile_kb, h->W);
+        FFn ffn = gen4 ? pick_fast4(h->W, h->nch2, h->progress != 0) : gen2 ? pick_fast2(tile_kb, h->W, h->nch2, h->progress != 0) : pick_fast(tile_kb, h->W, false), fixfn = pick_fix(tile_kb, h->W);
         const size_t flds = gen4 ? lds_bytes_fast4(h) : gen2 ? lds_bytes_fast2(h, tile_kb) : lds_bytes_fast(h, tile_kb), fixlds = lds_bytes_fast(h, tile_kb);
         const unsigned main_threads = gen4 ? (unsigned)tdk::F4_BLOCK : (unsigned)tdk::FBLOCK, fix_threads = tile_kb == 12 ? 128u : (unsigned)tdk::FBLOCK;
         if (flds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
@@ -529,6 +533,12 @@ int launch_count(td_handle *h, const void *d_fastq, uint64_t nbytes, uint64_t fi
             }
             e0 = h->ev_pool[h->ev_used].first; e1 = h->ev_pool[h->ev_used].second; h->ev_used++;
             HIPCHK(hipEventRecord(e0, stream));
+        }
+        if (gen4 && !h->f4_nprod) {
+            // (the tail copy holds the bytes of a buffer shorter than a tile)
+            int rc4 = h->d_f4np.ensure(4); if (rc4) return rc4;
+            hipLaunchKernelGGL(tdk::k_f4_estimate, dim3(1), dim3(256), 0, stream, (const uint8_t *)d_fastq, nbytes, h->d_f4np.p);
+            fp.k.f4_nprod_dev = h->d_f4np.p;
         }
         hipLaunchKernelGGL(ffn, dim3(grid), dim3(main_threads), flds, stream, fp);
         {   // exact line phase of every tile (d_state is free on this path: it holds the block sums)
@@ -689,7 +699,7 @@ void td_destroy(td_handle *h) {
     (void)hipDeviceSynchronize();
     h->d_bblob.release(); h->d_slots.release(); h->d_shorts.release(); h->d_counts.release();
     if (h->pin_cursor) (void)hipHostFree(h->pin_cursor);
-    h->d_win.release(); h->d_tilesums.release(); h->d_sp_entries16.release(); h->d_sp_e8.release(); h->d_sp_pool2.release();
+    h->d_win.release(); h->d_tilesums.release(); h->d_f4np.release(); h->d_sp_entries16.release(); h->d_sp_e8.release(); h->d_sp_pool2.release();
     h->d_counts64.release(); h->d_stats.release(); h->d_state.release(); h->d_tilecounts.release();
     h->d_ticket.release(); h->d_cursor.release(); h->d_tileinfo.release(); h->d_nfix.release(); h->d_tail.release(); h->d_fixlist.release(); h->d_rowmap.release();
     for (auto &ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -1913,6 +1923,9 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
         if (value != 0 && value != 16 && value != 24 && value != 32) return fail(TD_E_ARG, "tile_kb2 must be 0 (automatic), 16, 24 or 32");
         if (value && h->have_index && lds_bytes_fast2(h, (int)value) > LDS_BUDGET) return fail(TD_E_LIMIT, "tile does not fit the LDS budget with this index");
         h->tile_kb2 = (int)value;
+    } else if (n == "f4_nprod") {
+        if (value != 0 && (value < tdk::F4_NPROD_MIN || value > tdk::F4_NPROD_MAX)) return fail(TD_E_ARG, "f4_nprod: 7 .. 13 producer waves of k_fast4's sixteen (0: from the input's line density)");
+        h->f4_nprod = (int)value;
     } else if (n == "hot_cache") h->hot_cache = value == 2 ? 2 : value ? 1 : 0;
     else if (n == "run") h->run = (int)std::max<int64_t>(1, std::min<int64_t>(value, 4096));
     else if (n == "progress") h->progress = value ? 1 : 0;

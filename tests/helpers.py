@@ -9,7 +9,7 @@ from oracle import c_oracle
 
 
 # Every way the count can be computed on the device (td_set_option names): the free-running path with its
-# producer / consumer main pass (k_fast4, 12 KiB tiles), its second-generation main pass (k_fast2, 24 and 32 KiB tiles) and its first (k_fast, 32 and 16 KiB tiles), and
+# producer / consumer main pass (k_fast4, 24 KiB tiles; the default), its second-generation main pass (k_fast2, 24 and 32 KiB tiles) and its first (k_fast, 32 and 16 KiB tiles), and
 # the exact look-back kernel.  All give the same counts.
 KERNEL_MODES = [
     dict(fastpath=1, kernel=2, tile_kb2=24),
@@ -20,7 +20,7 @@ KERNEL_MODES = [
     dict(fastpath=0, tile_kb=32),
     dict(fastpath=1, kernel=4),
 ]
-DEFAULT_MODE = dict(fastpath=1, kernel=2, tile_kb2=0, tile_kb=32)
+DEFAULT_MODE = dict(fastpath=1, kernel=4, tile_kb2=0, tile_kb=32)
 
 
 def apply_mode(eng, mode):
@@ -125,3 +125,20 @@ import os as _os
 import sys as _sys
 _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools"))
 from compress_formats import bgzf_bytes, gzip_one_member  # noqa: E402,F401  (tools/compress_formats.py: shared with the bench's tiers)
+
+
+FUZZ_CUTS = ["TGCAG", "CWGC", "", "RCATGY", "TGCAT", "CATGG", "GWC"]
+
+
+def fuzz_case(seed):
+    """Case number `seed` of the randomised campaign (tests/test_gpu_parity.py::test_fuzz_campaign, tools/fuzz_repro.py):
+    (barcodes, tags, cutsite, newline styles, bytes)."""
+    import random
+    rnd = random.Random(seed)
+    cutsite = rnd.choice(FUZZ_CUTS)
+    nl = rnd.choice([("\n",), ("\r\n",), ("\r",), ("\n", "\r\n", "\r")])
+    taglens = rnd.choice([(8, 30), (20, 70), (60, 130), (30, 64)])
+    barcodes, tags, cutsites = small_index(rnd, cutsite, nbar=rnd.randint(1, 24), ntag=rnd.randint(1, 120), taglens=taglens)
+    data = dirty_fastq(rnd, barcodes, tags, cutsites, nrec=rnd.randint(1, 3000), nl_choices=nl,
+                       long_lines=rnd.random() < 0.3, permanent_shifts=rnd.random() < 0.3)
+    return barcodes, tags, cutsite, nl, data

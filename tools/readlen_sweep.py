@@ -11,9 +11,14 @@ from tagdigger_amd.synth import SynthConfig
 eng = tagdigger_amd.Engine(0)
 for kv in os.environ.get('TD_OPTS', '').split():      # e.g. TD_OPTS='kernel=1 table_load_pct=25'
     k, v = kv.split('='); eng.set_option(k, int(v))
+NBAR, NMARK = int(os.environ.get('TD_SWEEP_NBAR', '96')), int(os.environ.get('TD_SWEEP_NMARK', '5000'))     # (index shape: config 2's by default)
+LENS = [int(x) for x in os.environ.get('TD_SWEEP_LENS', '36 50 75 100 150 250').split()]
+print("index: %d barcodes x %d tags; options: %s" % (NBAR, 2 * NMARK, os.environ.get('TD_OPTS', '(default)')))
 for read_len, body in ((36, 20), (50, 30), (75, 45), (100, 59), (150, 59), (250, 59)):
+    if read_len not in LENS:
+        continue
     nreads = int(4e9 // (2 * read_len + 19))
-    cfg = SynthConfig(nreads=nreads, nbar=96, nmarkers=5000, seed=2, read_len=read_len, body=body)
+    cfg = SynthConfig(nreads=nreads, nbar=NBAR, nmarkers=NMARK, seed=2, read_len=read_len, body=body)
     nb = cfg.nbytes()
     d = eng.dev_alloc(nb)
     cfg.fill_device(eng, d, 0, nreads)
