@@ -136,7 +136,7 @@ def measure_traffic(args):
             for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as fh:
                     for row in csv.DictReader(fh):
-                        if row.get("Counter_Name") == counter and "k_fast2" in row.get("Kernel_Name", ""):
+                        if row.get("Counter_Name") == counter and ("k_fast4" in row.get("Kernel_Name", "") or "k_fast2" in row.get("Kernel_Name", "")):
                             vals.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
             if not vals:
                 return None
@@ -150,6 +150,14 @@ def measure_traffic(args):
             "what": "2 x FETCH_SIZE + WRITE_SIZE of the main pass, two rocprofv3 --pmc child runs of this script in this run "
                     "(gfx950 tallies a wide coalesced read stream at half its bytes: MI355X_MICROARCH.md, HBM); requests at the "
                     "L2's memory side, Infinity-Cache hits included: fabric traffic, an upper bound of the HBM bytes"}
+
+
+def main_kernel_name(args):
+    """The main pass the options select (td_set_option "kernel": 4 -- the default -- k_fast4, 2 k_fast2, 1 k_fast)."""
+    opts = dict(kv.split("=") for kv in (args.opt or []))
+    if int(opts.get("fastpath", "1")) == 0:
+        return "k_count"
+    return {4: "k_fast4", 2: "k_fast2", 1: "k_fast"}.get(int(opts.get("kernel", "4")), "k_fast4")
 
 
 def make_config(args, cid, reads=0):
@@ -428,7 +436,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["fabric_bytes_per_launch"] if traffic else None,
                          "traffic_kind": "fabric_bytes_per_launch", "traffic_detail": traffic,
-                         "kernel": "tdk::k_fast2 main pass + k_resolve + k_fast fix-up pass (HIP events around the three)", "kernel_ms": kms,
+                         "kernel": "tdk::%s main pass + k_resolve + k_fast fix-up pass (HIP events around the three)" % main_kernel_name(args), "kernel_ms": kms,
                          "kernel_ms_min": min(ktimes) if ktimes else None, "kernel_ms_max": max(ktimes) if ktimes else None,
                          "fixup_queue": R["fixups"], "kernel_launches": len(ktimes),
                          "algorithmic_bytes_per_launch": algo_bytes},
@@ -685,7 +693,7 @@ def cpu_baseline(cfg, sample_reads, python_reads=0):
 def tiers(eng, cfg, reads):
     """Tiers T2/T3 of SURVEY 8d on `reads` reads of the same stream and index -- inputs NOT resident in HBM:
     T2 host buffer -> pinned staging -> hipMemcpyAsync overlapped with counting; T3 from a file: plain,
-    ordinary gzip (chunk-parallel decode on the host, markers and CRC-32 on the GPU), BGZF (member-parallel inflate).  Each result is checked
+    ordinary gzip (decoded on the device; and as before: chunk-parallel decode on the host, markers and CRC-32 on the GPU), BGZF (member-parallel inflate).  Each result is checked
     against the generator's expected matrix.  Never the bench `value`."""
     import gzip
     import tempfile
@@ -733,8 +741,17 @@ def tiers(eng, cfg, reads):
         gzp = os.path.join(tmp, "tiers_lib.fq.gz")
         with open(gzp, "wb") as fh:
             fh.write(gzip_one_member(host, level=1, threads=16))
-        # DEFLATE is decoded into symbols by the host threads; markers -> bytes and the CRC-32 on the GPU (count_gzip_dev);
-        # "gpu_resolve" 0: all of it on the host, as in rounds 1-2
+        # the whole of it on the device (csrc/gz_gpu.hpp: block search, Huffman decoding, LZ77, windows, CRC-32: only the
+        # compressed bytes cross PCIe) ...
+        eng.count_file(gzp)                                             # (warm: the decoder's buffers)
+        r = timed(lambda: eng.count_file(gzp), reads, want)
+        r["reads"] = reads
+        r["gz_bytes"] = os.path.getsize(gzp)
+        r["decoded_on_device"] = bool(eng.last_gz_route() == 1)
+        out["T3_gzip_file_gpu_inflate"] = r
+        # ... DEFLATE decoded into symbols by the host threads, markers -> bytes and the CRC-32 on the GPU (count_gzip_dev:
+        # round 3's path, and the fallback of the one above); "gpu_resolve" 0: all of it on the host, as in rounds 1-2
+        eng.set_option("gpu_huffman", 0)
         eng.count_file(gzp)                                             # (warm: the decoder's pinned buffers)
         r = timed(lambda: eng.count_file(gzp), reads, want)
         r["reads"] = reads
@@ -743,6 +760,7 @@ def tiers(eng, cfg, reads):
         eng.set_option("gpu_resolve", 0)
         r = timed(lambda: eng.count_file(gzp), reads, want)
         eng.set_option("gpu_resolve", 1)
+        eng.set_option("gpu_huffman", 1)
         r["reads"] = reads
         out["T3_gzip_file_host_inflate"] = r
         os.unlink(gzp)

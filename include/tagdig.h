@@ -145,6 +145,16 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
  * can be tested where there is no GPU. */
 int td_gunzip_file(const char *path, void *dst, uint64_t capacity, uint64_t chunk, uint64_t *n_out);
 
+/* An ordinary (single-member) .gz file inflated ON THE DEVICE (csrc/gz_gpu.hpp: block search, Huffman decoding into
+ * tokens, LZ77 and the 32 KiB windows between chunks, CRC-32 and length check -- what td_count_file does with such a
+ * file before it counts), its text copied to host memory `dst`.  *on_gpu = 0 and *n_out = 0: the device decoder leaves
+ * this file to the host decoders (too small -- option "gz_gpu_min", default 8 MiB of compressed data -- several members,
+ * no room on the device, or a stream it does not chain); td_gunzip_file reads such a file.  TD_E_IO: the member fails its
+ * CRC-32 check.  Replaces gzip.open(fqfile, 'rt') of tagdigger_fun.py:240-241 for the test of that decoder alone. */
+int td_gunzip_file_gpu(td_handle *h, const char *path, void *dst, uint64_t capacity, uint64_t *n_out, int *on_gpu);
+/* 1: the .gz file td_count_file counted last was inflated by the device decoder; 0: by one of the others. */
+int td_last_gz_route(td_handle *h);
+
 /* What the reference's loop over gzip.open(path, 'rt'), left at read number max_reads (:272-273), meets in this
  * file (host only, no GPU): TD_OK -- it ends without an exception -- or TD_E_GZ_EOF / TD_E_GZ_BADFILE /
  * TD_E_GZ_DATA with the exception's message in td_last_error.  td_count_file, td_gunzip_file and td_split_file

@@ -1,0 +1,636 @@
+// Ordinary (single-stream) gzip decoded ON THE GPU: what the reference reads through gzip.open (tagdigger_fun.py:240-243).
+// The host threads of par_inflate.hpp bound that tier (16 cores decode ~3 GB/s of compressed data into symbols, and the
+// symbols are twice the size of the text on their way over PCIe); here only the compressed bytes go to the device:
+//   1. k_gz_find     one wave per territory of the compressed file (128 KiB): the first bit position where a block
+//                    starts that only a compressor would write -- non-final, dynamic Huffman, all three codes complete --
+//                    and that decodes to its end code and is followed by another plausible header.  64 positions a step:
+//                    a lane each for the header's fixed fields and the code-length code's Kraft sum; the few that pass are
+//                    looked at by the whole wave.
+//   2. k_gz_tokens   one wave per chunk (from one found start to the next): the Huffman decoding, SERIAL per stream and
+//                    therefore wave-uniform scalar code -- bit buffer, positions and table entries live in scalar registers,
+//                    the tables (10-bit literal/length, 8-bit distance, canonical arrays for longer codes) in 3.5 KiB of LDS
+//                    per wave, the lanes work together where there is something to share out (a block's tables, the
+//                    compressed bytes: 64 words a load, read by lane number; the tokens: staged in a register, stored 64 at a
+//                    time).  Output: TOKENS (a literal, or length + distance) -- the decoder never reads what it has decoded,
+//                    so no memory latency sits in its loop.  A chunk ends at the first block boundary at or past its
+//                    successor's start.
+//   3. the host chains the chunks (each must begin exactly where its predecessor ended: the result never depends on
+//      what step 1 found), and sums their sizes;
+//   4. k_gz_lz       one wave per chunk, 64 tokens at a time: positions by a wave scan, literals stored, copies made lane
+//                    by lane in rounds (a copy waits for the copies in front of it that it reads from); a copy that reaches
+//                    before its chunk gives MARKERS (0x8000 | position in the unknown 32 KiB before the chunk), as in
+//                    par_inflate.hpp.  Output: 16-bit symbols;
+//   5. k_gz_windows  one workgroup walks the chunks in order: every chunk's window = its predecessor's last 32 KiB with the
+//                    markers in them replaced from the predecessor's window;
+//   6. gz_resolve.hpp's k_gz_resolve / k_gz_crc turn symbols into bytes and take the CRC-32 (as for the host decoder's
+//      symbols), and the count kernels run over the bytes where they lie.
+// Anything unusual -- a second member, a chunk that does not chain, tables zlib would refuse, an overflowing token buffer --
+// sends the file to the host decoder (count_gzip_dev) before anything has been counted; a failed CRC or length check to the
+// reference's reading rules (gz_pyrules.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tdgz2 {
+
+constexpr int LROOT = 10, DROOT = 8, PROOT = 7;
+constexpr uint32_t WAVES = 4;                         // waves (streams) per workgroup
+constexpr uint32_t WINDOW = 32768;
+constexpr uint64_t NONE = ~0ull;
+
+// A table entry (32 bits): bits 0-3 the code's length (0: no code of this index -- E_NONE -- or a longer one -- E_SLOW);
+// bits 4-7 the number of extra bits; bits 8-23 the value: a literal's byte, a copy's base length, a distance's base;
+// F_COPY / F_END / F_BAD: a length symbol, the end-of-block symbol, a symbol DEFLATE does not define (286, 287; 30, 31)
+constexpr uint32_t E_NONE = 0u, E_SLOW = 0x10u, F_COPY = 1u << 24, F_END = 1u << 25, F_BAD = 1u << 26;
+struct __attribute__((aligned(16))) WaveMem {         // one wave's tables (LDS)
+    uint32_t ltab[1 << LROOT];                        // literal/length
+    uint32_t dtab[1 << DROOT];                        // distance (and the code-length code while a header is read)
+    uint16_t lsym[288], dsym[32];                     // symbols in canonical order (codes longer than the index)
+    uint16_t lcnt[16], dcnt[16];                      // codes per length
+    uint8_t lens[320];                                // code lengths: literal/length [0, 288), distance [288, 320)
+};
+
+struct Chunk {
+    uint64_t start_bit;       // where its first block header begins
+    uint64_t stop_bit;        // it ends at the first block boundary at or past this (its successor's start)
+    uint64_t tok_off;         // its tokens in the token buffer
+    uint32_t tok_cap, pad;
+};
+enum { S_NONE = 0, S_BOUNDARY = 1, S_FINAL = 2, S_ERR = 3, S_TOKCAP = 4, S_UNUSUAL = 5 };
+struct ChunkOut {
+    uint64_t end_bit;         // the bit behind its last block
+    uint64_t out_len;         // bytes it inflates to
+    uint32_t ntok, status;
+};
+
+// ---------------------------------------------------------------- the bit reader: wave-uniform state, the compressed bytes in
+// two registers (this lane's word of the current block of 64 words, and of the next)
+struct Bits {
+    const uint32_t *base;
+    uint64_t nwords;          // words that may be loaded (zero padding behind the file included)
+    uint64_t w0;              // the word wpos counts from (a multiple of 64)
+    uint32_t wpos;            // the next word to go into the bit buffer
+    uint32_t bc;
+    uint64_t bb;
+    uint32_t vin, vnext;
+};
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t bits_block(const Bits &b, uint32_t blk, int lane) {
+    const uint64_t i = b.w0 + (uint64_t)blk * 64u + (uint32_t)lane;
+    return i < b.nwords ? b.base[i] : 0u;
+}
+__device__ __forceinline__ void refill(Bits &b, int lane) {
+    if (b.bc <= 32u) {
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)b.vin, (int)(b.wpos & 63u));
+        b.bb |= (uint64_t)w << b.bc;
+        b.bc += 32u;
+        b.wpos++;
+        if (__builtin_expect((b.wpos & 63u) == 0u, 0)) {
+            b.vin = b.vnext;
+            b.vnext = bits_block(b, (b.wpos >> 6) + 1u, lane);
+        }
+    }
+}
+__device__ __forceinline__ void drop(Bits &b, uint32_t n) { b.bb >>= n; b.bc -= n; }
+__device__ __forceinline__ uint32_t take(Bits &b, uint32_t n) {
+    const uint32_t v = (uint32_t)b.bb & ((1u << n) - 1u);
+    drop(b, n);
+    return v;
+}
+__device__ __forceinline__ uint64_t bitpos(const Bits &b) { return (b.w0 + b.wpos) * 32u - b.bc; }
+__device__ __forceinline__ void bits_init(Bits &b, uint64_t pos, int lane) {
+    b.w0 = (pos >> 5) & ~(uint64_t)63;
+    b.wpos = (uint32_t)(pos >> 5) & 63u;
+    b.vin = bits_block(b, 0u, lane);
+    b.vnext = bits_block(b, 1u, lane);
+    b.bb = 0; b.bc = 0;
+    refill(b, lane);
+    drop(b, (uint32_t)pos & 31u);
+    refill(b, lane);
+}
+
+// ---------------------------------------------------------------- canonical Huffman tables from n code lengths in LDS (n <= 320),
+// built by the wave: tab[1 << root], sym[] (symbols in canonical order), cnt[16].  Returns 0 for a complete code, 1 for an
+// incomplete one (ncodes, maxlen say how incomplete), -1 for an over-subscribed one.
+// length and distance of a copy from their symbols: base value and number of extra bits (RFC 1951 3.2.5, by formula)
+__device__ __forceinline__ void length_code(uint32_t sy, uint32_t &base, uint32_t &ext) {
+    const uint32_t li = sy - 257u;
+    ext = li < 8u ? 0u : (li - 4u) >> 2;
+    base = li < 8u ? li + 3u : ((4u + (li & 3u)) << ext) + 3u;
+    if (li == 28u) { ext = 0; base = 258u; }
+}
+__device__ __forceinline__ void distance_code(uint32_t ds, uint32_t &base, uint32_t &ext) {
+    ext = ds < 4u ? 0u : (ds - 2u) >> 1;
+    base = ds < 4u ? ds + 1u : ((2u + (ds & 1u)) << ext) + 1u;
+}
+// what a table says about symbol i (without the code's length): KIND 0 literal/length, 1 distance, 2 the code-length code
+template <int KIND> __device__ __forceinline__ uint32_t entry_of(uint32_t i) {
+    if (KIND == 2) return i << 8;
+    if (KIND == 1) {
+        if (i > 29u) return F_BAD;
+        uint32_t base, ext;
+        distance_code(i, base, ext);
+        return (base << 8) | (ext << 4);
+    }
+    if (i < 256u) return i << 8;
+    if (i == 256u) return F_END;
+    if (i > 285u) return F_BAD;
+    uint32_t base, ext;
+    length_code(i, base, ext);
+    return F_COPY | (base << 8) | (ext << 4);
+}
+template <int KIND>
+__device__ __forceinline__ int build(const uint8_t *lens, uint32_t n, uint32_t *tab, uint32_t root, uint16_t *sym, uint16_t *cnt, int lane,
+                                     uint32_t &ncodes, uint32_t &maxlen) {
+    uint32_t c[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) c[l] = 0;
+    for (uint32_t base = 0; base < n; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        const uint32_t li = i < n ? lens[i] : 0u;
+#pragma unroll
+        for (int l = 1; l < 16; l++) c[l] += (uint32_t)__builtin_popcountll(__ballot(li == (uint32_t)l));
+    }
+    int left = 1;
+    ncodes = 0; maxlen = 0;
+    bool over = false;
+#pragma unroll
+    for (int l = 1; l < 16; l++) {
+        left = 2 * left - (int)c[l];
+        over |= left < 0;
+        ncodes += c[l];
+        if (c[l]) maxlen = (uint32_t)l;
+    }
+    if (over) return -1;
+    for (uint32_t k = (uint32_t)lane; k < (1u << root); k += 64u) tab[k] = E_NONE;
+#pragma unroll
+    for (int l = 0; l < 16; l++) cnt[l] = (uint16_t)c[l];              // (every lane the same value)
+    uint32_t nc[16], of[16];
+    nc[1] = 0; of[1] = 0;
+#pragma unroll
+    for (int l = 1; l < 15; l++) { nc[l + 1] = (nc[l] + c[l]) << 1; of[l + 1] = of[l] + c[l]; }
+    for (uint32_t base = 0; base < n; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        const uint32_t li = i < n ? lens[i] : 0u;
+        uint32_t mycode = 0, mypos = 0;
+#pragma unroll
+        for (int l = 1; l < 16; l++) {
+            const uint64_t m = __ballot(li == (uint32_t)l);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (li == (uint32_t)l) { mycode = nc[l] + below; mypos = of[l] + below; }
+            const uint32_t k = (uint32_t)__builtin_popcountll(m);
+            nc[l] += k; of[l] += k;
+        }
+        if (li) {
+            sym[mypos] = (uint16_t)i;
+            const uint32_t rv = __builtin_bitreverse32(mycode) >> (32u - li);
+            if (li <= root) {
+                const uint32_t e = entry_of<KIND>(i) | li;
+                for (uint32_t k = rv; k < (1u << root); k += 1u << li) tab[k] = e;
+            } else {
+                tab[rv & ((1u << root) - 1u)] = E_SLOW;
+            }
+        }
+    }
+    return left == 0 ? 0 : 1;
+}
+
+// a symbol whose code is longer than the table's index: bit by bit against the canonical arrays (RFC 1951 3.2.2); the
+// code's bits are dropped; returns its entry (length bits 0) or E_NONE
+template <int KIND>
+__device__ __forceinline__ uint32_t slow_entry(Bits &b, const uint16_t *sym, const uint16_t *cnt) {
+    uint32_t code = 0, first = 0, index = 0;
+    for (uint32_t l = 1; l < 16; l++) {
+        code |= (uint32_t)(b.bb >> (l - 1u)) & 1u;
+        const uint32_t c = rfl(cnt[l]);
+        if (code < first + c) { drop(b, l); return entry_of<KIND>(rfl(sym[index + (code - first)])) | 1u; }
+        index += c; first += c;
+        first <<= 1; code <<= 1;
+    }
+    return E_NONE;
+}
+// the next symbol's entry, its code's bits dropped (at least 15 bits are in the buffer); E_NONE: no such code
+template <int KIND>
+__device__ __forceinline__ uint32_t next_entry(Bits &b, const uint32_t *tab, uint32_t root, const uint16_t *sym, const uint16_t *cnt) {
+    const uint32_t e = rfl(tab[(uint32_t)b.bb & ((1u << root) - 1u)]);
+    if (__builtin_expect((e & 15u) == 0u, 0)) return e == E_SLOW ? slow_entry<KIND>(b, sym, cnt) : E_NONE;
+    drop(b, e & 15u);
+    return e;
+}
+
+__constant__ const uint8_t PRECODE_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// One block header.  Returns 2: Huffman tables built; 0: a stored block (`stored` bytes follow at the byte boundary the
+// reader stands on); -1: invalid (what zlib refuses); -2: valid for zlib perhaps, but not decoded here (an incomplete
+// literal/length code).  strict (the block search): a dynamic block with all three codes complete, or -1.
+__device__ __attribute__((noinline)) int read_header_impl(Bits &b, WaveMem &m, bool strict, uint32_t &final, uint32_t &stored, int lane) {
+    refill(b, lane);
+    final = take(b, 1);
+    const uint32_t type = take(b, 2);
+    if (type == 3u) return -1;
+    if (strict && (type != 2u || final)) return -1;
+    if (type == 0u) {
+        drop(b, b.bc & 7u);
+        refill(b, lane);
+        const uint32_t len = take(b, 16);
+        refill(b, lane);
+        const uint32_t nlen = take(b, 16);
+        if ((len ^ nlen) != 0xFFFFu) return -1;
+        stored = len;
+        return 0;
+    }
+    uint32_t nlit = 288, ndist = 30;
+    if (type == 1u) {
+        for (uint32_t i = (uint32_t)lane; i < 320u; i += 64u)
+            m.lens[i] = (uint8_t)(i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : i < 288u ? 8 : i < 318u ? 5 : 0);
+    } else {
+        nlit = take(b, 5) + 257u; ndist = take(b, 5) + 1u;
+        const uint32_t ncl = take(b, 4) + 4u;
+        if (nlit > 286u || ndist > 30u) return -1;
+        uint8_t *pl = reinterpret_cast<uint8_t *>(m.lsym);              // the code-length code's lengths (19)
+        if (lane < 19) pl[lane] = 0;
+        for (uint32_t i = 0; i < ncl; i++) {
+            refill(b, lane);
+            pl[PRECODE_ORDER[i]] = (uint8_t)take(b, 3);
+        }
+        uint32_t pn, pmax;
+        if (build<2>(pl, 19, m.dtab, PROOT, m.dsym, m.dcnt, lane, pn, pmax) != 0) return -1;   // (zlib: must be complete)
+        const uint32_t total = nlit + ndist;
+        uint32_t i = 0, prev = 0;
+        while (i < total) {
+            refill(b, lane);
+            const uint32_t ce = next_entry<2>(b, m.dtab, PROOT, m.dsym, m.dcnt);
+            if (ce == E_NONE) return -1;
+            const int c = (int)(ce >> 8);
+            if (c < 16) { m.lens[i++] = (uint8_t)c; prev = (uint32_t)c; continue; }
+            uint32_t val = 0, rep;
+            if (c == 16) { if (i == 0) return -1; val = prev; rep = 3u + take(b, 2); }
+            else if (c == 17) { rep = 3u + take(b, 3); }
+            else { rep = 11u + take(b, 7); }
+            if (i + rep > total) return -1;
+            for (uint32_t k = (uint32_t)lane; k < rep; k += 64u) m.lens[i + k] = (uint8_t)val;
+            i += rep; prev = val;
+        }
+        // the distance lengths follow the literal/length ones: to their place (one instruction reads them all, the next writes)
+        const uint32_t dl = (uint32_t)lane < ndist ? m.lens[nlit + (uint32_t)lane] : 0u;
+        if (lane < 32) m.lens[288 + lane] = (uint8_t)dl;
+        for (uint32_t k = nlit + (uint32_t)lane; k < 288u; k += 64u) m.lens[k] = 0;
+        if (rfl(m.lens[256]) == 0u) return -1;                           // no end-of-block code
+    }
+    uint32_t ln, lmax, dn, dmax;
+    const int rl = build<0>(m.lens, 288, m.ltab, LROOT, m.lsym, m.lcnt, lane, ln, lmax);
+    const int rd = build<1>(m.lens + 288, 32, m.dtab, DROOT, m.dsym, m.dcnt, lane, dn, dmax);
+    if (rl < 0 || rd < 0) return -1;
+    if (strict) return rl == 0 && rd == 0 ? 2 : -1;
+    if (rl == 1) return lmax == 1u ? -2 : -1;                            // (zlib allows an incomplete code of one 1-bit symbol only)
+    if (rd == 1 && type == 2u && !(dn == 0u || dmax == 1u)) return -1;   // (... the fixed block's 30 of 32 five-bit codes are its own)
+    return 2;
+}
+
+// (a real call, once a block: the decoding loop's registers are not the header's -- and the reader goes in and out by value,
+// so that it never lives in memory)
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v); }
+__device__ __forceinline__ int read_header(Bits &b, WaveMem &m, bool strict, uint32_t &final, uint32_t &stored, int lane) {
+    Bits t = b;
+    uint32_t f = 0, st = 0;
+    const int r = read_header_impl(t, m, strict, f, st, lane);
+    b.w0 = rfl64(t.w0); b.wpos = rfl(t.wpos); b.bc = rfl(t.bc); b.bb = rfl64(t.bb);
+    b.vin = t.vin; b.vnext = t.vnext;
+    final = rfl(f); stored = rfl(st);
+    return (int)rfl((uint32_t)r);
+}
+
+// ---------------------------------------------------------------- a block's symbols, 64 bit positions at a time
+// A Huffman stream is serial -- where a code starts is known only when the one before it has been read -- but WHAT would
+// start at a given bit is not: every lane decodes the token that would begin at its bit of the next 64 (a literal, the end
+// code, or length + extra bits + distance + extra bits: two table look-ups, all 64 lanes' at once), and the wave then only
+// follows the chain from the first bit -- token and size by lane number out of two registers, no table, no memory.  What a
+// look-up cannot settle (a code longer than the table's index) is decoded by the scalar code when the chain comes to it.
+// pos: in, the bit behind the block's header; out, the bit behind its end code.  emit(token) -> false stops the decoding
+// (the caller's status says why).  Returns S_NONE at the end code, S_ERR for invalid data, or the caller's stop.
+template <class F>
+__device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, uint64_t in_bits, const WaveMem &m, int lane, F &&emit) {
+    Bits t = rd;
+    t.w0 = (pos >> 5) & ~(uint64_t)63;
+    uint32_t cur = (uint32_t)(pos - (t.w0 << 5));
+    uint32_t vin = bits_block(t, 0u, lane), vnext = bits_block(t, 1u, lane);
+    for (;;) {
+        if (cur >= 2048u) {
+            t.w0 += 64u; cur -= 2048u;
+            vin = vnext; vnext = bits_block(t, 1u, lane);
+        }
+        if ((t.w0 << 5) + cur > in_bits) return S_ERR;
+        const uint32_t k0 = cur >> 5, off = cur & 31u;
+        uint32_t W[5];
+#pragma unroll
+        for (uint32_t i = 0; i < 5u; i++) {
+            const uint32_t k = k0 + i;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)(k & 63u)), c = (uint32_t)__builtin_amdgcn_readlane((int)vnext, (int)(k & 63u));
+            W[i] = k < 64u ? a : c;
+        }
+        // this lane's 64 bits from its position on
+        const uint32_t bp = off + (uint32_t)lane, q = bp >> 5, r = bp & 31u;
+        const uint32_t lo = q == 0u ? W[0] : q == 1u ? W[1] : W[2], mid = q == 0u ? W[1] : q == 1u ? W[2] : W[3], hi = q == 0u ? W[2] : q == 1u ? W[3] : W[4];
+        uint64_t x = ((((uint64_t)mid << 32) | lo) >> r) | (((uint64_t)hi << 1) << (63u - r));
+        const uint32_t e = m.ltab[(uint32_t)x & ((1u << LROOT) - 1u)];
+        const uint32_t l1 = e & 15u, ext = (e >> 4) & 15u;
+        x >>= l1;
+        const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)x & ((1u << ext) - 1u));
+        x >>= ext;
+        const uint32_t d = m.dtab[(uint32_t)x & ((1u << DROOT) - 1u)];
+        const uint32_t l2 = d & 15u, dext = (d >> 4) & 15u;
+        x >>= l2;
+        const uint32_t dist = ((d >> 8) & 0xFFFFu) + ((uint32_t)x & ((1u << dext) - 1u));
+        const bool copy = (e & F_COPY) != 0;
+        // kind: 0 literal, 1 copy, 2 end code, 3 for the scalar code (a longer code, or none)
+        const bool rare = l1 == 0u || (e & F_BAD) || (copy && (l2 == 0u || (d & F_BAD)));
+        const uint32_t kind = rare ? 3u : (e & F_END) ? 2u : copy ? 1u : 0u;
+        const uint32_t vtok = copy ? 0x80000000u | (len << 15) | (dist - 1u) : (e >> 8) & 0xFFu;
+        const uint32_t vinfo = (copy ? l1 + ext + l2 + dext : l1) | (kind << 8);
+        // the chain from bit 0
+        uint32_t o = 0;
+        while (o < 64u) {
+            uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)vinfo, (int)o);
+            uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)vtok, (int)o);
+            if (__builtin_expect((info >> 8) == 3u, 0)) {
+                // the scalar decoder on this one token: 64 bits from its position are enough (15 + 5 + 15 + 13)
+                const uint32_t sb = off + o, sq = sb >> 5, sr = sb & 31u;
+                const uint32_t slo = sq == 0u ? W[0] : sq == 1u ? W[1] : W[2], smid = sq == 0u ? W[1] : sq == 1u ? W[2] : W[3],
+                               shi = sq == 0u ? W[2] : sq == 1u ? W[3] : W[4];
+                Bits sbits = t;
+                sbits.bb = ((((uint64_t)smid << 32) | slo) >> sr) | (((uint64_t)shi << 1) << (63u - sr));
+                sbits.bc = 64u;
+                const uint32_t se = next_entry<0>(sbits, m.ltab, LROOT, m.lsym, m.lcnt);
+                if (se == E_NONE || (se & F_BAD)) return S_ERR;
+                if (se & F_END) { info = (64u - sbits.bc) | (2u << 8); }
+                else if (!(se & F_COPY)) { tk = (se >> 8) & 0xFFu; info = 64u - sbits.bc; }
+                else {
+                    const uint32_t slen = ((se >> 8) & 0xFFFFu) + take(sbits, (se >> 4) & 15u);
+                    const uint32_t sd = next_entry<1>(sbits, m.dtab, DROOT, m.dsym, m.dcnt);
+                    if (sd == E_NONE || (sd & F_BAD)) return S_ERR;
+                    const uint32_t sdist = ((sd >> 8) & 0xFFFFu) + take(sbits, (sd >> 4) & 15u);
+                    tk = 0x80000000u | (slen << 15) | (sdist - 1u);
+                    info = (64u - sbits.bc) | (1u << 8);
+                }
+            }
+            if ((info >> 8) == 2u) {
+                pos = (t.w0 << 5) + cur + o + (info & 0xFFu);
+                return S_NONE;
+            }
+            if (!emit(tk)) return S_TOKCAP;
+            o += info & 0xFFu;
+        }
+        cur += o;
+    }
+}
+
+// ---------------------------------------------------------------- 1. the block search
+// found[t] (t >= 1): the first block start in territory t, or NONE
+__global__ __launch_bounds__(64 * WAVES) void k_gz_find(const uint8_t *in, uint64_t in_bits, uint64_t nwords, uint64_t first_bit,
+                                                        uint64_t terr_bits, uint32_t nterr, uint64_t *found) {
+    __shared__ WaveMem mem[WAVES];
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    const uint32_t t = blockIdx.x * WAVES + wave + 1u;
+    if (t >= nterr) return;
+    WaveMem &m = mem[wave];
+    uint64_t lo = (uint64_t)t * terr_bits;
+    const uint64_t hi = lo + terr_bits < in_bits ? lo + terr_bits : in_bits;
+    if (lo <= first_bit) lo = first_bit + 1u;
+    uint64_t result = NONE;
+    Bits b;
+    b.base = reinterpret_cast<const uint32_t *>(in); b.nwords = nwords;
+    for (uint64_t p0 = lo; p0 < hi && result == NONE; p0 += 64u) {
+        const uint64_t p = p0 + (uint32_t)lane;
+        // the header's fixed fields and the code-length code's lengths: 17 + 3 x 19 bits from p
+        uint64_t w0, w1;
+        __builtin_memcpy(&w0, in + (p >> 3), 8);
+        __builtin_memcpy(&w1, in + (p >> 3) + 8, 8);
+        const uint32_t sh = (uint32_t)p & 7u;
+        const uint64_t x0 = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0, x1 = w1 >> sh;
+        bool cand = p < hi && ((uint32_t)x0 & 7u) == 4u && (((uint32_t)x0 >> 3) & 31u) <= 29u && (((uint32_t)x0 >> 8) & 31u) <= 29u;
+        if (cand) {
+            const uint32_t ncl = (((uint32_t)x0 >> 13) & 15u) + 4u;
+            const uint64_t y = (x0 >> 17) | (x1 << 47);
+            uint32_t kraft = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 19u; i++) {
+                const uint32_t l = (uint32_t)(y >> (3u * i)) & 7u;
+                kraft += i < ncl && l ? 128u >> l : 0u;
+            }
+            cand = kraft == 128u;
+        }
+        uint64_t mask = __ballot(cand);
+        while (mask) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1u;
+            const uint64_t pc = p0 + l;
+            // the whole wave on this position: the header, the block to its end code, the header behind it
+            bits_init(b, pc, lane);
+            uint32_t final, stored;
+            if (read_header(b, m, true, final, stored, lane) != 2) continue;
+            uint64_t at = bitpos(b);
+            uint32_t nsym = 0;
+            const uint32_t dr = decode_block(b, at, in_bits, m, lane, [&](uint32_t) { return ++nsym < (1u << 21); });
+            if (dr != S_NONE || at + 3u > in_bits) continue;
+            bits_init(b, at, lane);
+            // what follows must read as a header as well
+            refill(b, lane);
+            const uint32_t nx = (uint32_t)b.bb;
+            const uint32_t ntype = (nx >> 1) & 3u;
+            if (ntype == 3u) continue;
+            if (ntype == 0u) {
+                drop(b, 3);
+                drop(b, b.bc & 7u);
+                refill(b, lane);
+                const uint32_t len = take(b, 16);
+                refill(b, lane);
+                const uint32_t nlen = take(b, 16);
+                if ((len ^ nlen) != 0xFFFFu) continue;
+            } else if (ntype == 2u) {
+                if (((nx >> 3) & 31u) > 29u || ((nx >> 8) & 31u) > 29u) continue;
+            }
+            result = pc;
+            break;
+        }
+    }
+    if (lane == 0) found[t] = result;
+}
+
+// ---------------------------------------------------------------- 2. Huffman decoding into tokens
+// a token: a literal (its byte), or 0x80000000 | length << 15 | (distance - 1)
+__global__ __launch_bounds__(64 * WAVES) void k_gz_tokens(const uint8_t *in, uint64_t in_bits, uint64_t nwords, const Chunk *chunks, uint32_t nchunks,
+                                                          uint32_t *tok, ChunkOut *out) {
+    __shared__ WaveMem mem[WAVES];
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    const uint32_t ci = blockIdx.x * WAVES + wave;
+    if (ci >= nchunks) return;
+    WaveMem &m = mem[wave];
+    const uint64_t start = chunks[ci].start_bit, stop = chunks[ci].stop_bit;
+    uint32_t *tk = tok + chunks[ci].tok_off;
+    const uint32_t cap = chunks[ci].tok_cap;
+    Bits b;
+    b.base = reinterpret_cast<const uint32_t *>(in); b.nwords = nwords;
+    bits_init(b, start, lane);
+    uint32_t ntok = 0, glo = 0, tokv = 0, status = S_NONE;
+    uint64_t out_len = 0, end_bit = 0;
+    // the staged tokens [glo, hi) of the current group of 64 to memory
+    auto flush = [&](uint32_t hi) {
+        const uint32_t g0 = (ntok - 1u) & ~63u;                        // (called with ntok > 0 behind the group's last token)
+        if ((uint32_t)lane >= glo && (uint32_t)lane < hi) tk[g0 + (uint32_t)lane] = tokv;
+    };
+    // (every 64 tokens: room for 64 more, and the input not overrun -- zeros are read behind it)
+    auto emit = [&](uint32_t t) {
+        tokv = (uint32_t)lane == (ntok & 63u) ? t : tokv;
+        ntok++;
+        if (__builtin_expect((ntok & 63u) == 0u, 0)) {
+            flush(64u); glo = 0;
+            if (ntok + 128u > cap) status = S_TOKCAP;
+            else if (bitpos(b) > in_bits) status = S_ERR;
+        }
+    };
+    for (;;) {
+        const uint64_t pos = bitpos(b);
+        if (pos >= stop) { status = S_BOUNDARY; end_bit = pos; break; }
+        if (pos + 3u > in_bits) { status = S_ERR; break; }
+        uint32_t final = 0, stored = 0;
+        const int h = read_header(b, m, false, final, stored, lane);
+        if (h < 0) { status = h == -2 ? S_UNUSUAL : S_ERR; break; }
+        if (h == 0) {
+            // a stored block: its bytes are literals (64 a step); the reader starts again behind them
+            const uint64_t at = bitpos(b) >> 3;
+            if ((at + stored) * 8u > in_bits) { status = S_ERR; break; }
+            if ((uint64_t)ntok + stored + 192u > cap) { status = S_TOKCAP; break; }
+            if ((ntok & 63u) > glo) flush(ntok & 63u);
+            for (uint32_t i = (uint32_t)lane; i < stored; i += 64u) tk[ntok + i] = in[at + i];
+            ntok += stored; out_len += stored;
+            glo = ntok & 63u;
+            bits_init(b, (at + stored) * 8u, lane);
+        } else {
+            uint64_t at = bitpos(b);
+            const uint32_t dr = decode_block(b, at, in_bits, m, lane, [&](uint32_t t) {
+                emit(t);
+                out_len += t >> 31 ? (t >> 15) & 0x1FFu : 1u;
+                return status == S_NONE;
+            });
+            if (dr != S_NONE && status == S_NONE) status = dr;
+            if (status == S_NONE) bits_init(b, at, lane);
+            if (status != S_NONE) break;
+        }
+        if (final) { status = S_FINAL; end_bit = bitpos(b); break; }
+    }
+    if ((ntok & 63u) > glo) flush(ntok & 63u);
+    if (lane == 0) {
+        ChunkOut o;
+        o.end_bit = end_bit; o.out_len = out_len; o.ntok = ntok; o.status = status;
+        out[ci] = o;
+    }
+}
+
+// ---------------------------------------------------------------- 4. tokens -> 16-bit symbols
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+__global__ __launch_bounds__(64 * WAVES) void k_gz_lz(const uint32_t *tok, const Chunk *chunks, const ChunkOut *res, const uint64_t *sym_off,
+                                                      uint32_t nchunks, uint16_t *sym) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    const uint32_t ci = blockIdx.x * WAVES + wave;
+    if (ci >= nchunks) return;
+    const uint32_t ntok = res[ci].ntok;
+    const uint32_t *tk = tok + chunks[ci].tok_off;
+    uint16_t *out = sym + sym_off[ci];
+    int64_t base = 0;
+    for (uint32_t g = 0; g < ntok; g += 64u) {
+        const bool valid = g + (uint32_t)lane < ntok;
+        const uint32_t t = valid ? tk[g + (uint32_t)lane] : 0u;
+        const bool match = valid && (t >> 31);
+        const uint32_t L = match ? (t >> 15) & 0x1FFu : (valid ? 1u : 0u);
+        const uint32_t dist = (t & 0x7FFFu) + 1u;
+        const uint32_t incl = wave_scan_incl(L, lane);
+        const int64_t pos = base + (int64_t)(incl - L);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (valid && !match) out[pos] = (uint16_t)t;
+        const int64_t src = pos - (int64_t)dist;
+        const uint32_t need = L < dist ? L : dist;
+        bool pending = match;
+        wave_mem_fence();
+        for (;;) {
+            const uint64_t pm = __ballot(pending);
+            if (!pm) break;
+            // everything in front of the first pending copy's destination is in place
+            const int first = (int)__builtin_ctzll(pm);
+            const uint32_t flo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)pos, first);
+            const uint32_t fhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)pos >> 32), first);
+            const int64_t F = (int64_t)(((uint64_t)fhi << 32) | flo);
+            const bool ready = pending && src + (int64_t)need <= F;
+            if (ready) {
+                // every symbol comes from [src, src + min(L, dist)), all of it in front of this copy: eight loads, then eight
+                // stores (a load that had to wait for the store before it would take a memory round trip per symbol)
+                uint32_t k = 0;
+                for (uint32_t j = 0; j < L; j += 8u) {
+                    uint16_t v[8];
+#pragma unroll
+                    for (uint32_t i = 0; i < 8u; i++) {
+                        const int64_t s = src + (int64_t)k;
+                        v[i] = j + i >= L ? (uint16_t)0 : s < 0 ? (uint16_t)(0x8000u | (uint32_t)((int64_t)WINDOW + s)) : out[s];
+                        if (++k == dist) k = 0;
+                    }
+#pragma unroll
+                    for (uint32_t i = 0; i < 8u; i++)
+                        if (j + i < L) out[pos + (int64_t)(j + i)] = v[i];
+                }
+            }
+            wave_mem_fence();
+            pending = pending && !ready;
+        }
+        base += total;
+    }
+}
+
+// ---------------------------------------------------------------- 5. the chunks' windows, in order
+// d_win + 32768 c: chunk c's window (what its markers point into); carry: in, the window of the first chunk; out, the window
+// behind the last.  first_len: chunk c's symbols are sym[sym_off[c] .. + out_len[c])
+__global__ __launch_bounds__(1024) void k_gz_windows(const uint16_t *sym, const uint64_t *sym_off, const ChunkOut *res, uint32_t nchunks,
+                                                     uint8_t *d_win, uint8_t *carry) {
+    __shared__ uint8_t W[2][WINDOW];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t p = tid * 16u; p < WINDOW; p += 1024u * 16u)
+        *reinterpret_cast<uint4 *>(&W[0][p]) = *reinterpret_cast<const uint4 *>(carry + p);
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t c = 0; c < nchunks; c++) {
+        const uint64_t n = res[c].out_len;
+        const uint16_t *s = sym + sym_off[c];
+        uint8_t *wout = d_win + (size_t)c * WINDOW;
+        for (uint32_t p = tid * 16u; p < WINDOW; p += 1024u * 16u)
+            *reinterpret_cast<uint4 *>(wout + p) = *reinterpret_cast<const uint4 *>(&W[cur][p]);
+        // the window behind this chunk: its last 32 KiB (or less, behind what is left of the window before it)
+        uint16_t v[WINDOW / 1024];
+#pragma unroll
+        for (uint32_t i = 0; i < WINDOW / 1024u; i++) {
+            const uint32_t p = tid + 1024u * i;
+            const int64_t o = (int64_t)n - (int64_t)WINDOW + (int64_t)p;
+            v[i] = o >= 0 ? s[o] : (uint16_t)(0x8000u | (uint32_t)((int64_t)p + (int64_t)n));      // (p + n < 32768: a place in the old window)
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < WINDOW / 1024u; i++) {
+            const uint32_t p = tid + 1024u * i;
+            W[cur ^ 1u][p] = (v[i] & 0x8000u) ? W[cur][v[i] & 0x7FFFu] : (uint8_t)v[i];
+        }
+        __syncthreads();
+        cur ^= 1u;
+    }
+    for (uint32_t p = tid * 16u; p < WINDOW; p += 1024u * 16u)
+        *reinterpret_cast<uint4 *>(carry + p) = *reinterpret_cast<const uint4 *>(&W[cur][p]);
+}
+
+}  // namespace tdgz2

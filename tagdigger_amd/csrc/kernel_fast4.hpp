@@ -552,12 +552,13 @@ __global__ __launch_bounds__(F4_BLOCK, F4_WAVES / 4) void k_fast4(const FParams 
         // kres: 0 no barcode, 2 barcode only, 1 the tag is to be looked up, 6 leading blank (rare: raw bytes re-read)
         st_reads += kres == 0u || kres == 2u ? 1 : 0;
         st_bar += kres == 2u ? 1 : 0;
-        if (PROG) sums_add(kres == 1u || kres == 2u, my_tile, 1u);
         F4_STAMP(7);
         // the lines that have been pending since the pass before: their buckets were asked for a whole line_prepare ago -- then
         // this pass's buckets, which stay in flight
         settle();
         F4_STAMP(5);
+        // (behind the wait for the pending lines' buckets, not in front of it: the adds' round trips run under the next pass)
+        if (PROG) sums_add(kres == 1u || kres == 2u, my_tile, 1u);
         // (rare: a line that opens with a blank -- str.strip, reference :256 -- is matched from its raw bytes in global memory;
         // here, where no bucket is in flight and the pending registers are free)
         if (__builtin_expect(__any(kres == 6u), 0)) {

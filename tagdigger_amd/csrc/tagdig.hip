@@ -32,6 +32,7 @@
 #include "gz_pyrules.hpp"
 #include "gpu_inflate.hpp"
 #include "gz_resolve.hpp"
+#include "gz_gpu.hpp"
 
 namespace {
 
@@ -218,6 +219,15 @@ struct td_handle {
                    tdgz::Block *pin_blk = nullptr; uint32_t *pin_crc = nullptr; uint8_t *pin_tail = nullptr; size_t pin_cap = 0; hipEvent_t done = nullptr;
                    hipEvent_t copied = nullptr; } gslot[2];
     DevBuf<uint32_t> d_gzflag;
+    // ordinary gzip decoded on the GPU (count_gzip_gpu, gz_gpu.hpp): the whole file's buffers, kept between files
+    struct GzGpu { DevBuf<uint8_t> d_in, d_out, d_win, d_carry; DevBuf<uint32_t> d_tok, d_crc; DevBuf<uint16_t> d_sym; DevBuf<tdgz2::Chunk> d_chunks;
+                   DevBuf<tdgz2::ChunkOut> d_res; DevBuf<uint64_t> d_found, d_symoff; DevBuf<tdgz::Block> d_blk;
+                   void release() { d_in.release(); d_out.release(); d_win.release(); d_carry.release(); d_tok.release(); d_crc.release(); d_sym.release();
+                                    d_chunks.release(); d_res.release(); d_found.release(); d_symoff.release(); d_blk.release(); } } gzgpu;
+    int last_gz_route = 0;                    // how the last .gz file was decoded: 1 Huffman + LZ77 on the GPU, 0 otherwise
+    int gpu_huffman = 1;                      // ordinary gzip: Huffman decoding on the GPU too (0: host threads decode, the GPU resolves)
+    uint64_t gz_gpu_min = (uint64_t)8 << 20;  // ... for files of this many compressed bytes and more
+    uint32_t gz_gpu_terr_kb = 128;            // ... one chunk per this much compressed data
     int gpu_resolve = 1;                      // ordinary gzip of 8 MiB and more: markers -> bytes and CRC-32 on the GPU (0: all on the host)
     uint8_t *d_zscratch = nullptr; uint32_t *d_crctab = nullptr;
     uint32_t zcap_members = 0; size_t zcap_in = 0;   // what the batch buffers above were allocated for
@@ -721,6 +731,7 @@ void td_destroy(td_handle *h) {
         if (g.done) (void)hipEventDestroy(g.done);
     }
     h->d_gzflag.release();
+    h->gzgpu.release();
     if (h->d_crctab) (void)hipFree(h->d_crctab);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     for (auto &st : h->side_copy) if (st) (void)hipStreamDestroy(st);
@@ -1450,7 +1461,6 @@ int count_gzip_dev(td_handle *h, const char *path, uint64_t max_reads, int weigh
     return TD_OK;
 }
 
-// ---- a .gz input one of the decoders has refused: what does the reference do with it?  (gz_pyrules.hpp)
 struct MappedFile {
     const uint8_t *p = nullptr; size_t n = 0; bool ok = false;
     explicit MappedFile(const char *path) {
@@ -1470,6 +1480,192 @@ struct MappedFile {
     MappedFile(const MappedFile &) = delete;
     MappedFile &operator=(const MappedFile &) = delete;
 };
+
+// ---- ordinary gzip decoded on the GPU (gz_gpu.hpp): the compressed file goes to the device as it is; block starts are
+// searched, the chunks between them Huffman-decoded into tokens, chained here, turned into symbols and bytes, checked
+// against the member's CRC-32 and length, and counted where they lie.  *not_applicable: nothing has been counted and the
+// host decoder (count_gzip_dev) should take the file -- too small, no room on the device, a second member, or a stream this
+// decoder does not chain.
+extern "C" int td_load_file_range(td_handle *h, const char *path, uint64_t offset, uint64_t length, void *d_dst);
+// the file's text in h->gzgpu.d_out (*total bytes), checked
+int gz_gpu_inflate(td_handle *h, const char *path, uint64_t *total_out, bool *not_applicable) {
+    using FI = tdhost::FastInflate;
+    using PI = tdhost::ParInflate;
+    *not_applicable = true;
+    const bool verbose = getenv("TAGDIG_INFLATE_STATS") != nullptr;
+    auto skip = [&](const char *why) { if (verbose) fprintf(stderr, "gz_gpu_inflate: %s -- the host decoder takes the file\n", why); return TD_OK; };
+    MappedFile mf(path);
+    if (!mf.ok || mf.n < h->gz_gpu_min || mf.n < 64) return skip("small file");
+    const uint8_t *body = nullptr; const char *herr = nullptr;
+    if (FI::parse_member_header(mf.p, mf.p + mf.n, &body, &herr, true) != 1) return skip("no gzip header");
+    if (mf.n >= ((uint64_t)1 << 40)) return skip("file too large");
+    { uint32_t bs = 0, hs = 0; if (tdhost::GzSource::bgzf_header(mf.p, mf.n, &bs, &hs)) return skip("a BGZF file (many members)"); }
+    const uint64_t n = mf.n, first_bit = (uint64_t)(body - mf.p) * 8, in_bits = n * 8;
+    const uint64_t terr = (uint64_t)h->gz_gpu_terr_kb << 10;
+    const uint32_t nterr = (uint32_t)((n + terr - 1) / terr);
+    const uint64_t tok_total = 4 * n + (uint64_t)nterr * 4096;              // four tokens per compressed byte and a little per chunk
+    {   // room: the compressed bytes, the tokens, and -- FASTQ deflates to a quarter or a fifth -- twelve bytes per compressed byte
+        // of symbols, text and windows at the least (exactly known after the decoding; checked again there)
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t have = free_b + h->gzgpu.d_in.n + h->gzgpu.d_tok.n * 4 + h->gzgpu.d_sym.n * 2 + h->gzgpu.d_out.n + h->gzgpu.d_win.n;
+        if (n + tok_total * 4 + 16 * n + ((uint64_t)1 << 30) > have) return skip("no room on the device");
+    }
+    td_handle::GzGpu &g = h->gzgpu;
+    const double t0 = PI::now();
+    int rc = g.d_in.ensure(n + 8192); if (rc) return rc;
+    const size_t in_cap = ((n + 4096 + 15) & ~(size_t)15);                    // readable bytes (zeros behind the file)
+    HIPCHK(hipMemsetAsync(g.d_in.p + (n & ~(size_t)15), 0, in_cap - (n & ~(size_t)15), h->copy_stream));
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    rc = td_load_file_range(h, path, 0, n, g.d_in.p); if (rc) return rc;
+    const uint64_t nwords = in_cap / 4;
+    const double t1 = PI::now();
+    // 1. block starts
+    rc = g.d_found.ensure(nterr + 1); if (rc) return rc;
+    hipStream_t st = h->work_stream;
+    if (nterr > 1)
+        hipLaunchKernelGGL(tdgz2::k_gz_find, dim3((nterr - 1 + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
+                           g.d_in.p, in_bits, nwords, first_bit, terr * 8, nterr, g.d_found.p);
+    HIPCHK(hipGetLastError());
+    std::vector<uint64_t> found(nterr);
+    if (nterr > 1) HIPCHK(hipMemcpyAsync(found.data() + 1, g.d_found.p + 1, (size_t)(nterr - 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    found[0] = first_bit;
+    const double t2 = PI::now();
+    // 2. the chunks between them, decoded into tokens
+    std::vector<tdgz2::Chunk> chunks;
+    for (uint32_t t = 0; t < nterr; t++) if (found[t] != tdgz2::NONE) { tdgz2::Chunk c{}; c.start_bit = found[t]; chunks.push_back(c); }
+    const uint32_t nchunks = (uint32_t)chunks.size();
+    {
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < nchunks; i++) {
+            chunks[i].stop_bit = i + 1 < nchunks ? chunks[i + 1].start_bit : ~0ull;
+            const uint64_t span = ((i + 1 < nchunks ? chunks[i + 1].start_bit : in_bits) - chunks[i].start_bit + 7) / 8;
+            const uint64_t cap = std::min<uint64_t>(4 * span + 4096, 0xFFFFFF00u);
+            chunks[i].tok_off = at; chunks[i].tok_cap = (uint32_t)cap;
+            at += (cap + 63) & ~(uint64_t)63;
+        }
+        rc = g.d_tok.ensure(at + 64); if (rc) return rc;
+    }
+    rc = g.d_chunks.ensure(nchunks); if (rc) return rc;
+    rc = g.d_res.ensure(nchunks); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)nchunks * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(g.d_res.p, 0, (size_t)nchunks * sizeof(tdgz2::ChunkOut), st));
+    hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
+                       g.d_in.p, in_bits, nwords, g.d_chunks.p, nchunks, g.d_tok.p, g.d_res.p);
+    HIPCHK(hipGetLastError());
+    std::vector<tdgz2::ChunkOut> res(nchunks);
+    HIPCHK(hipMemcpyAsync(res.data(), g.d_res.p, (size_t)nchunks * sizeof(tdgz2::ChunkOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const double t3 = PI::now();
+    // 3. the chain: every chunk begins where its predecessor ended; the last one ends the member, and the file
+    std::vector<uint64_t> sym_off(nchunks + 1);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < nchunks; i++) {
+        const tdgz2::ChunkOut &o = res[i];
+        const bool last = i + 1 == nchunks;
+        if (o.status == tdgz2::S_TOKCAP) return skip("a chunk's tokens overflow their buffer");
+        if (o.status == tdgz2::S_UNUSUAL) return skip("a Huffman code this decoder leaves to zlib");
+        if (o.status == tdgz2::S_ERR) return skip("invalid DEFLATE data (or a false block start)");
+        if (!last && (o.status != tdgz2::S_BOUNDARY || o.end_bit != chunks[i + 1].start_bit))
+            return skip(o.status == tdgz2::S_FINAL ? "more than one member" : "a chunk does not end on its successor's start");
+        if (last && o.status != tdgz2::S_FINAL) return skip("the stream does not end with the file");
+        sym_off[i] = total;
+        total += o.out_len;
+    }
+    sym_off[nchunks] = total;
+    const uint64_t trailer = (res[nchunks - 1].end_bit + 7) / 8;
+    if (trailer + 8 > n) return skip("truncated member");
+    for (uint64_t k = trailer + 8; k < n; k++) if (mf.p[k]) return skip("bytes behind the member");
+    uint32_t want_crc, want_len;
+    memcpy(&want_crc, mf.p + trailer, 4); memcpy(&want_len, mf.p + trailer + 4, 4);
+    if (want_len != (uint32_t)total) return skip("the member fails its length check");
+    // 4.-6. symbols, windows, bytes, CRC-32
+    const uint64_t nblk64 = [&]() { uint64_t k = 0; for (uint32_t i = 0; i < nchunks; i++) k += (res[i].out_len + tdgz::BLOCK_SYMS - 1) / tdgz::BLOCK_SYMS; return k; }();
+    if (nblk64 >= 0x7FFFFFFFull) return skip("file too large");
+    const uint32_t nblk = (uint32_t)nblk64;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t need = 2 * total + total + (uint64_t)nchunks * tdgz2::WINDOW + (uint64_t)nblk * 40 + ((uint64_t)64 << 20);
+        if (need > free_b + g.d_sym.n * 2 + g.d_out.n + g.d_win.n) return skip("no room on the device for the text");
+    }
+    rc = g.d_sym.ensure(total + 64); if (rc) return rc;
+    rc = g.d_out.ensure(total + 4096 + (total >> 3)); if (rc) return rc;
+    rc = g.d_win.ensure((size_t)nchunks * tdgz2::WINDOW); if (rc) return rc;
+    rc = g.d_carry.ensure(tdgz2::WINDOW); if (rc) return rc;
+    rc = g.d_symoff.ensure(nchunks + 1); if (rc) return rc;
+    rc = g.d_blk.ensure(nblk + 1); if (rc) return rc;
+    rc = g.d_crc.ensure(nblk + 1); if (rc) return rc;
+    rc = h->d_gzflag.ensure(4); if (rc) return rc;
+    if (!h->d_crctab) { bool ok = true; rc = ensure_bgzf_buffers(h, 0, 0, &ok); if (rc) return rc; }      // (the CRC tables)
+    std::vector<tdgz::Block> blocks(nblk);
+    {
+        size_t kb = 0;
+        for (uint32_t i = 0; i < nchunks; i++) {
+            const uint32_t min_idx = tdgz2::WINDOW - (uint32_t)std::min<uint64_t>(tdgz2::WINDOW, sym_off[i]);
+            for (uint64_t o = 0; o < res[i].out_len; o += tdgz::BLOCK_SYMS)
+                blocks[kb++] = tdgz::Block{(sym_off[i] + o) * 2, sym_off[i] + o, (uint32_t)std::min<uint64_t>(tdgz::BLOCK_SYMS, res[i].out_len - o), i, min_idx, 0u};
+        }
+    }
+    HIPCHK(hipMemcpyAsync(g.d_symoff.p, sym_off.data(), (size_t)(nchunks + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(g.d_blk.p, blocks.data(), (size_t)nblk * sizeof(tdgz::Block), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(g.d_carry.p, 0, tdgz2::WINDOW, st));
+    HIPCHK(hipMemsetAsync(h->d_gzflag.p, 0, 16, st));
+    hipEvent_t ev[5] = {};
+    auto mark = [&](int k) { if (verbose) { if (!ev[k]) (void)hipEventCreate(&ev[k]); (void)hipEventRecord(ev[k], st); } };
+    mark(0);
+    hipLaunchKernelGGL(tdgz2::k_gz_lz, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
+                       g.d_tok.p, g.d_chunks.p, g.d_res.p, g.d_symoff.p, nchunks, g.d_sym.p);
+    mark(1);
+    hipLaunchKernelGGL(tdgz2::k_gz_windows, dim3(1), dim3(1024), 0, st, g.d_sym.p, g.d_symoff.p, g.d_res.p, nchunks, g.d_win.p, g.d_carry.p);
+    mark(2);
+    std::vector<uint32_t> crcs(nblk);
+    uint32_t flag = 0;
+    if (nblk) {
+        hipLaunchKernelGGL(tdgz::k_gz_resolve, dim3(nblk), dim3(256), 0, st, (const uint8_t *)g.d_sym.p, g.d_win.p, g.d_out.p, g.d_blk.p, nblk, h->d_gzflag.p);
+        mark(3);
+        hipLaunchKernelGGL(tdgz::k_gz_crc, dim3((nblk + 63) / 64), dim3(64), 0, st, g.d_out.p, g.d_blk.p, nblk, h->d_crctab, g.d_crc.p);
+        mark(4);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(crcs.data(), g.d_crc.p, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipMemcpyAsync(&flag, h->d_gzflag.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const double t4 = PI::now();
+    if (verbose && nblk) {
+        float a = 0, b = 0, c = 0, d = 0;
+        (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]); (void)hipEventElapsedTime(&d, ev[3], ev[4]);
+        uint64_t ntok = 0; for (const auto &o : res) ntok += o.ntok;
+        fprintf(stderr, "gz_gpu_inflate: %.1f M tokens; k_gz_lz %.1f ms, k_gz_windows %.1f ms, k_gz_resolve %.1f ms, k_gz_crc %.1f ms\n", ntok / 1e6, a, b, c, d);
+    }
+    for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    *not_applicable = false;                                                 // (from here on the file's verdict is this decoder's)
+    if (flag) return fail(TD_E_IO, "gzip: distance reaches before the start of the output");
+    uint32_t crc = 0;
+    for (uint32_t k = 0; k < nblk; k++) crc = FI::crc32_join(crc, crcs[k], blocks[k].len);
+    if (crc != want_crc) return fail(TD_E_IO, "gzip member fails its CRC-32 check");
+    if (verbose)
+        fprintf(stderr, "gz_gpu_inflate: %.1f MB -> %.1f MB, %u chunks of %u territories: upload %.1f ms, block search %.1f ms, Huffman decoding %.1f ms, "
+                "symbols + windows + bytes + CRC %.1f ms\n", n / 1e6, total / 1e6, nchunks, nterr, (t1 - t0) * 1e3, (t2 - t1) * 1e3,
+                (t3 - t2) * 1e3, (t4 - t3) * 1e3);
+    *total_out = total;
+    h->last_gz_route = 1;
+    return TD_OK;
+}
+int count_gzip_gpu(td_handle *h, const char *path, uint64_t max_reads, int weights, bool *not_applicable) {
+    uint64_t total = 0;
+    int rc = gz_gpu_inflate(h, path, &total, not_applicable);
+    if (rc || *not_applicable) return rc;
+    // the text, counted where it lies
+    hipStream_t st = h->work_stream;
+    HIPCHK(hipMemsetAsync(h->d_cursor.p, 0, 16, st));
+    if (total) { rc = launch_count(h, h->gzgpu.d_out.p, total, 0, max_reads, weights, st, h->d_cursor.p, h->d_cursor.p + 1, 0); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(st));
+    return TD_OK;
+}
+
+// ---- a .gz input one of the decoders has refused: what does the reference do with it?  (gz_pyrules.hpp)
 int gz_code(int kind) { return kind == tdhost::GZ_EOF ? TD_E_GZ_EOF : kind == tdhost::GZ_BADFILE ? TD_E_GZ_BADFILE : TD_E_GZ_DATA; }
 bool gz_refusal(int rc) { return rc == TD_E_IO || rc == TD_E_LIMIT; }
 
@@ -1507,6 +1703,23 @@ int count_gz_by_reference_rules(td_handle *h, const char *path, uint64_t max_rea
 }  // namespace
 
 extern "C" {
+
+int td_gunzip_file_gpu(td_handle *h, const char *path, void *dst, uint64_t capacity, uint64_t *n_out, int *on_gpu) {
+    if (!h || !path || !n_out || !on_gpu || (!dst && capacity)) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    *n_out = 0; *on_gpu = 0;
+    bool not_applicable = false;
+    uint64_t total = 0;
+    const int rc = gz_gpu_inflate(h, path, &total, &not_applicable);
+    if (rc) return rc;
+    if (not_applicable) return TD_OK;
+    if (total > capacity) return fail(TD_E_LIMIT, "destination too small");
+    if (total) HIPCHK(hipMemcpy(dst, h->gzgpu.d_out.p, total, hipMemcpyDeviceToHost));
+    *n_out = total; *on_gpu = 1;
+    return TD_OK;
+}
+
+int td_last_gz_route(td_handle *h) { return h ? h->last_gz_route : 0; }
 
 int td_gzip_check(const char *path, uint64_t max_reads) {
     if (!path) return fail(TD_E_ARG, "NULL argument");
@@ -1627,6 +1840,7 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
     const bool gz = len >= 2 && (path[len - 2] == 'g' || path[len - 2] == 'G') && (path[len - 1] == 'z' || path[len - 1] == 'Z');
     if (gz) {
         const bool was_fresh = !h->counted;
+        h->last_gz_route = 0;
         auto fast = [&]() -> int {
             {   // (an empty file: gzip.open reads it as no data at all)
                 struct stat sb0;
@@ -1639,6 +1853,12 @@ int td_count_file(td_handle *h, const char *path, uint64_t max_reads, int weight
                 if (rc || !not_bgzf) return rc;
             }
             static const bool resolve_off = getenv("TAGDIG_GPU_RESOLVE") && atoi(getenv("TAGDIG_GPU_RESOLVE")) == 0;
+            static const bool huffman_off = getenv("TAGDIG_GPU_HUFFMAN") && atoi(getenv("TAGDIG_GPU_HUFFMAN")) == 0;
+            if (h->gpu_huffman && !huffman_off && !getenv("TAGDIG_ZLIB")) {       // ordinary gzip: decoded on the GPU
+                bool not_applicable = false;
+                const int rc = count_gzip_gpu(h, path, max_reads, weights, &not_applicable);
+                if (rc || !not_applicable) return rc;
+            }
             if (h->gpu_resolve && !resolve_off) {                                 // ordinary gzip: decoded on the host threads, resolved on the GPU
                 bool not_applicable = false;
                 const int rc = count_gzip_dev(h, path, max_reads, weights, &not_applicable);
@@ -1931,6 +2151,10 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     else if (n == "progress") h->progress = value ? 1 : 0;
     else if (n == "zb_members") h->zb_members = (uint32_t)std::max<int64_t>(64, value);
     else if (n == "split_kernel") h->split_kernel = value == 1 ? 1 : 2;
+    else if (n == "gpu_huffman") h->gpu_huffman = value ? 1 : 0;
+    else if (n == "gz_gpu_min") h->gz_gpu_min = (uint64_t)std::max<long long>(0, value);
+    else if (n == "gz_gpu_terr_kb") { if (value < 16 || value > 4096) return fail(TD_E_ARG, "gz_gpu_terr_kb: 16..4096"); h->gz_gpu_terr_kb = (uint32_t)value; }
+    else if (n == "gz_gpu_release") { h->gzgpu.release(); }
     else if (n == "gpu_inflate") h->gpu_inflate = value ? 1 : 0;
     else if (n == "gpu_inflate_crc") h->gpu_inflate_crc = value ? 1 : 0;
     else if (n == "gpu_resolve") h->gpu_resolve = value ? 1 : 0;

@@ -157,6 +157,18 @@ class Engine:
         B.check(self._L.td_count_file(self._h, path.encode(), effective_maxreads(maxreads),
                                       1 if tassel_tagcount else 0))
 
+    def gunzip_file_gpu(self, path, capacity):
+        """An ordinary .gz file inflated by the device decoder (csrc/gz_gpu.hpp): its text as bytes, or None where that
+        decoder leaves the file to the host decoders (see td_gunzip_file_gpu in include/tagdig.h)."""
+        buf = (C.c_uint8 * max(1, capacity))()
+        n, on_gpu = C.c_uint64(0), C.c_int(0)
+        B.check(self._L.td_gunzip_file_gpu(self._h, path.encode(), buf, capacity, C.byref(n), C.byref(on_gpu)))
+        return bytes(memoryview(buf)[:n.value]) if on_gpu.value else None
+
+    def last_gz_route(self):
+        """1: the .gz file counted last was inflated on the device; 0: by a host decoder."""
+        return int(self._L.td_last_gz_route(self._h))
+
     # ------------------------------------------------------------------ barcode splitter
     def set_splitter(self, barcodes, cutsite, fullsite0, fullsite1, entries):
         """entries[b] = [(adapter beginning to look for at the end of a read, slice index), ...] for

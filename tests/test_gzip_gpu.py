@@ -96,7 +96,8 @@ def test_gzip_file_counts_like_plain(eng, sample, tmp_path, monkeypatch, kind, w
 
 
 def test_gpu_resolve_is_what_runs(eng, sample, tmp_path, monkeypatch, capfd):
-    """The default path of a gzip file of this size is count_gzip_dev (its statistics line says so), not the host reader."""
+    """With the device decoder off, the path of a gzip file of this size is count_gzip_dev (its statistics line says so), not
+    the host reader."""
     cfg, raw, want, ost = sample
     path = str(tmp_path / "lib.fq.gz")
     with open(path, "wb") as fh:
@@ -105,8 +106,12 @@ def test_gpu_resolve_is_what_runs(eng, sample, tmp_path, monkeypatch, capfd):
     monkeypatch.delenv("TAGDIG_PAR_INFLATE", raising=False)
     monkeypatch.setenv("TAGDIG_INFLATE_STATS", "1")
     eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
-    eng.reset()
-    eng.count_file(path)
+    eng.set_option("gpu_huffman", 0)                            # (the device decoder, tests/test_gzip_gpu_huffman.py, would take the file)
+    try:
+        eng.reset()
+        eng.count_file(path)
+    finally:
+        eng.set_option("gpu_huffman", 1)
     _check(eng, want * 3, {k: 3 * v for k, v in ost.items()}, "three times the sample")
     err = capfd.readouterr().err
     assert "count_gzip_dev:" in err and "par_inflate:" in err, err

@@ -15,7 +15,7 @@ f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$
 echo "[profile] the default bench"
 python3 "$ROOT/bench.py" > "$OUT/bench_default.log" 2> "$OUT/bench_default.err"
 echo "[profile] SQ counters"
-cd "$ROOT" && tools/sq2.sh ${TAG}_sq > /dev/null 2>&1; cp gpurun_out/${TAG}_sq/sq.txt "$OUT/sq_k_fast2.txt"
+cd "$ROOT" && tools/sq2.sh ${TAG}_sq > /dev/null 2>&1; cp gpurun_out/${TAG}_sq/sq.txt "$OUT/sq_main_pass.txt"
 echo "[profile] k_split2"
 READS=40000000 tools/split_kernels.sh libtagdig.so > "$OUT/split_kernels.txt" 2>&1
 echo "[profile] k_count (the exact in-flight kernel: tassel_tagcount, early maxreads, matrices of 4 GiB and more)"
@@ -28,6 +28,6 @@ python3 "$ROOT/tools/readlen_sweep.py" > "$OUT/readlen.txt" 2>&1
 python3 "$ROOT/tools/crlf_check.py" 8000000 > "$OUT/crlf.txt" 2>&1
 rm -rf "$OUT/stats"
 ls -la "$OUT"
-echo "[profile] k_fast2 against k_fast4 and against round 3's kernel, passes alternating in one process"
+echo "[profile] k_fast2 against k_fast4 (the default) and against round 3's kernel, passes alternating in one process"
 cd "$ROOT" && python3 tools/ab_inproc.py libtagdig_r3.so libtagdig.so libtagdig.so --arm "" --arm kernel=2 --arm kernel=4 --reads 100000000 --rounds 10 > "$OUT/ab_r3_fast2_fast4.txt" 2>&1
 ls -la "$OUT"
