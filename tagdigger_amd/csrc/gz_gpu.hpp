@@ -306,10 +306,11 @@ __device__ __forceinline__ int read_header(Bits &b, WaveMem &m, bool strict, uin
 // code, or length + extra bits + distance + extra bits: two table look-ups, all 64 lanes' at once), and the wave then only
 // follows the chain from the first bit -- token and size by lane number out of two registers, no table, no memory.  What a
 // look-up cannot settle (a code longer than the table's index) is decoded by the scalar code when the chain comes to it.
-// pos: in, the bit behind the block's header; out, the bit behind its end code.  emit(token) -> false stops the decoding
-// (the caller's status says why).  Returns S_NONE at the end code, S_ERR for invalid data, or the caller's stop.
+// pos: in, the bit behind the block's header; out, the bit behind its end code.  sink(mask, tokens): the lanes of `mask` hold
+// the next tokens, in lane order; false stops the decoding.  Returns S_NONE at the end code, S_ERR for invalid data, S_TOKCAP
+// for the sink's stop.
 template <class F>
-__device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, uint64_t in_bits, const WaveMem &m, int lane, F &&emit) {
+__device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, uint64_t in_bits, const WaveMem &m, int lane, F &&sink) {
     Bits t = rd;
     t.w0 = (pos >> 5) & ~(uint64_t)63;
     uint32_t cur = (uint32_t)(pos - (t.w0 << 5));
@@ -345,13 +346,14 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
         // kind: 0 literal, 1 copy, 2 end code, 3 for the scalar code (a longer code, or none)
         const bool rare = l1 == 0u || (e & F_BAD) || (copy && (l2 == 0u || (d & F_BAD)));
         const uint32_t kind = rare ? 3u : (e & F_END) ? 2u : copy ? 1u : 0u;
-        const uint32_t vtok = copy ? 0x80000000u | (len << 15) | (dist - 1u) : (e >> 8) & 0xFFu;
-        const uint32_t vinfo = (copy ? l1 + ext + l2 + dext : l1) | (kind << 8);
-        // the chain from bit 0
+        uint32_t vtok = copy ? 0x80000000u | (len << 15) | (dist - 1u) : (e >> 8) & 0xFFu;
+        uint32_t vinfo = (copy ? l1 + ext + l2 + dext : l1) | (kind << 8);
+        // the chain from bit 0: which lanes' tokens are real
         uint32_t o = 0;
+        uint64_t onpath = 0;
+        bool ended = false;
         while (o < 64u) {
             uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)vinfo, (int)o);
-            uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)vtok, (int)o);
             if (__builtin_expect((info >> 8) == 3u, 0)) {
                 // the scalar decoder on this one token: 64 bits from its position are enough (15 + 5 + 15 + 13)
                 const uint32_t sb = off + o, sq = sb >> 5, sr = sb & 31u;
@@ -360,6 +362,7 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
                 Bits sbits = t;
                 sbits.bb = ((((uint64_t)smid << 32) | slo) >> sr) | (((uint64_t)shi << 1) << (63u - sr));
                 sbits.bc = 64u;
+                uint32_t tk = 0;
                 const uint32_t se = next_entry<0>(sbits, m.ltab, LROOT, m.lsym, m.lcnt);
                 if (se == E_NONE || (se & F_BAD)) return S_ERR;
                 if (se & F_END) { info = (64u - sbits.bc) | (2u << 8); }
@@ -372,22 +375,23 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
                     tk = 0x80000000u | (slen << 15) | (sdist - 1u);
                     info = (64u - sbits.bc) | (1u << 8);
                 }
+                if ((uint32_t)lane == o) vtok = tk;
             }
-            if ((info >> 8) == 2u) {
-                pos = (t.w0 << 5) + cur + o + (info & 0xFFu);
-                return S_NONE;
-            }
-            if (!emit(tk)) return S_TOKCAP;
+            if ((info >> 8) == 2u) { ended = true; o += info & 0xFFu; break; }
+            onpath |= 1ull << o;
             o += info & 0xFFu;
         }
+        // the real tokens, in order, to the sink (false: it has no room, or has seen enough)
+        if (onpath && !sink(onpath, vtok)) return S_TOKCAP;
         cur += o;
+        if (ended) { pos = (t.w0 << 5) + cur; return S_NONE; }
     }
 }
 
 // ---------------------------------------------------------------- 1. the block search
 // found[t] (t >= 1): the first block start in territory t, or NONE
-__global__ __launch_bounds__(64 * WAVES) void k_gz_find(const uint8_t *in, uint64_t in_bits, uint64_t nwords, uint64_t first_bit,
-                                                        uint64_t terr_bits, uint32_t nterr, uint64_t *found) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_gz_find(const uint8_t *in, uint64_t in_bits, uint64_t nwords, uint64_t first_bit,
+                                                        uint64_t terr_bits, uint32_t nterr, uint64_t *found, uint32_t verify) {
     __shared__ WaveMem mem[WAVES];
     const int lane = (int)(threadIdx.x & 63u);
     const uint32_t wave = rfl(threadIdx.x >> 6);
@@ -429,9 +433,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_find(const uint8_t *in, uint6
             bits_init(b, pc, lane);
             uint32_t final, stored;
             if (read_header(b, m, true, final, stored, lane) != 2) continue;
+            if (lane == 0) atomicAdd((unsigned long long *)(found + nterr), 1ull);          // (statistics: headers that pass)
+            // verify: the block is decoded to its end code, and another header must follow -- else the headers' checks are
+            // trusted (they left no false start in 10^9 positions of the measured file), and a false start costs the chunk in
+            // front of it a second decoding when the host chains the chunks
+            if (!verify) {
+                result = pc;
+                if (lane == 0) atomicAdd((unsigned long long *)(found + nterr + 1), 1ull);
+                break;
+            }
             uint64_t at = bitpos(b);
             uint32_t nsym = 0;
-            const uint32_t dr = decode_block(b, at, in_bits, m, lane, [&](uint32_t) { return ++nsym < (1u << 21); });
+            const uint32_t dr = decode_block(b, at, in_bits, m, lane, [&](uint64_t mask, uint32_t) { nsym += (uint32_t)__builtin_popcountll(mask); return nsym < (1u << 21); });
             if (dr != S_NONE || at + 3u > in_bits) continue;
             bits_init(b, at, lane);
             // what follows must read as a header as well
@@ -451,6 +464,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_find(const uint8_t *in, uint6
                 if (((nx >> 3) & 31u) > 29u || ((nx >> 8) & 31u) > 29u) continue;
             }
             result = pc;
+            if (lane == 0) atomicAdd((unsigned long long *)(found + nterr + 1), 1ull);      // (... of them block starts)
             break;
         }
     }
@@ -459,7 +473,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_find(const uint8_t *in, uint6
 
 // ---------------------------------------------------------------- 2. Huffman decoding into tokens
 // a token: a literal (its byte), or 0x80000000 | length << 15 | (distance - 1)
-__global__ __launch_bounds__(64 * WAVES) void k_gz_tokens(const uint8_t *in, uint64_t in_bits, uint64_t nwords, const Chunk *chunks, uint32_t nchunks,
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_gz_tokens(const uint8_t *in, uint64_t in_bits, uint64_t nwords, const Chunk *chunks, uint32_t nchunks,
                                                           uint32_t *tok, ChunkOut *out) {
     __shared__ WaveMem mem[WAVES];
     const int lane = (int)(threadIdx.x & 63u);
@@ -473,23 +487,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_tokens(const uint8_t *in, uin
     Bits b;
     b.base = reinterpret_cast<const uint32_t *>(in); b.nwords = nwords;
     bits_init(b, start, lane);
-    uint32_t ntok = 0, glo = 0, tokv = 0, status = S_NONE;
+    uint32_t ntok = 0, status = S_NONE;
     uint64_t out_len = 0, end_bit = 0;
-    // the staged tokens [glo, hi) of the current group of 64 to memory
-    auto flush = [&](uint32_t hi) {
-        const uint32_t g0 = (ntok - 1u) & ~63u;                        // (called with ntok > 0 behind the group's last token)
-        if ((uint32_t)lane >= glo && (uint32_t)lane < hi) tk[g0 + (uint32_t)lane] = tokv;
-    };
-    // (every 64 tokens: room for 64 more, and the input not overrun -- zeros are read behind it)
-    auto emit = [&](uint32_t t) {
-        tokv = (uint32_t)lane == (ntok & 63u) ? t : tokv;
-        ntok++;
-        if (__builtin_expect((ntok & 63u) == 0u, 0)) {
-            flush(64u); glo = 0;
-            if (ntok + 128u > cap) status = S_TOKCAP;
-            else if (bitpos(b) > in_bits) status = S_ERR;
-        }
-    };
+    uint64_t vlen = 0;                                                     // this lane's share of the decoded tokens' bytes
     for (;;) {
         const uint64_t pos = bitpos(b);
         if (pos >= stop) { status = S_BOUNDARY; end_bit = pos; break; }
@@ -502,17 +502,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_tokens(const uint8_t *in, uin
             const uint64_t at = bitpos(b) >> 3;
             if ((at + stored) * 8u > in_bits) { status = S_ERR; break; }
             if ((uint64_t)ntok + stored + 192u > cap) { status = S_TOKCAP; break; }
-            if ((ntok & 63u) > glo) flush(ntok & 63u);
             for (uint32_t i = (uint32_t)lane; i < stored; i += 64u) tk[ntok + i] = in[at + i];
             ntok += stored; out_len += stored;
-            glo = ntok & 63u;
             bits_init(b, (at + stored) * 8u, lane);
         } else {
             uint64_t at = bitpos(b);
-            const uint32_t dr = decode_block(b, at, in_bits, m, lane, [&](uint32_t t) {
-                emit(t);
-                out_len += t >> 31 ? (t >> 15) & 0x1FFu : 1u;
-                return status == S_NONE;
+            const uint32_t dr = decode_block(b, at, in_bits, m, lane, [&](uint64_t mask, uint32_t t) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if ((mask >> lane) & 1ull) {
+                    tk[ntok + rank] = t;
+                    vlen += t >> 31 ? (t >> 15) & 0x1FFu : 1u;
+                }
+                ntok += (uint32_t)__builtin_popcountll(mask);
+                return ntok + 128u <= cap;
             });
             if (dr != S_NONE && status == S_NONE) status = dr;
             if (status == S_NONE) bits_init(b, at, lane);
@@ -520,7 +522,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_tokens(const uint8_t *in, uin
         }
         if (final) { status = S_FINAL; end_bit = bitpos(b); break; }
     }
-    if ((ntok & 63u) > glo) flush(ntok & 63u);
+    {
+        uint64_t v = vlen;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, d, 64);
+        out_len += v;
+    }
     if (lane == 0) {
         ChunkOut o;
         o.end_bit = end_bit; o.out_len = out_len; o.ntok = ntok; o.status = status;
@@ -573,20 +580,47 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_lz(const uint32_t *tok, const
             const int64_t F = (int64_t)(((uint64_t)fhi << 32) | flo);
             const bool ready = pending && src + (int64_t)need <= F;
             if (ready) {
-                // every symbol comes from [src, src + min(L, dist)), all of it in front of this copy: eight loads, then eight
-                // stores (a load that had to wait for the store before it would take a memory round trip per symbol)
-                uint32_t k = 0;
-                for (uint32_t j = 0; j < L; j += 8u) {
-                    uint16_t v[8];
+                if (L <= dist && src >= 0) {
+                    // the common copy -- source and destination apart, nothing from before the chunk: four symbols (8 bytes, at any
+                    // 2-byte boundary) a load, sixteen symbols in flight before the first store (a load that had to wait for the
+                    // store before it would take a memory round trip per piece)
+                    const uint16_t *sp = out + src;
+                    uint16_t *dp = out + pos;
+                    uint32_t j = 0;
+                    for (; j + 16u <= L; j += 16u) {
+                        uint64_t v[4];
 #pragma unroll
-                    for (uint32_t i = 0; i < 8u; i++) {
-                        const int64_t s = src + (int64_t)k;
-                        v[i] = j + i >= L ? (uint16_t)0 : s < 0 ? (uint16_t)(0x8000u | (uint32_t)((int64_t)WINDOW + s)) : out[s];
-                        if (++k == dist) k = 0;
+                        for (uint32_t i = 0; i < 4u; i++) __builtin_memcpy(&v[i], sp + j + 4u * i, 8);
+#pragma unroll
+                        for (uint32_t i = 0; i < 4u; i++) __builtin_memcpy(dp + j + 4u * i, &v[i], 8);
                     }
+                    uint64_t v[4];
+                    const uint32_t rest = L - j;                           // 0..15
 #pragma unroll
-                    for (uint32_t i = 0; i < 8u; i++)
-                        if (j + i < L) out[pos + (int64_t)(j + i)] = v[i];
+                    for (uint32_t i = 0; i < 4u; i++) if (4u * i < rest) __builtin_memcpy(&v[i], sp + j + 4u * i, 8);     // (reads up to 3 symbols past the source: inside the buffer)
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; i++) {
+                        if (4u * i + 4u <= rest) __builtin_memcpy(dp + j + 4u * i, &v[i], 8);
+                        else if (4u * i < rest) {
+                            for (uint32_t q = 0; q < rest - 4u * i; q++) dp[j + 4u * i + q] = (uint16_t)(v[i] >> (16u * q));
+                        }
+                    }
+                } else {
+                    // a run (the source overlaps the destination: every symbol comes from [src, src + dist)), or symbols from before
+                    // the chunk (markers): symbol by symbol, sixteen loads, then sixteen stores
+                    uint32_t k = 0;
+                    for (uint32_t j = 0; j < L; j += 16u) {
+                        uint16_t v[16];
+#pragma unroll
+                        for (uint32_t i = 0; i < 16u; i++) {
+                            const int64_t s = src + (int64_t)k;
+                            v[i] = j + i >= L ? (uint16_t)0 : s < 0 ? (uint16_t)(0x8000u | (uint32_t)((int64_t)WINDOW + s)) : out[s];
+                            if (++k == dist) k = 0;
+                        }
+#pragma unroll
+                        for (uint32_t i = 0; i < 16u; i++)
+                            if (j + i < L) out[pos + (int64_t)(j + i)] = v[i];
+                    }
                 }
             }
             wave_mem_fence();
@@ -602,32 +636,76 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_lz(const uint32_t *tok, const
 __global__ __launch_bounds__(1024) void k_gz_windows(const uint16_t *sym, const uint64_t *sym_off, const ChunkOut *res, uint32_t nchunks,
                                                      uint8_t *d_win, uint8_t *carry) {
     __shared__ uint8_t W[2][WINDOW];
+    constexpr uint32_t PER = WINDOW / 4096u;                             // groups of four consecutive symbols per thread
     const uint32_t tid = threadIdx.x;
     for (uint32_t p = tid * 16u; p < WINDOW; p += 1024u * 16u)
         *reinterpret_cast<uint4 *>(&W[0][p]) = *reinterpret_cast<const uint4 *>(carry + p);
-    __syncthreads();
-    uint32_t cur = 0;
-    for (uint32_t c = 0; c < nchunks; c++) {
+    // a chunk's last 32 KiB of symbols, this thread's eight groups of four (8 bytes a load, at any 2-byte boundary); a chunk
+    // shorter than that: markers into what is left of the window before it
+    // (off: where the chunk's last 32 KiB of symbols begin -- read a step ahead of the loads that need it; NONE: a short chunk)
+    auto tail_at = [&](uint32_t c) -> uint64_t {
+        if (c >= nchunks) return NONE;
         const uint64_t n = res[c].out_len;
-        const uint16_t *s = sym + sym_off[c];
+        return n >= WINDOW ? sym_off[c] + n - WINDOW : NONE;
+    };
+    auto tail = [&](uint32_t c, uint64_t off, uint64_t (&v)[PER]) {
+        if (off != NONE) {
+            const uint16_t *t0 = sym + off;
+#pragma unroll
+            for (uint32_t i = 0; i < PER; i++) __builtin_memcpy(&v[i], t0 + (i * 1024u + tid) * 4u, 8);
+        } else {
+            const uint64_t n = res[c].out_len;
+            const uint16_t *s = sym + sym_off[c];
+#pragma unroll
+            for (uint32_t i = 0; i < PER; i++) {
+                uint64_t x = 0;
+                for (uint32_t q = 0; q < 4u; q++) {
+                    const uint32_t p = (i * 1024u + tid) * 4u + q;
+                    const int64_t o = (int64_t)n - (int64_t)WINDOW + (int64_t)p;
+                    const uint16_t y = o >= 0 ? s[o] : (uint16_t)(0x8000u | (uint32_t)((int64_t)p + (int64_t)n));   // (p + n < 32768: a place in the old window)
+                    x |= (uint64_t)y << (16u * q);
+                }
+                v[i] = x;
+            }
+        }
+    };
+    // one chunk: its window out, the window behind it from its symbols `v` -- while the symbols of the chunk after next come (two
+    // sets of registers taking turns: a set is not touched between its loads and its turn)
+    uint32_t cur = 0;
+    uint64_t off_next = NONE;                                            // tail_at(chunk after next), known a step early
+    auto step = [&](uint32_t c, uint64_t (&v)[PER]) {
+        const uint64_t off_use = off_next;
+        off_next = tail_at(c + 3u);
         uint8_t *wout = d_win + (size_t)c * WINDOW;
         for (uint32_t p = tid * 16u; p < WINDOW; p += 1024u * 16u)
             *reinterpret_cast<uint4 *>(wout + p) = *reinterpret_cast<const uint4 *>(&W[cur][p]);
-        // the window behind this chunk: its last 32 KiB (or less, behind what is left of the window before it)
-        uint16_t v[WINDOW / 1024];
 #pragma unroll
-        for (uint32_t i = 0; i < WINDOW / 1024u; i++) {
-            const uint32_t p = tid + 1024u * i;
-            const int64_t o = (int64_t)n - (int64_t)WINDOW + (int64_t)p;
-            v[i] = o >= 0 ? s[o] : (uint16_t)(0x8000u | (uint32_t)((int64_t)p + (int64_t)n));      // (p + n < 32768: a place in the old window)
-        }
+        for (uint32_t i = 0; i < PER; i++) {
+            const uint64_t x = v[i];
+            uint32_t y = ((uint32_t)x & 0xFFu) | (((uint32_t)(x >> 16) & 0xFFu) << 8) | (((uint32_t)(x >> 32) & 0xFFu) << 16) | (((uint32_t)(x >> 48) & 0xFFu) << 24);
+            if (x & 0x8000800080008000ull) {                              // (markers are the exception: only they read the old window --
+                uint32_t wb[4];                                           // four reads in flight, then four selects)
 #pragma unroll
-        for (uint32_t i = 0; i < WINDOW / 1024u; i++) {
-            const uint32_t p = tid + 1024u * i;
-            W[cur ^ 1u][p] = (v[i] & 0x8000u) ? W[cur][v[i] & 0x7FFFu] : (uint8_t)v[i];
+                for (uint32_t q = 0; q < 4u; q++) wb[q] = W[cur][(uint32_t)(x >> (16u * q)) & 0x7FFFu];
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; q++)
+                    if ((x >> (16u * q)) & 0x8000u) y = (y & ~(0xFFu << (8u * q))) | (wb[q] << (8u * q));
+            }
+            *reinterpret_cast<uint32_t *>(&W[cur ^ 1u][(i * 1024u + tid) * 4u]) = y;
         }
-        __syncthreads();
+        if (c + 2u < nchunks) tail(c + 2u, off_use, v);
+        // (the workgroup's LDS writes, not its loads from memory: __syncthreads would wait for those too)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         cur ^= 1u;
+    };
+    uint64_t va[PER], vb[PER];
+    if (nchunks) tail(0, tail_at(0), va);
+    if (nchunks > 1u) tail(1, tail_at(1), vb);
+    off_next = tail_at(2);
+    __syncthreads();
+    for (uint32_t c = 0; c < nchunks; c += 2u) {
+        step(c, va);
+        if (c + 1u < nchunks) step(c + 1u, vb);
     }
     for (uint32_t p = tid * 16u; p < WINDOW; p += 1024u * 16u)
         *reinterpret_cast<uint4 *>(carry + p) = *reinterpret_cast<const uint4 *>(&W[cur][p]);

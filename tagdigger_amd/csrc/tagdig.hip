@@ -228,6 +228,8 @@ struct td_handle {
     int gpu_huffman = 1;                      // ordinary gzip: Huffman decoding on the GPU too (0: host threads decode, the GPU resolves)
     uint64_t gz_gpu_min = (uint64_t)8 << 20;  // ... for files of this many compressed bytes and more
     uint32_t gz_gpu_terr_kb = 128;            // ... one chunk per this much compressed data
+    int gz_gpu_verify = 0;                    // ... the block search decodes a block before it believes its header
+    int gz_gpu_false_every = 0;               // (tests) every n-th found block start is moved by some bits: a false start
     int gpu_resolve = 1;                      // ordinary gzip of 8 MiB and more: markers -> bytes and CRC-32 on the GPU (0: all on the host)
     uint8_t *d_zscratch = nullptr; uint32_t *d_crctab = nullptr;
     uint32_t zcap_members = 0; size_t zcap_in = 0;   // what the batch buffers above were allocated for
@@ -1521,21 +1523,28 @@ int gz_gpu_inflate(td_handle *h, const char *path, uint64_t *total_out, bool *no
     const uint64_t nwords = in_cap / 4;
     const double t1 = PI::now();
     // 1. block starts
-    rc = g.d_found.ensure(nterr + 1); if (rc) return rc;
+    rc = g.d_found.ensure(nterr + 4); if (rc) return rc;
     hipStream_t st = h->work_stream;
+    HIPCHK(hipMemsetAsync(g.d_found.p + nterr, 0, 32, st));
     if (nterr > 1)
         hipLaunchKernelGGL(tdgz2::k_gz_find, dim3((nterr - 1 + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
-                           g.d_in.p, in_bits, nwords, first_bit, terr * 8, nterr, g.d_found.p);
+                           g.d_in.p, in_bits, nwords, first_bit, terr * 8, nterr, g.d_found.p, (uint32_t)h->gz_gpu_verify);
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> found(nterr);
     if (nterr > 1) HIPCHK(hipMemcpyAsync(found.data() + 1, g.d_found.p + 1, (size_t)(nterr - 1) * 8, hipMemcpyDeviceToHost, st));
+    uint64_t fstat[2] = {0, 0};
+    if (verbose) HIPCHK(hipMemcpyAsync(fstat, g.d_found.p + nterr, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (verbose) fprintf(stderr, "gz_gpu_inflate: block search: %lu headers passed the checks, %lu of them were block starts\n", (unsigned long)fstat[0], (unsigned long)fstat[1]);
     found[0] = first_bit;
+    if (h->gz_gpu_false_every > 0)
+        for (uint32_t t = 1; t < nterr; t++)
+            if (found[t] != tdgz2::NONE && t % (uint32_t)h->gz_gpu_false_every == 0 && found[t] + 4099 < in_bits) found[t] += 4099;
     const double t2 = PI::now();
     // 2. the chunks between them, decoded into tokens
     std::vector<tdgz2::Chunk> chunks;
     for (uint32_t t = 0; t < nterr; t++) if (found[t] != tdgz2::NONE) { tdgz2::Chunk c{}; c.start_bit = found[t]; chunks.push_back(c); }
-    const uint32_t nchunks = (uint32_t)chunks.size();
+    uint32_t nchunks = (uint32_t)chunks.size();
     {
         uint64_t at = 0;
         for (uint32_t i = 0; i < nchunks; i++) {
@@ -1547,8 +1556,8 @@ int gz_gpu_inflate(td_handle *h, const char *path, uint64_t *total_out, bool *no
         }
         rc = g.d_tok.ensure(at + 64); if (rc) return rc;
     }
-    rc = g.d_chunks.ensure(nchunks); if (rc) return rc;
-    rc = g.d_res.ensure(nchunks); if (rc) return rc;
+    rc = g.d_chunks.ensure(2 * (size_t)nchunks); if (rc) return rc;               // (behind the chunks: the ones decoded a second time)
+    rc = g.d_res.ensure(2 * (size_t)nchunks); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)nchunks * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(g.d_res.p, 0, (size_t)nchunks * sizeof(tdgz2::ChunkOut), st));
     hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
@@ -1558,21 +1567,78 @@ int gz_gpu_inflate(td_handle *h, const char *path, uint64_t *total_out, bool *no
     HIPCHK(hipMemcpyAsync(res.data(), g.d_res.p, (size_t)nchunks * sizeof(tdgz2::ChunkOut), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const double t3 = PI::now();
-    // 3. the chain: every chunk begins where its predecessor ended; the last one ends the member, and the file
+    // 3. the chain: every chunk begins where its predecessor ended.  A chunk that ran past its successor's start met a false
+    // one there: the successor is dropped, and what lies between this chunk's end and the next start is decoded in a second
+    // launch (into the dropped chunk's token buffer).  The last chunk ends the member, and the file.
+    std::vector<uint8_t> dead(nchunks, 0);
+    for (int round = 0;; round++) {
+        std::vector<uint32_t> redo;
+        uint32_t i = 0;
+        bool assumed = false;                 // behind this round's first gap the chain is a guess: nothing there refuses the file yet
+        while (true) {
+            const tdgz2::ChunkOut &o = res[i];
+            if (assumed && (o.status != tdgz2::S_BOUNDARY && o.status != tdgz2::S_FINAL)) break;
+            if (o.status == tdgz2::S_TOKCAP) return skip("a chunk's tokens overflow their buffer");
+            if (o.status == tdgz2::S_UNUSUAL) return skip("a Huffman code this decoder leaves to zlib");
+            if (o.status == tdgz2::S_ERR) return skip("invalid DEFLATE data");
+            uint32_t j = i + 1;
+            while (j < nchunks && dead[j]) j++;
+            if (j == nchunks) {
+                if (assumed) break;
+                if (o.status != tdgz2::S_FINAL) return skip("the stream does not end with the file");
+                break;
+            }
+            if (o.status == tdgz2::S_FINAL) { if (assumed) break; return skip("more than one member"); }
+            if (o.end_bit == chunks[j].start_bit) { i = j; continue; }
+            // chunks[j] is no block start (the chunk in front of it was decoded up to a boundary at or past it)
+            if (o.end_bit < chunks[j].start_bit) { if (assumed) break; return skip("a chunk ends before its successor's start"); }
+            if (assumed) break;               // (a guess must not drop chunks)
+            uint32_t k = j + 1;
+            while (k < nchunks && (dead[k] || chunks[k].start_bit < o.end_bit)) { dead[k] = 1; k++; }
+            if (k < nchunks && chunks[k].start_bit == o.end_bit) { dead[j] = 1; i = k; continue; }
+            // the gap [end, next start): chunk j's place and buffer
+            const uint64_t gap_end = k < nchunks ? chunks[k].start_bit : in_bits;
+            if ((gap_end - o.end_bit + 7) / 8 * 4 + 4096 > chunks[j].tok_cap) return skip("a false block start in front of a long stretch without one");
+            chunks[j].start_bit = o.end_bit;
+            chunks[j].stop_bit = k < nchunks ? chunks[k].start_bit : ~0ull;
+            redo.push_back(j);
+            // (the walk goes on behind the gap as if its decoding will end on the next start; the next round looks at that)
+            if (k == nchunks) break;
+            i = k;
+            assumed = true;
+        }
+        if (redo.empty()) break;
+        if (round >= 8) return skip("too many false block starts");
+        // the gaps of this round in one launch (a false start is rare: the header checks pass for about one position in 10^10)
+        const uint32_t nr = (uint32_t)redo.size();
+        std::vector<tdgz2::Chunk> rc_in(nr);
+        std::vector<tdgz2::ChunkOut> rc_out(nr);
+        for (uint32_t q = 0; q < nr; q++) rc_in[q] = chunks[redo[q]];
+        HIPCHK(hipMemcpyAsync(g.d_chunks.p + nchunks, rc_in.data(), (size_t)nr * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nr + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st, g.d_in.p, in_bits, nwords,
+                           g.d_chunks.p + nchunks, nr, g.d_tok.p, g.d_res.p + nchunks);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(rc_out.data(), g.d_res.p + nchunks, (size_t)nr * sizeof(tdgz2::ChunkOut), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (uint32_t q = 0; q < nr; q++) res[redo[q]] = rc_out[q];
+        if (verbose) fprintf(stderr, "gz_gpu_inflate: %u false block starts; the stretches behind them decoded again\n", nr);
+    }
+    HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)nchunks * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(g.d_res.p, res.data(), (size_t)nchunks * sizeof(tdgz2::ChunkOut), hipMemcpyHostToDevice, st));
+    // the chunks that count, compacted (the kernels behind this walk them by index)
+    {
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < nchunks; i++) if (!dead[i]) { chunks[w] = chunks[i]; res[w] = res[i]; w++; }
+        if (w != nchunks) {
+            chunks.resize(w); res.resize(w);
+            HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)w * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(g.d_res.p, res.data(), (size_t)w * sizeof(tdgz2::ChunkOut), hipMemcpyHostToDevice, st));
+        }
+    }
+    nchunks = (uint32_t)chunks.size();
     std::vector<uint64_t> sym_off(nchunks + 1);
     uint64_t total = 0;
-    for (uint32_t i = 0; i < nchunks; i++) {
-        const tdgz2::ChunkOut &o = res[i];
-        const bool last = i + 1 == nchunks;
-        if (o.status == tdgz2::S_TOKCAP) return skip("a chunk's tokens overflow their buffer");
-        if (o.status == tdgz2::S_UNUSUAL) return skip("a Huffman code this decoder leaves to zlib");
-        if (o.status == tdgz2::S_ERR) return skip("invalid DEFLATE data (or a false block start)");
-        if (!last && (o.status != tdgz2::S_BOUNDARY || o.end_bit != chunks[i + 1].start_bit))
-            return skip(o.status == tdgz2::S_FINAL ? "more than one member" : "a chunk does not end on its successor's start");
-        if (last && o.status != tdgz2::S_FINAL) return skip("the stream does not end with the file");
-        sym_off[i] = total;
-        total += o.out_len;
-    }
+    for (uint32_t i = 0; i < nchunks; i++) { sym_off[i] = total; total += res[i].out_len; }
     sym_off[nchunks] = total;
     const uint64_t trailer = (res[nchunks - 1].end_bit + 7) / 8;
     if (trailer + 8 > n) return skip("truncated member");
@@ -2155,6 +2221,8 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     else if (n == "gz_gpu_min") h->gz_gpu_min = (uint64_t)std::max<long long>(0, value);
     else if (n == "gz_gpu_terr_kb") { if (value < 16 || value > 4096) return fail(TD_E_ARG, "gz_gpu_terr_kb: 16..4096"); h->gz_gpu_terr_kb = (uint32_t)value; }
     else if (n == "gz_gpu_release") { h->gzgpu.release(); }
+    else if (n == "gz_gpu_verify") h->gz_gpu_verify = value ? 1 : 0;
+    else if (n == "gz_gpu_false_every") h->gz_gpu_false_every = (int)std::max<long long>(0, value);
     else if (n == "gpu_inflate") h->gpu_inflate = value ? 1 : 0;
     else if (n == "gpu_inflate_crc") h->gpu_inflate_crc = value ? 1 : 0;
     else if (n == "gpu_resolve") h->gpu_resolve = value ? 1 : 0;

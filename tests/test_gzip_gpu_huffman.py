@@ -118,6 +118,37 @@ def test_text_and_counts(eng, sample, tmp_path, kind, terr_kb):
     assert eng.last_gz_route() == (1 if on_device else 0)
 
 
+@pytest.mark.parametrize("every", [1, 40, 97])
+def test_false_block_starts_cost_a_second_decoding_only(eng, sample, tmp_path, every):
+    """The chunks are chained by the host: a start that is none (here every n-th found start, moved by 4099 bits) is dropped and
+    the stretch behind its predecessor's end decoded again -- the text is the same."""
+    cfg, raw, want, ost = sample
+    path = str(tmp_path / "lib.fq.gz")
+    with open(path, "wb") as fh:
+        fh.write(gzip.compress(raw, compresslevel=6))
+    eng.set_option("gz_gpu_terr_kb", 64)
+    eng.set_option("gz_gpu_false_every", every)
+    try:
+        got = eng.gunzip_file_gpu(path, len(raw) + 64)
+        assert got is None or got == raw          # (None: more false starts than the decoder repairs, eight -- the host decoder's file then)
+        if every > 1:
+            assert got == raw
+    finally:
+        eng.set_option("gz_gpu_false_every", 0)
+
+
+def test_block_search_that_decodes_before_it_believes(eng, sample, tmp_path):
+    cfg, raw, want, ost = sample
+    path = str(tmp_path / "lib.fq.gz")
+    with open(path, "wb") as fh:
+        fh.write(gzip.compress(raw, compresslevel=6))
+    eng.set_option("gz_gpu_verify", 1)
+    try:
+        assert eng.gunzip_file_gpu(path, len(raw) + 64) == raw
+    finally:
+        eng.set_option("gz_gpu_verify", 0)
+
+
 def test_what_the_device_decoder_leaves_to_the_host(eng, sample, tmp_path):
     """Tiny and empty inputs, text that deflates a thousandfold (more tokens than a chunk's buffer holds), a file below the
     size bound: td_count_file counts them as before."""
