@@ -630,24 +630,39 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_lz(const uint32_t *tok, const
     }
 }
 
-// ---------------------------------------------------------------- 5. the chunks' windows, in order
-// d_win + 32768 c: chunk c's window (what its markers point into); carry: in, the window of the first chunk; out, the window
-// behind the last.  first_len: chunk c's symbols are sym[sym_off[c] .. + out_len[c])
-__global__ __launch_bounds__(1024) void k_gz_windows(const uint16_t *sym, const uint64_t *sym_off, const ChunkOut *res, uint32_t nchunks,
-                                                     uint8_t *d_win, uint8_t *carry) {
-    __shared__ uint8_t W[2][WINDOW];
+// ---------------------------------------------------------------- 5. the chunks' windows
+// A chunk's window is its predecessor's last 32 KiB with the markers in them replaced from the predecessor's window: a chain
+// through all chunks -- 3.5 us a link on one CU, 18 ms for 5 000 chunks.  So the chain is walked in SEGMENTS of chunks, three
+// launches:
+//   k_gz_windows<uint16_t>  every segment by itself (a workgroup each), from the identity: what each place of the window behind
+//                           the segment holds -- a byte, or a marker into the window in FRONT of the segment (a map);
+//   k_gz_seg_windows        one workgroup, segment by segment: the window in front of each, through the maps;
+//   k_gz_windows<uint8_t>   every segment by itself again, from its real window: each chunk's window to d_win.
+// T: what a place of the window holds (uint8_t a byte; uint16_t a symbol).  LDS: two windows of T.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_gz_windows(const uint16_t *sym, const uint64_t *sym_off, const ChunkOut *res, uint32_t nchunks, uint32_t seg_len,
+                                                     const T *seg_in, T *seg_out, uint8_t *d_win) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    T *W0 = reinterpret_cast<T *>(lds_raw);
     constexpr uint32_t PER = WINDOW / 4096u;                             // groups of four consecutive symbols per thread
+    constexpr bool BYTES = sizeof(T) == 1;
     const uint32_t tid = threadIdx.x;
-    for (uint32_t p = tid * 16u; p < WINDOW; p += 1024u * 16u)
-        *reinterpret_cast<uint4 *>(&W[0][p]) = *reinterpret_cast<const uint4 *>(carry + p);
-    // a chunk's last 32 KiB of symbols, this thread's eight groups of four (8 bytes a load, at any 2-byte boundary); a chunk
-    // shorter than that: markers into what is left of the window before it
+    const uint32_t c0 = blockIdx.x * seg_len, c1 = c0 + seg_len < nchunks ? c0 + seg_len : nchunks;
+    if (c0 >= nchunks) return;
+    if (seg_in) {
+        const T *src = seg_in + (size_t)blockIdx.x * WINDOW;
+        for (uint32_t p = tid; p < WINDOW; p += 1024u) W0[p] = src[p];
+    } else {
+        for (uint32_t p = tid; p < WINDOW; p += 1024u) W0[p] = (T)(0x8000u | p);
+    }
     // (off: where the chunk's last 32 KiB of symbols begin -- read a step ahead of the loads that need it; NONE: a short chunk)
     auto tail_at = [&](uint32_t c) -> uint64_t {
-        if (c >= nchunks) return NONE;
+        if (c >= c1) return NONE;
         const uint64_t n = res[c].out_len;
         return n >= WINDOW ? sym_off[c] + n - WINDOW : NONE;
     };
+    // a chunk's last 32 KiB of symbols, this thread's eight groups of four (8 bytes a load, at any 2-byte boundary); a chunk
+    // shorter than that: markers into what is left of the window before it
     auto tail = [&](uint32_t c, uint64_t off, uint64_t (&v)[PER]) {
         if (off != NONE) {
             const uint16_t *t0 = sym + off;
@@ -676,39 +691,83 @@ __global__ __launch_bounds__(1024) void k_gz_windows(const uint16_t *sym, const 
     auto step = [&](uint32_t c, uint64_t (&v)[PER]) {
         const uint64_t off_use = off_next;
         off_next = tail_at(c + 3u);
-        uint8_t *wout = d_win + (size_t)c * WINDOW;
-        for (uint32_t p = tid * 16u; p < WINDOW; p += 1024u * 16u)
-            *reinterpret_cast<uint4 *>(wout + p) = *reinterpret_cast<const uint4 *>(&W[cur][p]);
+        const T *Wc = W0 + cur * WINDOW;
+        T *Wn = W0 + (cur ^ 1u) * WINDOW;
+        if (BYTES && d_win) {
+            uint8_t *wout = d_win + (size_t)c * WINDOW;
+            for (uint32_t p = tid * 16u; p < WINDOW; p += 1024u * 16u)
+                *reinterpret_cast<uint4 *>(wout + p) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(Wc) + p);
+        }
 #pragma unroll
         for (uint32_t i = 0; i < PER; i++) {
             const uint64_t x = v[i];
-            uint32_t y = ((uint32_t)x & 0xFFu) | (((uint32_t)(x >> 16) & 0xFFu) << 8) | (((uint32_t)(x >> 32) & 0xFFu) << 16) | (((uint32_t)(x >> 48) & 0xFFu) << 24);
-            if (x & 0x8000800080008000ull) {                              // (markers are the exception: only they read the old window --
-                uint32_t wb[4];                                           // four reads in flight, then four selects)
+            const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+            const uint32_t at = (i * 1024u + tid) * 4u;
+            if (BYTES) {
+                uint32_t y = __builtin_amdgcn_perm(xh, xl, 0x06040200u);  // the four symbols' low bytes
+                if ((xl | xh) & 0x80008000u) {                            // (markers are the exception: only they read the old window --
+                    uint32_t wb[4];                                       // four reads in flight, then four selects)
 #pragma unroll
-                for (uint32_t q = 0; q < 4u; q++) wb[q] = W[cur][(uint32_t)(x >> (16u * q)) & 0x7FFFu];
+                    for (uint32_t q = 0; q < 4u; q++) wb[q] = (uint32_t)Wc[(uint32_t)(x >> (16u * q)) & 0x7FFFu];
 #pragma unroll
-                for (uint32_t q = 0; q < 4u; q++)
-                    if ((x >> (16u * q)) & 0x8000u) y = (y & ~(0xFFu << (8u * q))) | (wb[q] << (8u * q));
+                    for (uint32_t q = 0; q < 4u; q++)
+                        if ((x >> (16u * q)) & 0x8000u) y = (y & ~(0xFFu << (8u * q))) | (wb[q] << (8u * q));
+                }
+                *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(Wn) + at) = y;
+            } else {
+                uint64_t y = x;
+                if ((xl | xh) & 0x80008000u) {
+                    uint32_t wb[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; q++) wb[q] = (uint32_t)Wc[(uint32_t)(x >> (16u * q)) & 0x7FFFu];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; q++)
+                        if ((x >> (16u * q)) & 0x8000u) y = (y & ~(0xFFFFull << (16u * q))) | ((uint64_t)wb[q] << (16u * q));
+                }
+                *reinterpret_cast<uint64_t *>(reinterpret_cast<uint16_t *>(Wn) + at) = y;
             }
-            *reinterpret_cast<uint32_t *>(&W[cur ^ 1u][(i * 1024u + tid) * 4u]) = y;
         }
-        if (c + 2u < nchunks) tail(c + 2u, off_use, v);
+        if (c + 2u < c1) tail(c + 2u, off_use, v);
         // (the workgroup's LDS writes, not its loads from memory: __syncthreads would wait for those too)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         cur ^= 1u;
     };
     uint64_t va[PER], vb[PER];
-    if (nchunks) tail(0, tail_at(0), va);
-    if (nchunks > 1u) tail(1, tail_at(1), vb);
-    off_next = tail_at(2);
+    tail(c0, tail_at(c0), va);
+    if (c0 + 1u < c1) tail(c0 + 1u, tail_at(c0 + 1u), vb);
+    off_next = tail_at(c0 + 2u);
     __syncthreads();
-    for (uint32_t c = 0; c < nchunks; c += 2u) {
+    for (uint32_t c = c0; c < c1; c += 2u) {
         step(c, va);
-        if (c + 1u < nchunks) step(c + 1u, vb);
+        if (c + 1u < c1) step(c + 1u, vb);
     }
-    for (uint32_t p = tid * 16u; p < WINDOW; p += 1024u * 16u)
-        *reinterpret_cast<uint4 *>(carry + p) = *reinterpret_cast<const uint4 *>(&W[cur][p]);
+    if (seg_out) {
+        T *dst = seg_out + (size_t)blockIdx.x * WINDOW;
+        const T *Wc = W0 + cur * WINDOW;
+        for (uint32_t p = tid; p < WINDOW; p += 1024u) dst[p] = Wc[p];
+    }
+}
+
+// the window in front of every segment (seg_win + 32768 s), through the segments' maps, in order; carry: in, the window in front
+// of the first chunk; out, the window behind the last
+__global__ __launch_bounds__(1024) void k_gz_seg_windows(const uint16_t *maps, uint32_t nseg, uint8_t *seg_win, uint8_t *carry) {
+    __shared__ uint8_t W[2][WINDOW];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t p = tid; p < WINDOW; p += 1024u) W[0][p] = carry[p];
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t sgm = 0; sgm < nseg; sgm++) {
+        const uint16_t *mp = maps + (size_t)sgm * WINDOW;
+        uint8_t *wout = seg_win + (size_t)sgm * WINDOW;
+        for (uint32_t p = tid; p < WINDOW; p += 1024u) {
+            wout[p] = W[cur][p];
+            const uint32_t y = mp[p];
+            W[cur ^ 1u][p] = (y & 0x8000u) ? W[cur][y & 0x7FFFu] : (uint8_t)y;
+        }
+        __syncthreads();
+        cur ^= 1u;
+    }
+    for (uint32_t p = tid; p < WINDOW; p += 1024u) carry[p] = W[cur][p];
 }
 
 }  // namespace tdgz2

@@ -220,10 +220,10 @@ struct td_handle {
                    hipEvent_t copied = nullptr; } gslot[2];
     DevBuf<uint32_t> d_gzflag;
     // ordinary gzip decoded on the GPU (count_gzip_gpu, gz_gpu.hpp): the whole file's buffers, kept between files
-    struct GzGpu { DevBuf<uint8_t> d_in, d_out, d_win, d_carry; DevBuf<uint32_t> d_tok, d_crc; DevBuf<uint16_t> d_sym; DevBuf<tdgz2::Chunk> d_chunks;
+    struct GzGpu { DevBuf<uint8_t> d_in, d_out, d_win, d_carry, d_segwin; DevBuf<uint16_t> d_maps; DevBuf<uint32_t> d_tok, d_crc; DevBuf<uint16_t> d_sym; DevBuf<tdgz2::Chunk> d_chunks;
                    DevBuf<tdgz2::ChunkOut> d_res; DevBuf<uint64_t> d_found, d_symoff; DevBuf<tdgz::Block> d_blk;
                    void release() { d_in.release(); d_out.release(); d_win.release(); d_carry.release(); d_tok.release(); d_crc.release(); d_sym.release();
-                                    d_chunks.release(); d_res.release(); d_found.release(); d_symoff.release(); d_blk.release(); } } gzgpu;
+                                    d_chunks.release(); d_res.release(); d_found.release(); d_symoff.release(); d_blk.release(); d_segwin.release(); d_maps.release(); } } gzgpu;
     int last_gz_route = 0;                    // how the last .gz file was decoded: 1 Huffman + LZ77 on the GPU, 0 otherwise
     int gpu_huffman = 1;                      // ordinary gzip: Huffman decoding on the GPU too (0: host threads decode, the GPU resolves)
     uint64_t gz_gpu_min = (uint64_t)8 << 20;  // ... for files of this many compressed bytes and more
@@ -1684,7 +1684,22 @@ int gz_gpu_inflate(td_handle *h, const char *path, uint64_t *total_out, bool *no
     hipLaunchKernelGGL(tdgz2::k_gz_lz, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
                        g.d_tok.p, g.d_chunks.p, g.d_res.p, g.d_symoff.p, nchunks, g.d_sym.p);
     mark(1);
-    hipLaunchKernelGGL(tdgz2::k_gz_windows, dim3(1), dim3(1024), 0, st, g.d_sym.p, g.d_symoff.p, g.d_res.p, nchunks, g.d_win.p, g.d_carry.p);
+    {   // the windows: segments of chunks (gz_gpu.hpp, 5.)
+        const uint32_t seg_len = 32, nseg = (nchunks + seg_len - 1) / seg_len;
+        rc = g.d_maps.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return rc;
+        rc = g.d_segwin.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return rc;
+        static bool attr_done = false;
+        if (!attr_done) {
+            HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)tdgz2::WINDOW));
+            HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)tdgz2::WINDOW));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(tdgz2::k_gz_windows<uint16_t>, dim3(nseg), dim3(1024), 4 * tdgz2::WINDOW, st, g.d_sym.p, g.d_symoff.p, g.d_res.p, nchunks, seg_len,
+                           (const uint16_t *)nullptr, g.d_maps.p, (uint8_t *)nullptr);
+        hipLaunchKernelGGL(tdgz2::k_gz_seg_windows, dim3(1), dim3(1024), 0, st, g.d_maps.p, nseg, g.d_segwin.p, g.d_carry.p);
+        hipLaunchKernelGGL(tdgz2::k_gz_windows<uint8_t>, dim3(nseg), dim3(1024), 2 * tdgz2::WINDOW, st, g.d_sym.p, g.d_symoff.p, g.d_res.p, nchunks, seg_len,
+                           (const uint8_t *)g.d_segwin.p, (uint8_t *)nullptr, g.d_win.p);
+    }
     mark(2);
     std::vector<uint32_t> crcs(nblk);
     uint32_t flag = 0;
