@@ -1,7 +1,8 @@
 // k_fast4: the main pass of the free-running path with the workgroup's waves in TWO ROLES and no workgroup barrier
-// in the tile loop.  An experiment that is kept -- parity-green in every kernel-mode test, td_set_option("kernel", 4) --
-// and that LOSES to k_fast2 by 5 % at the bench shape (profiles/r04_final/k_fast4_*.txt); the default stays
-// k_fast2.
+// in the tile loop.  The DEFAULT main pass (td_set_option("kernel", 4)) since the split of the waves between the roles
+// follows the input's line density: 10.1-10.9 ms a step at the bench shape against k_fast2's 10.9-11.2 on the same boxes, and
+// ahead of it at every read length from 36 to 250 bp (profiles/r04_final/k_fast4_*.txt).  With a fixed 11 + 5
+// it had been 5 % behind.
 //
 // k_fast2 (kernel_fast2.hpp) takes every tile through phases A-B (all four waves: terminators, lists of line starts),
 // a barrier, phases C-D (the wanted lines matched by the two waves whose lanes they fill) and a second barrier: per
@@ -9,7 +10,7 @@
 // 72 % at best -- and every wave stands at two barriers behind the slowest.  Here a workgroup is sixteen waves, one
 // workgroup per CU, all of the CU's LDS one ring of five 24 KiB tiles:
 //
-//   producers (11 waves)   stream the FASTQ.  A job is a quarter of a tile (6 KiB); job 4 k + q goes to producer (4 k + q) mod 11;
+//   producers (7..13 waves: k_f4_estimate below)   stream the FASTQ.  A job is a quarter of a tile (6 KiB); job 4 k + q goes to producer (4 k + q) mod their number;
 //                          a producer's next TWO jobs' bytes are in flight in registers.  Per job: raw bytes -> the tile's
 //                          slot in LDS, terminator masks, the list of the quarter's line starts (k_fast2's phases A and B,
 //                          nothing shared between the producers).  The producer whose arrival makes four ("closer") waits
@@ -17,7 +18,7 @@
 //                          run or takes the vote at its start, writes the tile's word for k_resolve, and publishes how many
 //                          wanted lines (every fourth line start) the tile holds and how many the workgroup's tiles held
 //                          before it.
-//   consumers (5 waves)    match.  The wanted lines of the workgroup's tiles form ONE sequence; a consumer claims the next 64
+//   consumers (the others)  match.  The wanted lines of the workgroup's tiles form ONE sequence; a consumer claims the next 64
 //                          of it (a compare-and-swap on a cursor in LDS) whatever tiles they lie in -- always full lanes,
 //                          whatever the read length -- finds each lane's tile among the ring's slots, reads the lines'
 //                          pieces into registers, takes the lines off their tiles' counts (the consumer that takes a tile's
@@ -36,9 +37,9 @@
 // waves; eight waves (4 + 4, then 5 + 3 with the quarter-tile jobs) 13.0-13.9 ms -- both roles wait for each other half
 // of their time, a ring of three tiles is too short for a matching pass that lasts two tiles' production; sixteen waves
 // with seven 16 KiB slots 12.5 ms at 11 + 5 (10 + 6: 12.7, 12 + 4: 13.5, 13 + 3: 16.1); with five 24 KiB slots (fewer, larger
-// jobs) 11.6-11.8 ms against 11.1-11.2 -- the form kept; consumers without their priority 13.1, 32 KiB tiles 20.3
-// (registers), short passes taken eagerly by idle consumers 11.6-11.7.  The instruction count per byte equals
-// k_fast2's; what the roles buy in balance they lose again in waiting at the hand-offs.
+// jobs) 11.6-11.8 ms against 11.1-11.2; consumers without their priority 13.1, 32 KiB tiles 20.3 (registers), short passes
+// taken eagerly by idle consumers 11.6-11.7; the split by read length (36 bp: 8 + 8 ... 250 bp: 12 + 4): ahead of k_fast2
+// everywhere -- the consumers never wait, the producers wait for slots: how many consumers a tile's lines need is the input's.
 // Tiles that are not "regular" (the buffer's first and last, bytes >= 0x80, '\r' at the end of a chunk next to another
 // wave's bytes, more line starts than a list holds) are only counted here (terminators) and flagged TI_SKIP for the
 // fix-up pass (k_fast<6, W, true>: the same 24 KiB tile), as in k_fast2.
@@ -51,7 +52,7 @@ namespace tdk {
 #define TD_F4_WAVES 16              // waves of a workgroup (a multiple of four: the waves go to the four SIMDs in turn)
 #endif
 #ifndef TD_F4_NPROD
-#define TD_F4_NPROD 11              // producer waves among them (they take the quarter-tile jobs in turn); the others match
+#define TD_F4_NPROD 11              // producer waves among them where no estimate is given (they take the quarter-tile jobs in turn); the others match
 #endif
 #ifndef TD_F4_SLOTS
 #define TD_F4_SLOTS 5               // tiles the ring in LDS holds
@@ -63,7 +64,7 @@ constexpr int F4_PROD = 4 /* quarters of a tile */, F4_WAVES = TD_F4_WAVES, F4_B
 constexpr int F4_CPT = TD_F4_CPT;                           // 16-byte chunks per producer lane and tile
 constexpr uint32_t F4_WCH = F4_CPT * 64;                    // chunks per producer and tile
 constexpr uint32_t F4_WBYTES = F4_WCH * 16;
-constexpr uint32_t F4_TILE = F4_PROD * F4_WBYTES;           // 16 KiB
+constexpr uint32_t F4_TILE = F4_PROD * F4_WBYTES;           // 24 KiB
 constexpr int F4_SLOTS = TD_F4_SLOTS;
 constexpr uint32_t F4_SPIN_LIMIT = 1u << 18;
 #ifndef TD_F4_EAGER_MIN

@@ -229,6 +229,7 @@ struct td_handle {
     uint64_t gz_gpu_min = (uint64_t)8 << 20;  // ... for files of this many compressed bytes and more
     uint32_t gz_gpu_terr_kb = 128;            // ... one chunk per this much compressed data
     int gz_gpu_verify = 0;                    // ... the block search decodes a block before it believes its header
+    uint32_t gz_gpu_seg_kb = 1u << 20, gz_gpu_margin_kb = 16384;      // ... a segment of compressed data (1 GiB), and how far its last chunk may run past it
     int gz_gpu_false_every = 0;               // (tests) every n-th found block start is moved by some bits: a false start
     int gpu_resolve = 1;                      // ordinary gzip of 8 MiB and more: markers -> bytes and CRC-32 on the GPU (0: all on the host)
     uint8_t *d_zscratch = nullptr; uint32_t *d_crctab = nullptr;
@@ -242,7 +243,7 @@ struct td_handle {
     int tile_kb2 = 0;                         // k_fast2's tile (16 | 24 | 32 KiB; 0 = fast2_auto_tile)
     int run = 8;                              // k_fast2: consecutive tiles per workgroup turn (measured: 4-16 alike, 1 and 64+ slower)
     int hot_cache = 1;                        // k_fast2: count through the per-wave hot-cell cache
-    int f4_nprod = 0;                         // k_fast4: producer waves of sixteen (0: TD_F4_NPROD)
+    int f4_nprod = 0;                         // k_fast4: producer waves of sixteen (0: k_f4_estimate's, from the buffer's line density)
     uint64_t fast_max_matrix = 1ull << 32;    // the free-running kernel addresses cells as base + 32-bit byte offset
     uint32_t debug_ablate = 0;
     double table_load = 0.25;
@@ -1489,260 +1490,399 @@ struct MappedFile {
 // host decoder (count_gzip_dev) should take the file -- too small, no room on the device, a second member, or a stream this
 // decoder does not chain.
 extern "C" int td_load_file_range(td_handle *h, const char *path, uint64_t offset, uint64_t length, void *d_dst);
-// the file's text in h->gzgpu.d_out (*total bytes), checked
-int gz_gpu_inflate(td_handle *h, const char *path, uint64_t *total_out, bool *not_applicable) {
-    using FI = tdhost::FastInflate;
-    using PI = tdhost::ParInflate;
-    *not_applicable = true;
-    const bool verbose = getenv("TAGDIG_INFLATE_STATS") != nullptr;
-    auto skip = [&](const char *why) { if (verbose) fprintf(stderr, "gz_gpu_inflate: %s -- the host decoder takes the file\n", why); return TD_OK; };
-    MappedFile mf(path);
-    if (!mf.ok || mf.n < h->gz_gpu_min || mf.n < 64) return skip("small file");
-    const uint8_t *body = nullptr; const char *herr = nullptr;
-    if (FI::parse_member_header(mf.p, mf.p + mf.n, &body, &herr, true) != 1) return skip("no gzip header");
-    if (mf.n >= ((uint64_t)1 << 40)) return skip("file too large");
-    { uint32_t bs = 0, hs = 0; if (tdhost::GzSource::bgzf_header(mf.p, mf.n, &bs, &hs)) return skip("a BGZF file (many members)"); }
-    const uint64_t n = mf.n, first_bit = (uint64_t)(body - mf.p) * 8, in_bits = n * 8;
-    const uint64_t terr = (uint64_t)h->gz_gpu_terr_kb << 10;
-    const uint32_t nterr = (uint32_t)((n + terr - 1) / terr);
-    const uint64_t tok_total = 4 * n + (uint64_t)nterr * 4096;              // four tokens per compressed byte and a little per chunk
-    {   // room: the compressed bytes, the tokens, and -- FASTQ deflates to a quarter or a fifth -- twelve bytes per compressed byte
-        // of symbols, text and windows at the least (exactly known after the decoding; checked again there)
+// The file goes through the device in SEGMENTS of compressed bytes (1 GiB; what the buffers are sized for): a segment's first
+// chunk starts exactly where the segment before ended -- a block boundary, or a member's first block -- its other chunks
+// where k_gz_find finds block starts, its last chunk ends at the first block boundary at or past the segment's end (the
+// upload reaches 16 MiB further), and the 32 KiB window behind it stays on the device for the next segment (d_carry).  A
+// member's end closes a segment: its CRC-32 and length are checked, the next member starts with an empty window.
+struct GzGpuStream {
+    td_handle *h = nullptr;
+    const char *path = nullptr;
+    MappedFile mf;
+    bool verbose = false;
+    uint64_t n = 0;
+    uint64_t next_bit = 0;            // where the next segment's first chunk starts (absolute bit of the file)
+    uint64_t member_out = 0;          // bytes the current member has inflated to so far
+    uint32_t crc_run = 0;
+    uint64_t segments = 0;
+    bool file_done = false, member_fresh = true;
+    const char *why = "";             // (give-ups)
+    double t_up = 0, t_find = 0, t_tok = 0, t_rest = 0;
+    uint64_t SEG = (uint64_t)1 << 30, MARGIN = (uint64_t)16 << 20;       // (options gz_gpu_seg_kb, gz_gpu_margin_kb)
+
+    explicit GzGpuStream(td_handle *hh, const char *p) : h(hh), path(p), mf(p) {
+        verbose = getenv("TAGDIG_INFLATE_STATS") != nullptr;
+        SEG = (uint64_t)hh->gz_gpu_seg_kb << 10; MARGIN = (uint64_t)hh->gz_gpu_margin_kb << 10;
+    }
+
+    // false: this file is not for the device decoder (why says why); nothing has been touched
+    bool open() {
+        using FI = tdhost::FastInflate;
+        if (!mf.ok || mf.n < h->gz_gpu_min || mf.n < 64) { why = "small file"; return false; }
+        n = mf.n;
+        if (n >= ((uint64_t)1 << 44)) { why = "file too large"; return false; }
+        { uint32_t bs = 0, hs = 0; if (tdhost::GzSource::bgzf_header(mf.p, mf.n, &bs, &hs)) { why = "a BGZF file (many members)"; return false; } }
+        const uint8_t *body = nullptr; const char *herr = nullptr;
+        if (FI::parse_member_header(mf.p, mf.p + mf.n, &body, &herr, true) != 1) { why = "no gzip header"; return false; }
+        next_bit = (uint64_t)(body - mf.p) * 8;
+        // room: a segment's compressed bytes, its tokens (16 bytes per compressed byte) and -- FASTQ deflates to a fifth -- its
+        // symbols, text and windows (checked again when they are known)
+        const uint64_t seg = std::min<uint64_t>(n, SEG + MARGIN);
         size_t free_b = 0, total_b = 0;
-        HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t have = free_b + h->gzgpu.d_in.n + h->gzgpu.d_tok.n * 4 + h->gzgpu.d_sym.n * 2 + h->gzgpu.d_out.n + h->gzgpu.d_win.n;
-        if (n + tok_total * 4 + 16 * n + ((uint64_t)1 << 30) > have) return skip("no room on the device");
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); why = "no device"; return false; }
+        const td_handle::GzGpu &g = h->gzgpu;
+        const uint64_t have = free_b + g.d_in.n + g.d_tok.n * 4 + g.d_sym.n * 2 + g.d_out.n + g.d_win.n;
+        if (seg * 33 + ((uint64_t)1 << 30) > have) { why = "no room on the device"; return false; }
+        return true;
     }
-    td_handle::GzGpu &g = h->gzgpu;
-    const double t0 = PI::now();
-    int rc = g.d_in.ensure(n + 8192); if (rc) return rc;
-    const size_t in_cap = ((n + 4096 + 15) & ~(size_t)15);                    // readable bytes (zeros behind the file)
-    HIPCHK(hipMemsetAsync(g.d_in.p + (n & ~(size_t)15), 0, in_cap - (n & ~(size_t)15), h->copy_stream));
-    HIPCHK(hipStreamSynchronize(h->copy_stream));
-    rc = td_load_file_range(h, path, 0, n, g.d_in.p); if (rc) return rc;
-    const uint64_t nwords = in_cap / 4;
-    const double t1 = PI::now();
-    // 1. block starts
-    rc = g.d_found.ensure(nterr + 4); if (rc) return rc;
-    hipStream_t st = h->work_stream;
-    HIPCHK(hipMemsetAsync(g.d_found.p + nterr, 0, 32, st));
-    if (nterr > 1)
-        hipLaunchKernelGGL(tdgz2::k_gz_find, dim3((nterr - 1 + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
-                           g.d_in.p, in_bits, nwords, first_bit, terr * 8, nterr, g.d_found.p, (uint32_t)h->gz_gpu_verify);
-    HIPCHK(hipGetLastError());
-    std::vector<uint64_t> found(nterr);
-    if (nterr > 1) HIPCHK(hipMemcpyAsync(found.data() + 1, g.d_found.p + 1, (size_t)(nterr - 1) * 8, hipMemcpyDeviceToHost, st));
-    uint64_t fstat[2] = {0, 0};
-    if (verbose) HIPCHK(hipMemcpyAsync(fstat, g.d_found.p + nterr, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (verbose) fprintf(stderr, "gz_gpu_inflate: block search: %lu headers passed the checks, %lu of them were block starts\n", (unsigned long)fstat[0], (unsigned long)fstat[1]);
-    found[0] = first_bit;
-    if (h->gz_gpu_false_every > 0)
-        for (uint32_t t = 1; t < nterr; t++)
-            if (found[t] != tdgz2::NONE && t % (uint32_t)h->gz_gpu_false_every == 0 && found[t] + 4099 < in_bits) found[t] += 4099;
-    const double t2 = PI::now();
-    // 2. the chunks between them, decoded into tokens
-    std::vector<tdgz2::Chunk> chunks;
-    for (uint32_t t = 0; t < nterr; t++) if (found[t] != tdgz2::NONE) { tdgz2::Chunk c{}; c.start_bit = found[t]; chunks.push_back(c); }
-    uint32_t nchunks = (uint32_t)chunks.size();
-    {
-        uint64_t at = 0;
-        for (uint32_t i = 0; i < nchunks; i++) {
-            chunks[i].stop_bit = i + 1 < nchunks ? chunks[i + 1].start_bit : ~0ull;
-            const uint64_t span = ((i + 1 < nchunks ? chunks[i + 1].start_bit : in_bits) - chunks[i].start_bit + 7) / 8;
-            const uint64_t cap = std::min<uint64_t>(4 * span + 4096, 0xFFFFFF00u);
-            chunks[i].tok_off = at; chunks[i].tok_cap = (uint32_t)cap;
-            at += (cap + 63) & ~(uint64_t)63;
-        }
-        rc = g.d_tok.ensure(at + 64); if (rc) return rc;
-    }
-    rc = g.d_chunks.ensure(2 * (size_t)nchunks); if (rc) return rc;               // (behind the chunks: the ones decoded a second time)
-    rc = g.d_res.ensure(2 * (size_t)nchunks); if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)nchunks * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(g.d_res.p, 0, (size_t)nchunks * sizeof(tdgz2::ChunkOut), st));
-    hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
-                       g.d_in.p, in_bits, nwords, g.d_chunks.p, nchunks, g.d_tok.p, g.d_res.p);
-    HIPCHK(hipGetLastError());
-    std::vector<tdgz2::ChunkOut> res(nchunks);
-    HIPCHK(hipMemcpyAsync(res.data(), g.d_res.p, (size_t)nchunks * sizeof(tdgz2::ChunkOut), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const double t3 = PI::now();
-    // 3. the chain: every chunk begins where its predecessor ended.  A chunk that ran past its successor's start met a false
-    // one there: the successor is dropped, and what lies between this chunk's end and the next start is decoded in a second
-    // launch (into the dropped chunk's token buffer).  The last chunk ends the member, and the file.
-    std::vector<uint8_t> dead(nchunks, 0);
-    for (int round = 0;; round++) {
-        std::vector<uint32_t> redo;
-        uint32_t i = 0;
-        bool assumed = false;                 // behind this round's first gap the chain is a guess: nothing there refuses the file yet
-        while (true) {
-            const tdgz2::ChunkOut &o = res[i];
-            if (assumed && (o.status != tdgz2::S_BOUNDARY && o.status != tdgz2::S_FINAL)) break;
-            if (o.status == tdgz2::S_TOKCAP) return skip("a chunk's tokens overflow their buffer");
-            if (o.status == tdgz2::S_UNUSUAL) return skip("a Huffman code this decoder leaves to zlib");
-            if (o.status == tdgz2::S_ERR) return skip("invalid DEFLATE data");
-            uint32_t j = i + 1;
-            while (j < nchunks && dead[j]) j++;
-            if (j == nchunks) {
-                if (assumed) break;
-                if (o.status != tdgz2::S_FINAL) return skip("the stream does not end with the file");
-                break;
-            }
-            if (o.status == tdgz2::S_FINAL) { if (assumed) break; return skip("more than one member"); }
-            if (o.end_bit == chunks[j].start_bit) { i = j; continue; }
-            // chunks[j] is no block start (the chunk in front of it was decoded up to a boundary at or past it)
-            if (o.end_bit < chunks[j].start_bit) { if (assumed) break; return skip("a chunk ends before its successor's start"); }
-            if (assumed) break;               // (a guess must not drop chunks)
-            uint32_t k = j + 1;
-            while (k < nchunks && (dead[k] || chunks[k].start_bit < o.end_bit)) { dead[k] = 1; k++; }
-            if (k < nchunks && chunks[k].start_bit == o.end_bit) { dead[j] = 1; i = k; continue; }
-            // the gap [end, next start): chunk j's place and buffer
-            const uint64_t gap_end = k < nchunks ? chunks[k].start_bit : in_bits;
-            if ((gap_end - o.end_bit + 7) / 8 * 4 + 4096 > chunks[j].tok_cap) return skip("a false block start in front of a long stretch without one");
-            chunks[j].start_bit = o.end_bit;
-            chunks[j].stop_bit = k < nchunks ? chunks[k].start_bit : ~0ull;
-            redo.push_back(j);
-            // (the walk goes on behind the gap as if its decoding will end on the next start; the next round looks at that)
-            if (k == nchunks) break;
-            i = k;
-            assumed = true;
-        }
-        if (redo.empty()) break;
-        if (round >= 8) return skip("too many false block starts");
-        // the gaps of this round in one launch (a false start is rare: the header checks pass for about one position in 10^10)
-        const uint32_t nr = (uint32_t)redo.size();
-        std::vector<tdgz2::Chunk> rc_in(nr);
-        std::vector<tdgz2::ChunkOut> rc_out(nr);
-        for (uint32_t q = 0; q < nr; q++) rc_in[q] = chunks[redo[q]];
-        HIPCHK(hipMemcpyAsync(g.d_chunks.p + nchunks, rc_in.data(), (size_t)nr * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nr + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st, g.d_in.p, in_bits, nwords,
-                           g.d_chunks.p + nchunks, nr, g.d_tok.p, g.d_res.p + nchunks);
+
+    // The next segment's text behind `carry` bytes at the front of gzgpu.d_out.  Returns TD_OK and *gave_up = false: *nbytes
+    // of text, *last says whether the file is through; *gave_up = true: the decoder leaves the file (why); else an error code.
+    int next(size_t carry, uint64_t *nbytes, bool *last, bool *gave_up) {
+        using FI = tdhost::FastInflate;
+        using PI = tdhost::ParInflate;
+        *gave_up = false; *nbytes = 0; *last = false;
+        auto giveup = [&](const char *w) { why = w; *gave_up = true; if (verbose) fprintf(stderr, "gz_gpu_inflate: %s (segment %lu)\n", w, (unsigned long)segments); return TD_OK; };
+        td_handle::GzGpu &g = h->gzgpu;
+        hipStream_t st = h->work_stream;
+        const double t0 = PI::now();
+        // the segment's bytes
+        const uint64_t base = (next_bit >> 3) & ~(uint64_t)4095;
+        const uint64_t seg_end = std::min<uint64_t>(n, base + SEG), up_end = std::min<uint64_t>(n, seg_end + MARGIN);
+        const uint64_t nb = up_end - base;
+        const bool to_file_end = seg_end == n;
+        int rc = g.d_in.ensure(std::min<uint64_t>(n, SEG + MARGIN) + 8192 + 4096); if (rc) return rc;
+        const size_t in_cap = ((nb + 4096 + 15) & ~(size_t)15);
+        HIPCHK(hipStreamSynchronize(st));                                   // (the segment before may still read d_in)
+        HIPCHK(hipMemsetAsync(g.d_in.p + (nb & ~(size_t)15), 0, in_cap - (nb & ~(size_t)15), h->copy_stream));
+        HIPCHK(hipStreamSynchronize(h->copy_stream));
+        rc = td_load_file_range(h, path, base, nb, g.d_in.p); if (rc) return rc;
+        const uint64_t nwords = in_cap / 4, in_bits = nb * 8, first_bit = next_bit - base * 8;
+        const uint64_t stop_seg = to_file_end ? ~0ull : (seg_end - base) * 8;
+        const double t1 = PI::now();
+        // 1. block starts
+        const uint64_t terr = (uint64_t)h->gz_gpu_terr_kb << 10;
+        const uint32_t nterr = (uint32_t)((seg_end - base + terr - 1) / terr);
+        rc = g.d_found.ensure(nterr + 4); if (rc) return rc;
+        HIPCHK(hipMemsetAsync(g.d_found.p + nterr, 0, 32, st));
+        if (nterr > 1)
+            hipLaunchKernelGGL(tdgz2::k_gz_find, dim3((nterr - 1 + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
+                               g.d_in.p, in_bits, nwords, first_bit, terr * 8, nterr, g.d_found.p, (uint32_t)h->gz_gpu_verify);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(rc_out.data(), g.d_res.p + nchunks, (size_t)nr * sizeof(tdgz2::ChunkOut), hipMemcpyDeviceToHost, st));
+        std::vector<uint64_t> found(nterr);
+        if (nterr > 1) HIPCHK(hipMemcpyAsync(found.data() + 1, g.d_found.p + 1, (size_t)(nterr - 1) * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        for (uint32_t q = 0; q < nr; q++) res[redo[q]] = rc_out[q];
-        if (verbose) fprintf(stderr, "gz_gpu_inflate: %u false block starts; the stretches behind them decoded again\n", nr);
-    }
-    HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)nchunks * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(g.d_res.p, res.data(), (size_t)nchunks * sizeof(tdgz2::ChunkOut), hipMemcpyHostToDevice, st));
-    // the chunks that count, compacted (the kernels behind this walk them by index)
-    {
-        uint32_t w = 0;
-        for (uint32_t i = 0; i < nchunks; i++) if (!dead[i]) { chunks[w] = chunks[i]; res[w] = res[i]; w++; }
-        if (w != nchunks) {
-            chunks.resize(w); res.resize(w);
-            HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)w * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(g.d_res.p, res.data(), (size_t)w * sizeof(tdgz2::ChunkOut), hipMemcpyHostToDevice, st));
+        found[0] = tdgz2::NONE;
+        if (h->gz_gpu_false_every > 0)
+            for (uint32_t t = 1; t < nterr; t++)
+                if (found[t] != tdgz2::NONE && t % (uint32_t)h->gz_gpu_false_every == 0 && found[t] + 4099 < in_bits) found[t] += 4099;
+        const double t2 = PI::now();
+        // 2. the chunks between them, decoded into tokens
+        std::vector<tdgz2::Chunk> chunks;
+        { tdgz2::Chunk c{}; c.start_bit = first_bit; chunks.push_back(c); }
+        for (uint32_t t = 0; t < nterr; t++) if (found[t] != tdgz2::NONE && found[t] > first_bit) { tdgz2::Chunk c{}; c.start_bit = found[t]; chunks.push_back(c); }
+        uint32_t nchunks = (uint32_t)chunks.size();
+        {
+            uint64_t at = 0;
+            for (uint32_t i = 0; i < nchunks; i++) {
+                chunks[i].stop_bit = i + 1 < nchunks ? chunks[i + 1].start_bit : stop_seg;
+                // (the last chunk runs to the first block boundary behind the segment's end: room for a block of the margin's size)
+                const uint64_t span_end = i + 1 < nchunks ? chunks[i + 1].start_bit : in_bits;
+                const uint64_t span = (span_end - chunks[i].start_bit + 7) / 8;
+                const uint64_t cap = std::min<uint64_t>(4 * span + 4096, 0xFFFFFF00u);
+                chunks[i].tok_off = at; chunks[i].tok_cap = (uint32_t)cap;
+                at += (cap + 63) & ~(uint64_t)63;
+            }
+            rc = g.d_tok.ensure(at + 64); if (rc) return rc;
         }
-    }
-    nchunks = (uint32_t)chunks.size();
-    std::vector<uint64_t> sym_off(nchunks + 1);
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < nchunks; i++) { sym_off[i] = total; total += res[i].out_len; }
-    sym_off[nchunks] = total;
-    const uint64_t trailer = (res[nchunks - 1].end_bit + 7) / 8;
-    if (trailer + 8 > n) return skip("truncated member");
-    for (uint64_t k = trailer + 8; k < n; k++) if (mf.p[k]) return skip("bytes behind the member");
-    uint32_t want_crc, want_len;
-    memcpy(&want_crc, mf.p + trailer, 4); memcpy(&want_len, mf.p + trailer + 4, 4);
-    if (want_len != (uint32_t)total) return skip("the member fails its length check");
-    // 4.-6. symbols, windows, bytes, CRC-32
-    const uint64_t nblk64 = [&]() { uint64_t k = 0; for (uint32_t i = 0; i < nchunks; i++) k += (res[i].out_len + tdgz::BLOCK_SYMS - 1) / tdgz::BLOCK_SYMS; return k; }();
-    if (nblk64 >= 0x7FFFFFFFull) return skip("file too large");
-    const uint32_t nblk = (uint32_t)nblk64;
-    {
-        size_t free_b = 0, total_b = 0;
-        HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t need = 2 * total + total + (uint64_t)nchunks * tdgz2::WINDOW + (uint64_t)nblk * 40 + ((uint64_t)64 << 20);
-        if (need > free_b + g.d_sym.n * 2 + g.d_out.n + g.d_win.n) return skip("no room on the device for the text");
-    }
-    rc = g.d_sym.ensure(total + 64); if (rc) return rc;
-    rc = g.d_out.ensure(total + 4096 + (total >> 3)); if (rc) return rc;
-    rc = g.d_win.ensure((size_t)nchunks * tdgz2::WINDOW); if (rc) return rc;
-    rc = g.d_carry.ensure(tdgz2::WINDOW); if (rc) return rc;
-    rc = g.d_symoff.ensure(nchunks + 1); if (rc) return rc;
-    rc = g.d_blk.ensure(nblk + 1); if (rc) return rc;
-    rc = g.d_crc.ensure(nblk + 1); if (rc) return rc;
-    rc = h->d_gzflag.ensure(4); if (rc) return rc;
-    if (!h->d_crctab) { bool ok = true; rc = ensure_bgzf_buffers(h, 0, 0, &ok); if (rc) return rc; }      // (the CRC tables)
-    std::vector<tdgz::Block> blocks(nblk);
-    {
-        size_t kb = 0;
-        for (uint32_t i = 0; i < nchunks; i++) {
-            const uint32_t min_idx = tdgz2::WINDOW - (uint32_t)std::min<uint64_t>(tdgz2::WINDOW, sym_off[i]);
-            for (uint64_t o = 0; o < res[i].out_len; o += tdgz::BLOCK_SYMS)
-                blocks[kb++] = tdgz::Block{(sym_off[i] + o) * 2, sym_off[i] + o, (uint32_t)std::min<uint64_t>(tdgz::BLOCK_SYMS, res[i].out_len - o), i, min_idx, 0u};
-        }
-    }
-    HIPCHK(hipMemcpyAsync(g.d_symoff.p, sym_off.data(), (size_t)(nchunks + 1) * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(g.d_blk.p, blocks.data(), (size_t)nblk * sizeof(tdgz::Block), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(g.d_carry.p, 0, tdgz2::WINDOW, st));
-    HIPCHK(hipMemsetAsync(h->d_gzflag.p, 0, 16, st));
-    hipEvent_t ev[5] = {};
-    auto mark = [&](int k) { if (verbose) { if (!ev[k]) (void)hipEventCreate(&ev[k]); (void)hipEventRecord(ev[k], st); } };
-    mark(0);
-    hipLaunchKernelGGL(tdgz2::k_gz_lz, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
-                       g.d_tok.p, g.d_chunks.p, g.d_res.p, g.d_symoff.p, nchunks, g.d_sym.p);
-    mark(1);
-    {   // the windows: segments of chunks (gz_gpu.hpp, 5.)
-        const uint32_t seg_len = 32, nseg = (nchunks + seg_len - 1) / seg_len;
-        rc = g.d_maps.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return rc;
-        rc = g.d_segwin.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return rc;
-        static bool attr_done = false;
-        if (!attr_done) {
-            HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)tdgz2::WINDOW));
-            HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)tdgz2::WINDOW));
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(tdgz2::k_gz_windows<uint16_t>, dim3(nseg), dim3(1024), 4 * tdgz2::WINDOW, st, g.d_sym.p, g.d_symoff.p, g.d_res.p, nchunks, seg_len,
-                           (const uint16_t *)nullptr, g.d_maps.p, (uint8_t *)nullptr);
-        hipLaunchKernelGGL(tdgz2::k_gz_seg_windows, dim3(1), dim3(1024), 0, st, g.d_maps.p, nseg, g.d_segwin.p, g.d_carry.p);
-        hipLaunchKernelGGL(tdgz2::k_gz_windows<uint8_t>, dim3(nseg), dim3(1024), 2 * tdgz2::WINDOW, st, g.d_sym.p, g.d_symoff.p, g.d_res.p, nchunks, seg_len,
-                           (const uint8_t *)g.d_segwin.p, (uint8_t *)nullptr, g.d_win.p);
-    }
-    mark(2);
-    std::vector<uint32_t> crcs(nblk);
-    uint32_t flag = 0;
-    if (nblk) {
-        hipLaunchKernelGGL(tdgz::k_gz_resolve, dim3(nblk), dim3(256), 0, st, (const uint8_t *)g.d_sym.p, g.d_win.p, g.d_out.p, g.d_blk.p, nblk, h->d_gzflag.p);
-        mark(3);
-        hipLaunchKernelGGL(tdgz::k_gz_crc, dim3((nblk + 63) / 64), dim3(64), 0, st, g.d_out.p, g.d_blk.p, nblk, h->d_crctab, g.d_crc.p);
-        mark(4);
+        rc = g.d_chunks.ensure(2 * (size_t)nchunks); if (rc) return rc;               // (behind the chunks: the ones decoded a second time)
+        rc = g.d_res.ensure(2 * (size_t)nchunks); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)nchunks * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(g.d_res.p, 0, (size_t)nchunks * sizeof(tdgz2::ChunkOut), st));
+        hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
+                           g.d_in.p, in_bits, nwords, g.d_chunks.p, nchunks, g.d_tok.p, g.d_res.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(crcs.data(), g.d_crc.p, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
+        std::vector<tdgz2::ChunkOut> res(nchunks);
+        HIPCHK(hipMemcpyAsync(res.data(), g.d_res.p, (size_t)nchunks * sizeof(tdgz2::ChunkOut), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const double t3 = PI::now();
+        // 3. the chain: every chunk begins where its predecessor ended.  A chunk that ran past its successor's start met a false
+        // one there: the successor is dropped, and what lies between this chunk's end and the next start is decoded in a second
+        // launch (into the dropped chunk's token buffer).  A chunk that ends its member ends the segment.
+        std::vector<uint8_t> dead(nchunks, 0);
+        bool member_done = false;
+        for (int round = 0;; round++) {
+            std::vector<uint32_t> redo;
+            uint32_t i = 0;
+            bool assumed = false;                 // behind this round's first gap the chain is a guess: nothing there refuses the file yet
+            member_done = false;
+            while (true) {
+                const tdgz2::ChunkOut &o = res[i];
+                if (assumed && (o.status != tdgz2::S_BOUNDARY && o.status != tdgz2::S_FINAL)) break;
+                if (o.status == tdgz2::S_TOKCAP) return giveup("a chunk's tokens overflow their buffer");
+                if (o.status == tdgz2::S_UNUSUAL) return giveup("a Huffman code this decoder leaves to zlib");
+                if (o.status == tdgz2::S_ERR) return giveup("invalid DEFLATE data (or a block longer than the segments' overlap)");
+                if (o.status == tdgz2::S_FINAL) {
+                    if (assumed) break;
+                    for (uint32_t k = i + 1; k < nchunks; k++) dead[k] = 1;      // (what the search found behind the member's end is not this member's)
+                    member_done = true;
+                    break;
+                }
+                uint32_t j = i + 1;
+                while (j < nchunks && dead[j]) j++;
+                if (j == nchunks) {
+                    if (assumed) break;
+                    if (to_file_end) return giveup("the stream does not end with the file");
+                    if (o.end_bit < stop_seg) return giveup("a chunk ends before the segment does");
+                    break;
+                }
+                if (o.end_bit == chunks[j].start_bit) { i = j; continue; }
+                // chunks[j] is no block start (the chunk in front of it was decoded up to a boundary at or past it)
+                if (o.end_bit < chunks[j].start_bit) { if (assumed) break; return giveup("a chunk ends before its successor's start"); }
+                if (assumed) break;               // (a guess must not drop chunks)
+                uint32_t k = j + 1;
+                while (k < nchunks && (dead[k] || chunks[k].start_bit < o.end_bit)) { dead[k] = 1; k++; }
+                if (k < nchunks && chunks[k].start_bit == o.end_bit) { dead[j] = 1; i = k; continue; }
+                if (k == nchunks && !to_file_end && o.end_bit >= stop_seg) { dead[j] = 1; break; }      // (it ran past the segment's end: the segment's last chunk)
+                // the gap [end, next start): chunk j's place and buffer
+                const uint64_t gap_end = k < nchunks ? chunks[k].start_bit : in_bits;
+                if ((gap_end - o.end_bit + 7) / 8 * 4 + 4096 > chunks[j].tok_cap) return giveup("a false block start in front of a long stretch without one");
+                chunks[j].start_bit = o.end_bit;
+                chunks[j].stop_bit = k < nchunks ? chunks[k].start_bit : stop_seg;
+                redo.push_back(j);
+                // (the walk goes on behind the gap as if its decoding will end on the next start; the next round looks at that)
+                if (k == nchunks) break;
+                i = k;
+                assumed = true;
+            }
+            if (redo.empty()) break;
+            if (round >= 8) return giveup("too many false block starts");
+            // the gaps of this round in one launch (a false start is rare: the header checks pass for about one position in 10^10)
+            const uint32_t nr = (uint32_t)redo.size();
+            std::vector<tdgz2::Chunk> rc_in(nr);
+            std::vector<tdgz2::ChunkOut> rc_out(nr);
+            for (uint32_t q = 0; q < nr; q++) rc_in[q] = chunks[redo[q]];
+            HIPCHK(hipMemcpyAsync(g.d_chunks.p + nchunks, rc_in.data(), (size_t)nr * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nr + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st, g.d_in.p, in_bits, nwords,
+                               g.d_chunks.p + nchunks, nr, g.d_tok.p, g.d_res.p + nchunks);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(rc_out.data(), g.d_res.p + nchunks, (size_t)nr * sizeof(tdgz2::ChunkOut), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (uint32_t q = 0; q < nr; q++) res[redo[q]] = rc_out[q];
+            if (verbose) fprintf(stderr, "gz_gpu_inflate: %u false block starts; the stretches behind them decoded again\n", nr);
+        }
+        // the chunks that count, compacted (the kernels behind this walk them by index)
+        {
+            uint32_t w = 0;
+            for (uint32_t i = 0; i < nchunks; i++) if (!dead[i]) { chunks[w] = chunks[i]; res[w] = res[i]; w++; }
+            chunks.resize(w); res.resize(w);
+            nchunks = w;
+            HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)nchunks * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(g.d_res.p, res.data(), (size_t)nchunks * sizeof(tdgz2::ChunkOut), hipMemcpyHostToDevice, st));
+        }
+        std::vector<uint64_t> sym_off(nchunks + 1);
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < nchunks; i++) { sym_off[i] = total; total += res[i].out_len; }
+        sym_off[nchunks] = total;
+        const uint64_t end_abs = base * 8 + res[nchunks - 1].end_bit;
+        // a member's end: its trailer, and what follows it
+        uint32_t want_crc = 0, want_len = 0;
+        bool next_member = false;
+        uint64_t next_member_bit = 0;
+        if (member_done) {
+            const uint64_t trailer = (end_abs + 7) / 8;
+            if (trailer + 8 > n) return giveup("truncated member");
+            memcpy(&want_crc, mf.p + trailer, 4); memcpy(&want_len, mf.p + trailer + 4, 4);
+            if (want_len != (uint32_t)(member_out + total)) return giveup("the member fails its length check");
+            const uint8_t *body = nullptr; const char *herr = nullptr;
+            const int r = FI::parse_member_header(mf.p + trailer + 8, mf.p + n, &body, &herr, false);
+            if (r < 0) return giveup("bytes behind the member that are no gzip header");
+            if (r == 1) {
+                next_member = true; next_member_bit = (uint64_t)(body - mf.p) * 8;
+                // (a file of many small members is the host decoder's: a segment each would be mostly launches)
+                if (segments == 0 && trailer < ((uint64_t)1 << 20)) return giveup("small members");
+            }
+        }
+        // 4.-6. symbols, windows, bytes, CRC-32
+        const uint64_t nblk64 = [&]() { uint64_t k = 0; for (uint32_t i = 0; i < nchunks; i++) k += (res[i].out_len + tdgz::BLOCK_SYMS - 1) / tdgz::BLOCK_SYMS; return k; }();
+        if (nblk64 >= 0x7FFFFFFFull) return giveup("segment too large");
+        const uint32_t nblk = (uint32_t)nblk64;
+        {
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            const uint64_t need = 2 * total + total + ZB_CARRY + (uint64_t)nchunks * tdgz2::WINDOW + (uint64_t)nblk * 40 + ((uint64_t)64 << 20);
+            if (need > free_b + g.d_sym.n * 2 + g.d_out.n + g.d_win.n) return giveup("no room on the device for the text");
+        }
+        rc = g.d_sym.ensure(total + 64); if (rc) return rc;
+        if (g.d_out.n < ZB_CARRY + total + 4096 + (total >> 3)) {
+            // (the carried bytes lie at the front of the old buffer)
+            DevBuf<uint8_t> bigger;
+            rc = bigger.ensure(ZB_CARRY + total + 4096 + (total >> 3) + (total >> 2)); if (rc) return rc;
+            if (carry) HIPCHK(hipMemcpyAsync(bigger.p, g.d_out.p, carry, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            g.d_out.release();
+            g.d_out = bigger; bigger.p = nullptr; bigger.n = 0;
+        }
+        rc = g.d_win.ensure((size_t)nchunks * tdgz2::WINDOW); if (rc) return rc;
+        rc = g.d_carry.ensure(tdgz2::WINDOW); if (rc) return rc;
+        rc = g.d_symoff.ensure(nchunks + 1); if (rc) return rc;
+        rc = g.d_blk.ensure(nblk + 1); if (rc) return rc;
+        rc = g.d_crc.ensure(nblk + 1); if (rc) return rc;
+        rc = h->d_gzflag.ensure(4); if (rc) return rc;
+        if (!h->d_crctab) { bool ok = true; rc = ensure_bgzf_buffers(h, 0, 0, &ok); if (rc) return rc; }      // (the CRC tables)
+        std::vector<tdgz::Block> blocks(nblk);
+        {
+            size_t kb = 0;
+            for (uint32_t i = 0; i < nchunks; i++) {
+                const uint32_t min_idx = tdgz2::WINDOW - (uint32_t)std::min<uint64_t>(tdgz2::WINDOW, member_out + sym_off[i]);
+                for (uint64_t o = 0; o < res[i].out_len; o += tdgz::BLOCK_SYMS)
+                    blocks[kb++] = tdgz::Block{(sym_off[i] + o) * 2, sym_off[i] + o, (uint32_t)std::min<uint64_t>(tdgz::BLOCK_SYMS, res[i].out_len - o), i, min_idx, 0u};
+            }
+        }
+        HIPCHK(hipMemcpyAsync(g.d_symoff.p, sym_off.data(), (size_t)(nchunks + 1) * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(g.d_blk.p, blocks.data(), (size_t)nblk * sizeof(tdgz::Block), hipMemcpyHostToDevice, st));
+        if (member_fresh) HIPCHK(hipMemsetAsync(g.d_carry.p, 0, tdgz2::WINDOW, st));           // (a member begins with nothing behind it)
+        HIPCHK(hipMemsetAsync(h->d_gzflag.p, 0, 16, st));
+        hipEvent_t ev[5] = {};
+        auto mark = [&](int k) { if (verbose) { if (!ev[k]) (void)hipEventCreate(&ev[k]); (void)hipEventRecord(ev[k], st); } };
+        mark(0);
+        hipLaunchKernelGGL(tdgz2::k_gz_lz, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
+                           g.d_tok.p, g.d_chunks.p, g.d_res.p, g.d_symoff.p, nchunks, g.d_sym.p);
+        mark(1);
+        {   // the windows: segments of chunks (gz_gpu.hpp, 5.)
+            const uint32_t seg_len = 32, nseg = (nchunks + seg_len - 1) / seg_len;
+            rc = g.d_maps.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return rc;
+            rc = g.d_segwin.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return rc;
+            static bool attr_done = false;
+            if (!attr_done) {
+                HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)tdgz2::WINDOW));
+                HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)tdgz2::WINDOW));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(tdgz2::k_gz_windows<uint16_t>, dim3(nseg), dim3(1024), 4 * tdgz2::WINDOW, st, g.d_sym.p, g.d_symoff.p, g.d_res.p, nchunks, seg_len,
+                               (const uint16_t *)nullptr, g.d_maps.p, (uint8_t *)nullptr);
+            hipLaunchKernelGGL(tdgz2::k_gz_seg_windows, dim3(1), dim3(1024), 0, st, g.d_maps.p, nseg, g.d_segwin.p, g.d_carry.p);
+            hipLaunchKernelGGL(tdgz2::k_gz_windows<uint8_t>, dim3(nseg), dim3(1024), 2 * tdgz2::WINDOW, st, g.d_sym.p, g.d_symoff.p, g.d_res.p, nchunks, seg_len,
+                               (const uint8_t *)g.d_segwin.p, (uint8_t *)nullptr, g.d_win.p);
+        }
+        mark(2);
+        std::vector<uint32_t> crcs(nblk);
+        uint32_t flag = 0;
+        if (nblk) {
+            hipLaunchKernelGGL(tdgz::k_gz_resolve, dim3(nblk), dim3(256), 0, st, (const uint8_t *)g.d_sym.p, g.d_win.p, g.d_out.p + carry, g.d_blk.p, nblk, h->d_gzflag.p);
+            mark(3);
+            hipLaunchKernelGGL(tdgz::k_gz_crc, dim3((nblk + 63) / 64), dim3(64), 0, st, g.d_out.p + carry, g.d_blk.p, nblk, h->d_crctab, g.d_crc.p);
+            mark(4);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(crcs.data(), g.d_crc.p, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipMemcpyAsync(&flag, h->d_gzflag.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const double t4 = PI::now();
+        if (verbose && nblk) {
+            float a = 0, b = 0, c = 0, d = 0;
+            (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]); (void)hipEventElapsedTime(&d, ev[3], ev[4]);
+            uint64_t ntok = 0; for (const auto &o : res) ntok += o.ntok;
+            fprintf(stderr, "gz_gpu_inflate: segment %lu: %.1f MB -> %.1f MB, %u chunks, %.1f M tokens: upload %.1f ms, block search %.1f ms, Huffman decoding %.1f ms, "
+                    "k_gz_lz %.1f ms, windows %.1f ms, k_gz_resolve %.1f ms, k_gz_crc %.1f ms\n", (unsigned long)segments, (double)(seg_end - base) / 1e6, total / 1e6,
+                    nchunks, ntok / 1e6, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, a, b, c, d);
+        }
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        t_up += t1 - t0; t_find += t2 - t1; t_tok += t3 - t2; t_rest += t4 - t3;
+        if (flag) return fail(TD_E_IO, "gzip: distance reaches before the start of the output");
+        for (uint32_t k = 0; k < nblk; k++) crc_run = FI::crc32_join(crc_run, crcs[k], blocks[k].len);
+        member_out += total;
+        member_fresh = false;
+        if (member_done) {
+            if (crc_run != want_crc) return fail(TD_E_IO, "gzip member fails its CRC-32 check");
+            crc_run = 0; member_out = 0; member_fresh = true;
+            if (next_member) next_bit = next_member_bit;
+            else file_done = true;
+        } else {
+            next_bit = end_abs;
+        }
+        segments++;
+        *nbytes = total;
+        *last = file_done;
+        return TD_OK;
     }
-    HIPCHK(hipMemcpyAsync(&flag, h->d_gzflag.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const double t4 = PI::now();
-    if (verbose && nblk) {
-        float a = 0, b = 0, c = 0, d = 0;
-        (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]); (void)hipEventElapsedTime(&d, ev[3], ev[4]);
-        uint64_t ntok = 0; for (const auto &o : res) ntok += o.ntok;
-        fprintf(stderr, "gz_gpu_inflate: %.1f M tokens; k_gz_lz %.1f ms, k_gz_windows %.1f ms, k_gz_resolve %.1f ms, k_gz_crc %.1f ms\n", ntok / 1e6, a, b, c, d);
-    }
-    for (auto &e : ev) if (e) (void)hipEventDestroy(e);
-    *not_applicable = false;                                                 // (from here on the file's verdict is this decoder's)
-    if (flag) return fail(TD_E_IO, "gzip: distance reaches before the start of the output");
-    uint32_t crc = 0;
-    for (uint32_t k = 0; k < nblk; k++) crc = FI::crc32_join(crc, crcs[k], blocks[k].len);
-    if (crc != want_crc) return fail(TD_E_IO, "gzip member fails its CRC-32 check");
-    if (verbose)
-        fprintf(stderr, "gz_gpu_inflate: %.1f MB -> %.1f MB, %u chunks of %u territories: upload %.1f ms, block search %.1f ms, Huffman decoding %.1f ms, "
-                "symbols + windows + bytes + CRC %.1f ms\n", n / 1e6, total / 1e6, nchunks, nterr, (t1 - t0) * 1e3, (t2 - t1) * 1e3,
-                (t3 - t2) * 1e3, (t4 - t3) * 1e3);
-    *total_out = total;
-    h->last_gz_route = 1;
-    return TD_OK;
-}
+};
+
+// *not_applicable: nothing has been counted and the host decoder (count_gzip_dev) should take the file.  What the device
+// decoder gives up on LATER in a file (a token buffer that overflows, a Huffman code it does not build) is a refusal like a
+// decoding error: the reference's reading rules take the file (gz_pyrules.hpp).
 int count_gzip_gpu(td_handle *h, const char *path, uint64_t max_reads, int weights, bool *not_applicable) {
-    uint64_t total = 0;
-    int rc = gz_gpu_inflate(h, path, &total, not_applicable);
-    if (rc || *not_applicable) return rc;
-    // the text, counted where it lies
+    *not_applicable = true;
+    GzGpuStream zs(h, path);
+    if (!zs.open()) {
+        if (zs.verbose) fprintf(stderr, "gz_gpu_inflate: %s -- the host decoder takes the file\n", zs.why);
+        return TD_OK;
+    }
     hipStream_t st = h->work_stream;
     HIPCHK(hipMemsetAsync(h->d_cursor.p, 0, 16, st));
-    if (total) { rc = launch_count(h, h->gzgpu.d_out.p, total, 0, max_reads, weights, st, h->d_cursor.p, h->d_cursor.p + 1, 0); if (rc) return rc; }
-    HIPCHK(hipStreamSynchronize(st));
+    if (!h->pin_cursor) HIPCHK(hipHostMalloc((void **)&h->pin_cursor, 16, hipHostMallocDefault));
+    h->pin_cursor[0] = 0;
+    uint8_t *pin_tail = nullptr;
+    struct Free { uint8_t *&p; ~Free() { if (p) (void)hipHostFree(p); } } free_tail{pin_tail};
+    const uint64_t stop_line = max_reads >= (1ull << 60) ? ~0ull : 4 * (std::max<uint64_t>(1, max_reads) - 1) + 2;
+    size_t carry = 0;
+    uint64_t bytes_submitted = 0;
+    unsigned pieces = 0;
+    const double t0 = tdhost::ParInflate::now();
+    for (;;) {
+        uint64_t nb = 0; bool last = false, gave_up = false;
+        int rc = zs.next(carry, &nb, &last, &gave_up);
+        if (rc) { *not_applicable = false; return rc; }
+        if (gave_up) {
+            if (pieces == 0 && zs.segments == 0) { if (zs.verbose) fprintf(stderr, "gz_gpu_inflate: the host decoder takes the file\n"); return TD_OK; }
+            *not_applicable = false;
+            return fail(TD_E_IO, std::string("gzip (device decoder): ") + zs.why);
+        }
+        *not_applicable = false;                                           // (from here on the file's verdict is this decoder's)
+        td_handle::GzGpu &g = h->gzgpu;
+        const size_t total = carry + nb;
+        size_t cut = total;
+        if (!last && total) {
+            if (!pin_tail) HIPCHK(hipHostMalloc((void **)&pin_tail, ZB_TAIL, hipHostMallocDefault));
+            const size_t ntail = std::min(total, ZB_TAIL);
+            HIPCHK(hipMemcpyAsync(pin_tail, g.d_out.p + total - ntail, ntail, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            const size_t c = cut_at_line_end(pin_tail, ntail);
+            if (c == 0) {
+                if (total > ZB_CARRY) return fail(TD_E_LIMIT, "a single line exceeds the staging buffer");
+                cut = 0;
+            } else {
+                if (ntail - c > ZB_CARRY) return fail(TD_E_LIMIT, "a single line exceeds the staging buffer");
+                cut = total - ntail + c;
+            }
+        }
+        if (cut) {
+            rc = launch_count(h, g.d_out.p, cut, 0, max_reads, weights, st, h->d_cursor.p + (pieces & 1), h->d_cursor.p + ((pieces + 1) & 1), bytes_submitted);
+            if (rc) return rc;
+            bytes_submitted += cut; pieces++;
+            HIPCHK(hipMemcpyAsync(h->pin_cursor, h->d_cursor.p + (pieces & 1), 8, hipMemcpyDeviceToHost, st));
+        }
+        const size_t carry_next = total - cut;
+        if (!last && carry_next) {
+            // (to the front of the same buffer, behind the count: the pieces do not overlap when the text is longer than twice the carry)
+            if (cut >= carry_next) HIPCHK(hipMemcpyAsync(g.d_out.p, g.d_out.p + cut, carry_next, hipMemcpyDeviceToDevice, st));
+            else {
+                DevBuf<uint8_t> tmp; rc = tmp.ensure(carry_next); if (rc) return rc;
+                HIPCHK(hipMemcpyAsync(tmp.p, g.d_out.p + cut, carry_next, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(g.d_out.p, tmp.p, carry_next, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+                tmp.release();
+            }
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        carry = carry_next;
+        if (last) break;
+        if (h->pin_cursor[0] >= stop_line) break;                          // (the segments counted so far already hold read number max_reads)
+    }
+    h->last_gz_route = 1;
+    if (zs.verbose)
+        fprintf(stderr, "count_gzip_gpu: %lu segments in %.1f ms: upload %.1f, block search %.1f, Huffman decoding %.1f, symbols + windows + bytes + CRC %.1f ms\n",
+                (unsigned long)zs.segments, (tdhost::ParInflate::now() - t0) * 1e3, zs.t_up * 1e3, zs.t_find * 1e3, zs.t_tok * 1e3, zs.t_rest * 1e3);
     return TD_OK;
 }
 
@@ -1789,14 +1929,20 @@ int td_gunzip_file_gpu(td_handle *h, const char *path, void *dst, uint64_t capac
     if (!h || !path || !n_out || !on_gpu || (!dst && capacity)) return fail(TD_E_ARG, "NULL argument");
     HIPCHK(hipSetDevice(h->device));
     *n_out = 0; *on_gpu = 0;
-    bool not_applicable = false;
-    uint64_t total = 0;
-    const int rc = gz_gpu_inflate(h, path, &total, &not_applicable);
-    if (rc) return rc;
-    if (not_applicable) return TD_OK;
-    if (total > capacity) return fail(TD_E_LIMIT, "destination too small");
-    if (total) HIPCHK(hipMemcpy(dst, h->gzgpu.d_out.p, total, hipMemcpyDeviceToHost));
-    *n_out = total; *on_gpu = 1;
+    GzGpuStream zs(h, path);
+    if (!zs.open()) return TD_OK;
+    uint64_t at = 0;
+    for (;;) {
+        uint64_t nb = 0; bool last = false, gave_up = false;
+        const int rc = zs.next(0, &nb, &last, &gave_up);
+        if (rc) return rc;
+        if (gave_up) return TD_OK;                                         // (whatever was copied so far is not reported)
+        if (at + nb > capacity) return fail(TD_E_LIMIT, "destination too small");
+        if (nb) HIPCHK(hipMemcpy((uint8_t *)dst + at, h->gzgpu.d_out.p, nb, hipMemcpyDeviceToHost));
+        at += nb;
+        if (last) break;
+    }
+    *n_out = at; *on_gpu = 1;
     return TD_OK;
 }
 
@@ -2237,6 +2383,8 @@ int td_set_option(td_handle *h, const char *name, int64_t value) {
     else if (n == "gz_gpu_terr_kb") { if (value < 16 || value > 4096) return fail(TD_E_ARG, "gz_gpu_terr_kb: 16..4096"); h->gz_gpu_terr_kb = (uint32_t)value; }
     else if (n == "gz_gpu_release") { h->gzgpu.release(); }
     else if (n == "gz_gpu_verify") h->gz_gpu_verify = value ? 1 : 0;
+    else if (n == "gz_gpu_seg_kb") { if (value < 64 || value > (4 << 20)) return fail(TD_E_ARG, "gz_gpu_seg_kb: 64..4194304"); h->gz_gpu_seg_kb = (uint32_t)value; }
+    else if (n == "gz_gpu_margin_kb") { if (value < 64 || value > (1 << 20)) return fail(TD_E_ARG, "gz_gpu_margin_kb: 64..1048576"); h->gz_gpu_margin_kb = (uint32_t)value; }
     else if (n == "gz_gpu_false_every") h->gz_gpu_false_every = (int)std::max<long long>(0, value);
     else if (n == "gpu_inflate") h->gpu_inflate = value ? 1 : 0;
     else if (n == "gpu_inflate_crc") h->gpu_inflate_crc = value ? 1 : 0;

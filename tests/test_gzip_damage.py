@@ -116,7 +116,10 @@ ROUTES = {
     "sequential": {"env": {"TAGDIG_PAR_INFLATE": "0"}, "gpu_resolve": 1},                       # below 8 MiB: fast_inflate.hpp on the calling thread
     "chunks-gpu-resolve": {"env": {"TAGDIG_PAR_INFLATE": "1", "TAGDIG_INFLATE_CHUNK": "3000", "TAGDIG_INFLATE_THREADS": "4"}, "gpu_resolve": 1},   # count_gzip_dev
     "chunks-host-resolve": {"env": {"TAGDIG_PAR_INFLATE": "1", "TAGDIG_INFLATE_CHUNK": "3000", "TAGDIG_INFLATE_THREADS": "4"}, "gpu_resolve": 0},  # par_inflate.hpp, batches
+    # single-member files of 8 MiB and more: Huffman decoding and LZ77 on the device (gz_gpu.hpp); what it does not chain falls to the routes above
+    "device-decoder": {"env": {"TAGDIG_PAR_INFLATE": "0"}, "gpu_resolve": 1, "opts": {"gz_gpu_min": 0, "gz_gpu_terr_kb": 16}},
 }
+ROUTE_DEFAULTS = {"gz_gpu_min": 8 << 20, "gz_gpu_terr_kb": 128}
 
 
 @pytest.mark.gpu
@@ -131,10 +134,14 @@ def test_find_tags_fastq_on_the_damaged_files(case, route, tmp_path, capsys, mon
         monkeypatch.setenv(k, v)
     eng = default_engine(0)
     eng.set_option("gpu_resolve", ROUTES[route]["gpu_resolve"])
+    for k, v in ROUTES[route].get("opts", {}).items():
+        eng.set_option(k, v)
     try:
         got = expect(case, lambda: tf.find_tags_fastq(str(p), list(GOLD["barcodes"]), list(GOLD["tags"]), **case["kwargs"]))
     finally:
         eng.set_option("gpu_resolve", 1)
+        for k, v in ROUTE_DEFAULTS.items():
+            eng.set_option(k, v)
     capsys.readouterr()
     if got is not None:
         assert got == case["counts"]

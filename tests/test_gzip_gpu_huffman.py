@@ -80,7 +80,10 @@ STREAMS = {
     "header-fields": (lambda d: b"\x1f\x8b\x08\x1c" + b"\0" * 6 + struct.pack("<H", 5) + b"extra" + b"name.fq\0" + b"a comment\0"
                                 + _raw_deflate(d, 6) + struct.pack("<II", zlib.crc32(d), len(d) & 0xFFFFFFFF), True),
     "zero-padding": (lambda d: gzip.compress(d, compresslevel=6) + b"\0" * 1000, True),
-    "two-members": (lambda d: gzip.compress(d[:len(d) // 3], compresslevel=6) + gzip.compress(d[len(d) // 3:], compresslevel=1), False),
+    "two-members": (lambda d: gzip.compress(d[:len(d) // 3], compresslevel=6) + gzip.compress(d[len(d) // 3:], compresslevel=1), True),
+    "three-members-padded": (lambda d: gzip.compress(d[:len(d) // 3], compresslevel=6) + b"\0" * 700 + gzip.compress(d[len(d) // 3:2 * len(d) // 3], compresslevel=1)
+                                       + gzip.compress(d[2 * len(d) // 3:], compresslevel=9) + b"\0" * 64, True),
+    "small-members": (lambda d: b"".join(gzip.compress(d[i:i + 2_000_000], compresslevel=6) for i in range(0, len(d), 2_000_000)), False),
 }
 
 
@@ -116,6 +119,35 @@ def test_text_and_counts(eng, sample, tmp_path, kind, terr_kb):
     eng.count_file(path)
     _check(eng, want, ost, (kind, terr_kb))
     assert eng.last_gz_route() == (1 if on_device else 0)
+
+
+@pytest.mark.parametrize("seg_kb,margin_kb", [(1024, 256), (3000, 64), (700, 1024)])
+@pytest.mark.parametrize("kind", ["level6", "full-flushes", "two-members", "sync-flushes"])
+def test_segments_of_the_compressed_file(eng, sample, tmp_path, kind, seg_kb, margin_kb):
+    """The file goes through the device in segments of compressed bytes (1 GiB by default; here a megabyte or so): the window,
+    the unfinished line and the member's CRC-32 are carried from one to the next."""
+    cfg, raw, want, ost = sample
+    blob = STREAMS[kind][0](raw)
+    path = str(tmp_path / "lib.fq.gz")
+    with open(path, "wb") as fh:
+        fh.write(blob)
+    eng.set_option("gz_gpu_terr_kb", 64)
+    eng.set_option("gz_gpu_seg_kb", seg_kb)
+    eng.set_option("gz_gpu_margin_kb", margin_kb)
+    try:
+        got = eng.gunzip_file_gpu(path, len(raw) + 64)
+        assert got is not None and got == raw
+        eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        for maxreads in (5e9, NREADS // 2 + 17):
+            ost2 = {}
+            want2 = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(raw, maxreads=int(min(maxreads, 10 ** 12)), stats=ost2)
+            eng.reset()
+            eng.count_file(path, maxreads=maxreads)
+            _check(eng, want2, ost2, (kind, seg_kb, maxreads))
+            assert eng.last_gz_route() == 1
+    finally:
+        eng.set_option("gz_gpu_seg_kb", 1 << 20)
+        eng.set_option("gz_gpu_margin_kb", 16384)
 
 
 @pytest.mark.parametrize("every", [1, 40, 97])
