@@ -426,11 +426,11 @@ def test_bgzf_gpu_inflate_dirty_and_damaged(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("decoder", ["default", "sequential", "zlib"])
+@pytest.mark.parametrize("decoder", ["default", "host-threads", "sequential", "zlib"])
 def test_gzip_file_counts_like_plain(tmp_path, monkeypatch, capfd, decoder):
-    """An ordinary one-member gzip file above 8 MiB goes through the chunk-parallel decoder by default
-    (csrc/par_inflate.hpp; TAGDIG_PAR_INFLATE=0: one thread, TAGDIG_ZLIB=1: zlib): same matrix as the
-    plain bytes, also with a read limit that ends the stream early."""
+    """An ordinary one-member gzip file above 8 MiB is decoded on the device by default (csrc/gz_gpu.hpp); option
+    gpu_huffman 0: the chunk-parallel decoder on the host's threads (csrc/par_inflate.hpp; TAGDIG_PAR_INFLATE=0: one
+    thread, TAGDIG_ZLIB=1: zlib): same matrix as the plain bytes, also with a read limit that ends the stream early."""
     import gzip
     import tagdigger_amd
     from tagdigger_amd.synth import SynthConfig
@@ -450,11 +450,14 @@ def test_gzip_file_counts_like_plain(tmp_path, monkeypatch, capfd, decoder):
     eng = tagdigger_amd.Engine(0)
     try:
         eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        if decoder != "default":
+            eng.set_option("gpu_huffman", 0)
         eng.count_file(str(p))
         want, _ = synth_expected(cfg, 0, cfg.nreads)
         assert (eng.counts_numpy() == want).all()
-        ran_parallel = "par_inflate:" in capfd.readouterr().err
-        assert ran_parallel == (decoder == "default")
+        err = capfd.readouterr().err
+        assert ("count_gzip_gpu:" in err) == (decoder == "default") and eng.last_gz_route() == (1 if decoder == "default" else 0)
+        assert ("par_inflate:" in err) == (decoder == "host-threads")
         eng.reset()
         eng.count_file(str(p), maxreads=100_000)                           # (the reader stops asking early)
         want, _ = synth_expected(cfg, 0, 100_000)

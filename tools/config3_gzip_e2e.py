@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE configs[2] as written, once: ONE gzip file (one member, one DEFLATE stream) of the canonical synthetic
 stream -- 200 M reads x 384 barcodes x 100 k tags, 43.8 GB of FASTQ -- counted end to end by
-find_tags_fastq's file path (gzip.open of the reference, tagdigger_fun.py:240-243 -> td_count_file: DEFLATE decoded into
-symbols by the host's threads as a pipeline, the symbols uploaded from pinned memory, markers -> bytes and the CRC-32 on
-the GPU, counted where they land; TAGDIG_GPU_RESOLVE=0: all of it on the host as in rounds 1-2), the whole matrix
+find_tags_fastq's file path (gzip.open of the reference, tagdigger_fun.py:240-243 -> td_count_file: decoded on the device in
+segments of 1 GiB, csrc/gz_gpu.hpp; then once more with round 3's path -- DEFLATE decoded into symbols by the host's threads as a
+pipeline, markers -> bytes and the CRC-32 on the GPU), the whole matrix
 checked against the generator's expectation.  TAGDIG_INFLATE_STATS=1 prints where the time went.
 
   tools/config3_gzip_e2e.py [reads] [dir]      (default 200 000 000, $TMPDIR or /tmp)
@@ -70,7 +70,8 @@ want = np.frombuffer(eng.d2h(dw, cells * 4), dtype=np.uint32).reshape(len(cfg.ba
 eng.dev_free(dw)
 
 eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
-for attempt in ("first call (page cache warm from writing; pinned pieces allocated)", "second call"):
+for attempt in ("first call (page cache warm from writing; pinned pieces allocated)", "second call", "third call, Huffman decoding on the host's threads (gpu_huffman 0: round 3's path)"):
+    eng.set_option("gpu_huffman", 0 if attempt.startswith("third") else 1)
     eng.reset()
     t1 = time.perf_counter()
     eng.count_file(path)
@@ -79,7 +80,7 @@ for attempt in ("first call (page cache warm from writing; pinned pieces allocat
     ok = bool((eng.counts_numpy() == want).all())
     st = eng.stats()
     print("%s: %.2f s = %.1f M reads/s = %.2f GB/s of FASTQ (%.2f GB/s compressed); reads %d, tag hits %d (expected %d); bit-exact %s; "
-          "inflate threads %s" % (attempt, dt, reads / dt / 1e6, total / dt / 1e9, gz_bytes / dt / 1e9, st["reads"], st["tag"], hits, ok,
-                                  os.environ.get("TAGDIG_INFLATE_THREADS", "default (host cores, at most 16)")), flush=True)
+          "decoded on the device: %s; inflate threads %s" % (attempt, dt, reads / dt / 1e6, total / dt / 1e9, gz_bytes / dt / 1e9, st["reads"], st["tag"], hits, ok,
+                                  bool(eng.last_gz_route() == 1), os.environ.get("TAGDIG_INFLATE_THREADS", "default (host cores, at most 16)")), flush=True)
 os.remove(path)
 eng.close()
