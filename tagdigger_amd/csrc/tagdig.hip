@@ -220,9 +220,9 @@ struct td_handle {
                    hipEvent_t copied = nullptr; } gslot[2];
     DevBuf<uint32_t> d_gzflag;
     // ordinary gzip decoded on the GPU (count_gzip_gpu, gz_gpu.hpp): the whole file's buffers, kept between files
-    struct GzGpu { DevBuf<uint8_t> d_in, d_out, d_win, d_carry, d_segwin; DevBuf<uint16_t> d_maps; DevBuf<uint32_t> d_tok, d_crc; DevBuf<uint16_t> d_sym; DevBuf<tdgz2::Chunk> d_chunks;
+    struct GzGpu { DevBuf<uint8_t> d_in, d_in2, d_out, d_win, d_carry, d_segwin; DevBuf<uint16_t> d_maps; DevBuf<uint32_t> d_tok, d_crc; DevBuf<uint16_t> d_sym; DevBuf<tdgz2::Chunk> d_chunks;
                    DevBuf<tdgz2::ChunkOut> d_res; DevBuf<uint64_t> d_found, d_symoff; DevBuf<tdgz::Block> d_blk;
-                   void release() { d_in.release(); d_out.release(); d_win.release(); d_carry.release(); d_tok.release(); d_crc.release(); d_sym.release();
+                   void release() { d_in.release(); d_in2.release(); d_out.release(); d_win.release(); d_carry.release(); d_tok.release(); d_crc.release(); d_sym.release();
                                     d_chunks.release(); d_res.release(); d_found.release(); d_symoff.release(); d_blk.release(); d_segwin.release(); d_maps.release(); } } gzgpu;
     int last_gz_route = 0;                    // how the last .gz file was decoded: 1 Huffman + LZ77 on the GPU, 0 otherwise
     int gpu_huffman = 1;                      // ordinary gzip: Huffman decoding on the GPU too (0: host threads decode, the GPU resolves)
@@ -1508,6 +1508,14 @@ struct GzGpuStream {
     bool file_done = false, member_fresh = true;
     const char *why = "";             // (give-ups)
     double t_up = 0, t_find = 0, t_tok = 0, t_rest = 0;
+    // the next segment's bytes on their way while this one is decoded (the other of two buffers, a thread of its own: the
+    // loader stages through pinned pieces on the calling thread)
+    std::thread pf_thread;
+    bool pf_active = false, cur_alt = false;
+    uint64_t pf_base = 0, pf_nb = 0, pf_cap = 0;
+    uint8_t *pf_buf = nullptr;
+    int pf_rc = 0;
+    ~GzGpuStream() { if (pf_thread.joinable()) pf_thread.join(); }
     uint64_t SEG = (uint64_t)1 << 30, MARGIN = (uint64_t)16 << 20;       // (options gz_gpu_seg_kb, gz_gpu_margin_kb)
 
     explicit GzGpuStream(td_handle *hh, const char *p) : h(hh), path(p), mf(p) {
@@ -1532,7 +1540,7 @@ struct GzGpuStream {
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); why = "no device"; return false; }
         const td_handle::GzGpu &g = h->gzgpu;
         const uint64_t have = free_b + g.d_in.n + g.d_tok.n * 4 + g.d_sym.n * 2 + g.d_out.n + g.d_win.n;
-        if (seg * 33 + ((uint64_t)1 << 30) > have) { why = "no room on the device"; return false; }
+        if (seg * 34 + ((uint64_t)1 << 30) > have) { why = "no room on the device"; return false; }
         return true;
     }
 
@@ -1551,12 +1559,27 @@ struct GzGpuStream {
         const uint64_t seg_end = std::min<uint64_t>(n, base + SEG), up_end = std::min<uint64_t>(n, seg_end + MARGIN);
         const uint64_t nb = up_end - base;
         const bool to_file_end = seg_end == n;
-        int rc = g.d_in.ensure(std::min<uint64_t>(n, SEG + MARGIN) + 8192 + 4096); if (rc) return rc;
-        const size_t in_cap = ((nb + 4096 + 15) & ~(size_t)15);
-        HIPCHK(hipStreamSynchronize(st));                                   // (the segment before may still read d_in)
-        HIPCHK(hipMemsetAsync(g.d_in.p + (nb & ~(size_t)15), 0, in_cap - (nb & ~(size_t)15), h->copy_stream));
-        HIPCHK(hipStreamSynchronize(h->copy_stream));
-        rc = td_load_file_range(h, path, base, nb, g.d_in.p); if (rc) return rc;
+        const size_t buf_bytes = std::min<uint64_t>(n, SEG + 2 * MARGIN) + 8192 + 4096;
+        int rc = g.d_in.ensure(buf_bytes); if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(st));                                   // (the segment before may still read its bytes)
+        const uint8_t *din = nullptr;
+        size_t in_cap = 0;
+        if (pf_active) {
+            pf_thread.join();
+            pf_active = false;
+            if (pf_rc == 0 && pf_base <= base && base + nb <= pf_base + pf_nb) {
+                din = pf_buf + (base - pf_base);
+                in_cap = (size_t)(pf_base + pf_cap - base) & ~(size_t)15;
+                cur_alt = pf_buf == g.d_in2.p;
+            }
+        }
+        if (!din) {
+            in_cap = ((nb + 4096 + 15) & ~(size_t)15);
+            HIPCHK(hipMemsetAsync(g.d_in.p + (nb & ~(size_t)15), 0, in_cap - (nb & ~(size_t)15), h->copy_stream));
+            HIPCHK(hipStreamSynchronize(h->copy_stream));
+            rc = td_load_file_range(h, path, base, nb, g.d_in.p); if (rc) return rc;
+            din = g.d_in.p; cur_alt = false;
+        }
         const uint64_t nwords = in_cap / 4, in_bits = nb * 8, first_bit = next_bit - base * 8;
         const uint64_t stop_seg = to_file_end ? ~0ull : (seg_end - base) * 8;
         const double t1 = PI::now();
@@ -1567,7 +1590,7 @@ struct GzGpuStream {
         HIPCHK(hipMemsetAsync(g.d_found.p + nterr, 0, 32, st));
         if (nterr > 1)
             hipLaunchKernelGGL(tdgz2::k_gz_find, dim3((nterr - 1 + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
-                               g.d_in.p, in_bits, nwords, first_bit, terr * 8, nterr, g.d_found.p, (uint32_t)h->gz_gpu_verify);
+                               din, in_bits, nwords, first_bit, terr * 8, nterr, g.d_found.p, (uint32_t)h->gz_gpu_verify);
         HIPCHK(hipGetLastError());
         std::vector<uint64_t> found(nterr);
         if (nterr > 1) HIPCHK(hipMemcpyAsync(found.data() + 1, g.d_found.p + 1, (size_t)(nterr - 1) * 8, hipMemcpyDeviceToHost, st));
@@ -1600,7 +1623,7 @@ struct GzGpuStream {
         HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)nchunks * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(g.d_res.p, 0, (size_t)nchunks * sizeof(tdgz2::ChunkOut), st));
         hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
-                           g.d_in.p, in_bits, nwords, g.d_chunks.p, nchunks, g.d_tok.p, g.d_res.p);
+                           din, in_bits, nwords, g.d_chunks.p, nchunks, g.d_tok.p, g.d_res.p);
         HIPCHK(hipGetLastError());
         std::vector<tdgz2::ChunkOut> res(nchunks);
         HIPCHK(hipMemcpyAsync(res.data(), g.d_res.p, (size_t)nchunks * sizeof(tdgz2::ChunkOut), hipMemcpyDeviceToHost, st));
@@ -1663,7 +1686,7 @@ struct GzGpuStream {
             std::vector<tdgz2::ChunkOut> rc_out(nr);
             for (uint32_t q = 0; q < nr; q++) rc_in[q] = chunks[redo[q]];
             HIPCHK(hipMemcpyAsync(g.d_chunks.p + nchunks, rc_in.data(), (size_t)nr * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nr + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st, g.d_in.p, in_bits, nwords,
+            hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nr + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st, din, in_bits, nwords,
                                g.d_chunks.p + nchunks, nr, g.d_tok.p, g.d_res.p + nchunks);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(rc_out.data(), g.d_res.p + nchunks, (size_t)nr * sizeof(tdgz2::ChunkOut), hipMemcpyDeviceToHost, st));
@@ -1743,6 +1766,24 @@ struct GzGpuStream {
         HIPCHK(hipMemcpyAsync(g.d_blk.p, blocks.data(), (size_t)nblk * sizeof(tdgz::Block), hipMemcpyHostToDevice, st));
         if (member_fresh) HIPCHK(hipMemsetAsync(g.d_carry.p, 0, tdgz2::WINDOW, st));           // (a member begins with nothing behind it)
         HIPCHK(hipMemsetAsync(h->d_gzflag.p, 0, 16, st));
+        if (!to_file_end) {
+            // the bytes behind this segment on their way while its symbols, windows, bytes and CRC-32 are made and its text is
+            // counted: the next segment begins somewhere in the first MARGIN of them.  (Started here, behind this segment's
+            // allocations: hipMalloc and hipFree wait for the copies in flight.)
+            rc = g.d_in2.ensure(buf_bytes); if (rc) return rc;
+            pf_buf = cur_alt ? g.d_in.p : g.d_in2.p;
+            pf_base = seg_end & ~(uint64_t)4095;
+            pf_nb = std::min<uint64_t>(n, pf_base + SEG + 2 * MARGIN) - pf_base;
+            pf_cap = (pf_nb + 4096 + 15) & ~(uint64_t)15;
+            pf_rc = 0;
+            pf_active = true;
+            pf_thread = std::thread([this]() {
+                if (hipSetDevice(h->device) != hipSuccess) { pf_rc = TD_E_INTERNAL; return; }
+                if (hipMemsetAsync(pf_buf + (pf_nb & ~(uint64_t)15), 0, pf_cap - (pf_nb & ~(uint64_t)15), h->copy_stream) != hipSuccess ||
+                    hipStreamSynchronize(h->copy_stream) != hipSuccess) { pf_rc = TD_E_INTERNAL; return; }
+                pf_rc = td_load_file_range(h, path, pf_base, pf_nb, pf_buf);
+            });
+        }
         hipEvent_t ev[5] = {};
         auto mark = [&](int k) { if (verbose) { if (!ev[k]) (void)hipEventCreate(&ev[k]); (void)hipEventRecord(ev[k], st); } };
         mark(0);
