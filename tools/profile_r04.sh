@@ -5,6 +5,7 @@
 #   2. the default bench by itself (with its live FETCH_SIZE / WRITE_SIZE passes): the line the driver would see
 #   3. SQ instruction mix and waits of the main pass (tools/sq2.sh)
 #   4. k_split2's duration (tools/split_kernels.sh)
+#   5. the device gzip decoder's stages and kernels (tools/gz_tier.py)
 TAG=${1:-r04_final}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
@@ -26,6 +27,12 @@ print('k_count (fastpath=0): kernel_ms %.3f  frac %.3f  bit-exact %s' % (o['roof
 echo "[profile] read lengths, CRLF"
 python3 "$ROOT/tools/readlen_sweep.py" > "$OUT/readlen.txt" 2>&1
 python3 "$ROOT/tools/crlf_check.py" 8000000 > "$OUT/crlf.txt" 2>&1
+echo "[profile] ordinary gzip decoded on the device: stage times, then the kernels under rocprofv3"
+TAGDIG_INFLATE_STATS=1 python3 "$ROOT/tools/gz_tier.py" > "$OUT/gzip_gpu_tier.txt" 2> "$OUT/gzip_gpu_tier.err"
+grep -a "gz_gpu_inflate: segment\|count_gzip_gpu" "$OUT/gzip_gpu_tier.err" | tail -4 >> "$OUT/gzip_gpu_tier.txt"
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/gzstats" -- python3 "$ROOT/tools/gz_tier.py" 16000000 2 > "$OUT/gzip_gpu_traced.log" 2>&1
+f=$(find "$OUT/gzstats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -a "Name\|tdgz\|k_fast\|k_resolve" "$f" > "$OUT/gzip_gpu_kernel_stats.csv"
+rm -rf "$OUT/gzstats"
 rm -rf "$OUT/stats"
 ls -la "$OUT"
 echo "[profile] k_fast2 against k_fast4 (the default) and against round 3's kernel, passes alternating in one process"
