@@ -287,3 +287,67 @@ def test_larger_file_with_default_options(sample, tmp_path):
         assert e.last_gz_route() == 1
     finally:
         e.close()
+
+
+def _structured_bytes(rng, n):
+    """Bytes that are no FASTQ: stretches of noise (stored blocks), of one byte (runs of maximal copies), of text with repeats
+    at every distance up to the window's 32 KiB, and of short periodic patterns."""
+    out = bytearray()
+    words = [bytes(rng.choice(b"ACGTNacgt\n@+IF#") for _ in range(rng.randint(1, 40))) for _ in range(200)]
+    while len(out) < n:
+        kind = rng.randrange(6)
+        m = rng.randint(1, 200_000)
+        if kind == 0:
+            out += rng.randbytes(m)
+        elif kind == 1:
+            out += bytes([rng.randrange(256)]) * m
+        elif kind == 2:
+            out += b"".join(rng.choice(words) for _ in range(m // 20 + 1))
+        elif kind == 3:
+            pat = rng.randbytes(rng.randint(1, 9))
+            out += pat * (m // len(pat) + 1)
+        elif kind == 4 and len(out) > 40_000:
+            d = rng.choice([1, 2, 3, 4, 255, 256, 257, 258, 259, 4095, 4096, 32767, 32768])     # (copy from exactly that far back)
+            for _ in range(rng.randint(1, 50)):
+                k = rng.randint(3, 600)
+                out += out[len(out) - d:len(out) - d + k] if d >= k else (out[len(out) - d:] * (k // d + 1))[:k]
+        else:
+            out += bytes(rng.randrange(32, 127) for _ in range(min(m, 5000)))
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_streams_that_are_no_fastq(eng, tmp_path, seed):
+    """The decoder against zlib on structured bytes, compressed in several ways, cut into small blocks by flushes, at small
+    territories and segments: the text is zlib's, or the decoder says that the file is the host decoder's (None)."""
+    rng = random.Random(seed)
+    data = _structured_bytes(rng, 6_000_000 + rng.randrange(2_000_000))
+    writers = {
+        "level1": lambda d: gzip.compress(d, compresslevel=1),
+        "level9": lambda d: gzip.compress(d, compresslevel=9),
+        "flush-1k-9k": lambda d: _member(d, _raw_deflate(d, 6, flush_every=rng.randint(1000, 9000))),
+        "full-flush-50k": lambda d: _member(d, _raw_deflate(d, rng.choice([1, 4, 9]), flush_every=50_000, flush=zlib.Z_FULL_FLUSH)),
+        "filtered": lambda d: _member(d, _raw_deflate(d, 6, strategy=zlib.Z_FILTERED)),
+        "memlevel1": lambda d: _member(d, (lambda co: co.compress(d) + co.flush())(zlib.compressobj(6, zlib.DEFLATED, -15, 1))),     # (blocks of 127 symbols)
+        "window-512": lambda d: _member(d, (lambda co: co.compress(d) + co.flush())(zlib.compressobj(9, zlib.DEFLATED, -9))),
+    }
+    took = 0
+    try:
+        for name, w in writers.items():
+            blob = w(data)
+            assert gzip.decompress(blob) == data
+            path = str(tmp_path / "x.gz")
+            with open(path, "wb") as fh:
+                fh.write(blob)
+            for terr_kb, seg_kb in ((16, 1 << 20), (64, 900)):
+                eng.set_option("gz_gpu_terr_kb", terr_kb)
+                eng.set_option("gz_gpu_seg_kb", seg_kb)
+                eng.set_option("gz_gpu_margin_kb", 512)
+                got = eng.gunzip_file_gpu(path, len(data) + 64)
+                assert got is None or got == data, (name, terr_kb, seg_kb)
+                took += got is not None
+    finally:
+        eng.set_option("gz_gpu_seg_kb", 1 << 20)
+        eng.set_option("gz_gpu_margin_kb", 16384)
+        eng.set_option("gz_gpu_terr_kb", 128)
+    assert took >= 8          # (most of them are the device decoder's: the thousandfold stretches overflow a chunk's tokens in some)
