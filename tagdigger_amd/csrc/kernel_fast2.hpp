@@ -222,7 +222,7 @@ __device__ __forceinline__ uint32_t line_prepare_q(const KParams &p, const TileC
         const uint64_t lo = ((uint64_t)s1 << 32) | s2;
         pd.R[w] = ((uint64_t)(uint32_t)((hi << sh) >> 32) << 32) | (uint32_t)((lo << sh) >> 32);
     }
-    constexpr int BUCKET_U4_ = W <= 3 ? 4 : 8;
+    constexpr int BUCKET_U4_ = W <= 3 ? TD_BU4 : 8;
     pd.nr = min(nrem, 0x7FFFu) | (row << 16);
     if (nrem >= p.m_bases && !(TD_DBG(p) & DBG_NO_PROBE)) {
         pd.nr |= PD_PROBE;
@@ -244,7 +244,7 @@ __device__ __forceinline__ uint32_t line_prepare_q(const KParams &p, const TileC
 // the loads line_prepare<W, NQ, false> left out
 template <int W>
 __device__ __forceinline__ void bucket_issue(const KParams &p, Pending<W> &pd) {
-    constexpr int BUCKET_U4_ = W <= 3 ? 4 : 8;
+    constexpr int BUCKET_U4_ = W <= 3 ? TD_BU4 : 8;
     if (pd.nr & PD_PROBE) {
         const uint4 *bp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(p.buckets) + (pd.boff & ~(uint32_t)(BUCKET_U4_ * 16 - 1)));
 #pragma unroll

@@ -44,6 +44,9 @@ constexpr uint64_t FLAG_INC = 2ull << 62;  // tile state: inclusive prefix publi
 constexpr uint64_t VAL_MASK = (1ull << 62) - 1;
 constexpr uint32_t BDIR_BASES = 5;         // barcode directory is keyed on the first 5 bases
 constexpr uint32_t BDIR_SIZE = 1u << (2 * BDIR_BASES);
+#ifndef TD_BU4
+#define TD_BU4 4                    // 16-byte quarters of a tag bucket for tags of up to 96 bases (4: 64-byte buckets; 2: 32-byte ones)
+#endif
 constexpr uint32_t BMETA_LAST = 1u << 12;  // bmeta: len (6 bits) | tag offset (6 bits) << 6 | last-of-bucket | row << 16
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
 // per-line result of the matcher (top two bits) | count-matrix cell
@@ -363,7 +366,7 @@ template <int W> struct Pending {
     uint32_t boff;          // byte offset of that bucket in the table.  Kept (rather than recomputed) on purpose:
                             // the loads take it as their only address VGPR, and a VGPR that stays live is not
                             // overwritten while the loads still wait to read it (which would stall the wave)
-    uint4 b[W <= 3 ? 4 : 8];   // that bucket (loads left in flight by match_prepare)
+    uint4 b[W <= 3 ? TD_BU4 : 8];   // that bucket (loads left in flight by match_prepare)
 };
 constexpr uint32_t PD_PROBE = 1u << 15;
 constexpr uint64_t R_PEND = 1ull << 61;   // (kind bits 0) match_prepare: finish with match_finish
@@ -479,7 +482,7 @@ __device__ __forceinline__ uint64_t match_stream(const KParams &p, const TileCtx
         uint32_t bot = (uint32_t)(((lo << sh) >> 32));
         R[w] = ((uint64_t)top << 32) | bot;
     }
-    constexpr int BUCKET_U4_ = W <= 3 ? 4 : 8;
+    constexpr int BUCKET_U4_ = W <= 3 ? TD_BU4 : 8;
     TD_MSTAMP(cx, 10, 0);   // tag words
 #pragma unroll
     for (int w = 0; w < W; w++) pd.R[w] = R[w];
@@ -513,7 +516,7 @@ __device__ __forceinline__ uint64_t match_prepare(const KParams &p, const TileCt
 
 template <int W>
 __device__ __forceinline__ uint64_t match_finish(const KParams &p, const Pending<W> &pd) {
-    constexpr int BUCKET_U4 = W <= 3 ? 4 : 8;          // 64- or 128-byte buckets
+    constexpr int BUCKET_U4 = W <= 3 ? TD_BU4 : 8;          // 64- or 128-byte buckets
     constexpr int SLOT_DW = 2 * W + 1;
     constexpr int SPB = (BUCKET_U4 * 4 - 1) / SLOT_DW;  // slots per bucket
     const uint64_t *R = pd.R;

@@ -780,7 +780,7 @@ int td_set_index(td_handle *h, const char *const *barcut, uint32_t n_barcut, uin
     m = std::max<uint32_t>(m, 1);
     // buckets: dword 0 = overflow filter (kernels.hpp KParams::buckets), then SPB slots of {W x u64, u32 meta = col<<10 | len}
     if (ntags >= (1u << 22)) return fail(TD_E_LIMIT, "more than 4M tags");
-    const int bucket_dw = W <= 3 ? 16 : 32;
+    const int bucket_dw = W <= 3 ? 4 * TD_BU4 : 32;
     const int slot_dw = 2 * W + 1;
     const int spb = (bucket_dw - 1) / slot_dw;
     size_t nlong = 0;
