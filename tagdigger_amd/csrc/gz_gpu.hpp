@@ -20,13 +20,19 @@
 //                    by lane in rounds (a copy waits for the copies in front of it that it reads from); a copy that reaches
 //                    before its chunk gives MARKERS (0x8000 | position in the unknown 32 KiB before the chunk), as in
 //                    par_inflate.hpp.  Output: 16-bit symbols;
-//   5. k_gz_windows  one workgroup walks the chunks in order: every chunk's window = its predecessor's last 32 KiB with the
-//                    markers in them replaced from the predecessor's window;
+//   5. k_gz_windows  every chunk's window = its predecessor's last 32 KiB with the markers in them replaced from the
+//                    predecessor's window: a chain, walked in segments of 32 chunks (maps from the identity, one workgroup
+//                    applying them in order, the segments again from their real windows);
 //   6. gz_resolve.hpp's k_gz_resolve / k_gz_crc turn symbols into bytes and take the CRC-32 (as for the host decoder's
 //      symbols), and the count kernels run over the bytes where they lie.
-// Anything unusual -- a second member, a chunk that does not chain, tables zlib would refuse, an overflowing token buffer --
-// sends the file to the host decoder (count_gzip_dev) before anything has been counted; a failed CRC or length check to the
-// reference's reading rules (gz_pyrules.hpp).
+// The host side (tagdig.hip GzGpuStream) takes a file through these in SEGMENTS of 1 GiB of compressed bytes -- a segment's
+// first chunk starts where the segment before ended, the window, the unfinished line and the member's CRC-32 are carried,
+// the next segment's bytes are uploaded meanwhile -- and member by member.  Anything unusual in the first segment -- small
+// members, a chunk that does not chain, tables zlib would refuse, an overflowing token buffer -- sends the file to the host
+// decoder (count_gzip_dev) before anything has been counted; later, and for a failed CRC or length check, to the reference's
+// reading rules (gz_pyrules.hpp).
+// Measured (16 M reads, 662 MB of gzip, 427 M tokens of which 0.7 % need the scalar code): upload 14 ms, k_gz_find 8,
+// k_gz_tokens 43, k_gz_lz 24, windows 2, k_gz_resolve 3, k_gz_crc 6: 105 ms, 152 M reads/s (16 host threads: 79 M).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -61,6 +67,7 @@ struct ChunkOut {
     uint64_t end_bit;         // the bit behind its last block
     uint64_t out_len;         // bytes it inflates to
     uint32_t ntok, status;
+    uint32_t nslow, pad;      // (statistics: tokens the scalar code decoded)
 };
 
 // ---------------------------------------------------------------- the bit reader: wave-uniform state, the compressed bytes in
@@ -310,7 +317,7 @@ __device__ __forceinline__ int read_header(Bits &b, WaveMem &m, bool strict, uin
 // the next tokens, in lane order; false stops the decoding.  Returns S_NONE at the end code, S_ERR for invalid data, S_TOKCAP
 // for the sink's stop.
 template <class F>
-__device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, uint64_t in_bits, const WaveMem &m, int lane, F &&sink) {
+__device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, uint64_t in_bits, const WaveMem &m, int lane, F &&sink, uint32_t *nslow = nullptr) {
     Bits t = rd;
     t.w0 = (pos >> 5) & ~(uint64_t)63;
     uint32_t cur = (uint32_t)(pos - (t.w0 << 5));
@@ -356,6 +363,7 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
             uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)vinfo, (int)o);
             if (__builtin_expect((info >> 8) == 3u, 0)) {
                 // the scalar decoder on this one token: 64 bits from its position are enough (15 + 5 + 15 + 13)
+                if (nslow) (*nslow)++;
                 const uint32_t sb = off + o, sq = sb >> 5, sr = sb & 31u;
                 const uint32_t slo = sq == 0u ? W[0] : sq == 1u ? W[1] : W[2], smid = sq == 0u ? W[1] : sq == 1u ? W[2] : W[3],
                                shi = sq == 0u ? W[2] : sq == 1u ? W[3] : W[4];
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(6, 8
     Bits b;
     b.base = reinterpret_cast<const uint32_t *>(in); b.nwords = nwords;
     bits_init(b, start, lane);
-    uint32_t ntok = 0, status = S_NONE;
+    uint32_t ntok = 0, status = S_NONE, nslow = 0;
     uint64_t out_len = 0, end_bit = 0;
     uint64_t vlen = 0;                                                     // this lane's share of the decoded tokens' bytes
     for (;;) {
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(6, 8
                 }
                 ntok += (uint32_t)__builtin_popcountll(mask);
                 return ntok + 128u <= cap;
-            });
+            }, &nslow);
             if (dr != S_NONE && status == S_NONE) status = dr;
             if (status == S_NONE) bits_init(b, at, lane);
             if (status != S_NONE) break;
@@ -530,7 +538,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(6, 8
     }
     if (lane == 0) {
         ChunkOut o;
-        o.end_bit = end_bit; o.out_len = out_len; o.ntok = ntok; o.status = status;
+        o.end_bit = end_bit; o.out_len = out_len; o.ntok = ntok; o.status = status; o.nslow = nslow; o.pad = 0;
         out[ci] = o;
     }
 }

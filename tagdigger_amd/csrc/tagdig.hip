@@ -224,6 +224,7 @@ struct td_handle {
                    DevBuf<tdgz2::ChunkOut> d_res; DevBuf<uint64_t> d_found, d_symoff; DevBuf<tdgz::Block> d_blk;
                    void release() { d_in.release(); d_in2.release(); d_out.release(); d_win.release(); d_carry.release(); d_tok.release(); d_crc.release(); d_sym.release();
                                     d_chunks.release(); d_res.release(); d_found.release(); d_symoff.release(); d_blk.release(); d_segwin.release(); d_maps.release(); } } gzgpu;
+    bool gz_attr_done = false;
     int last_gz_route = 0;                    // how the last .gz file was decoded: 1 Huffman + LZ77 on the GPU, 0 otherwise
     int gpu_huffman = 1;                      // ordinary gzip: Huffman decoding on the GPU too (0: host threads decode, the GPU resolves)
     uint64_t gz_gpu_min = (uint64_t)8 << 20;  // ... for files of this many compressed bytes and more
@@ -1794,11 +1795,10 @@ struct GzGpuStream {
             const uint32_t seg_len = 32, nseg = (nchunks + seg_len - 1) / seg_len;
             rc = g.d_maps.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return rc;
             rc = g.d_segwin.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return rc;
-            static bool attr_done = false;
-            if (!attr_done) {
+            if (!h->gz_attr_done) {                                          // (per device: a handle has one)
                 HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)tdgz2::WINDOW));
                 HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)tdgz2::WINDOW));
-                attr_done = true;
+                h->gz_attr_done = true;
             }
             hipLaunchKernelGGL(tdgz2::k_gz_windows<uint16_t>, dim3(nseg), dim3(1024), 4 * tdgz2::WINDOW, st, g.d_sym.p, g.d_symoff.p, g.d_res.p, nchunks, seg_len,
                                (const uint16_t *)nullptr, g.d_maps.p, (uint8_t *)nullptr);
@@ -1823,7 +1823,8 @@ struct GzGpuStream {
         if (verbose && nblk) {
             float a = 0, b = 0, c = 0, d = 0;
             (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]); (void)hipEventElapsedTime(&d, ev[3], ev[4]);
-            uint64_t ntok = 0; for (const auto &o : res) ntok += o.ntok;
+            uint64_t ntok = 0, nslow = 0; for (const auto &o : res) { ntok += o.ntok; nslow += o.nslow; }
+            fprintf(stderr, "gz_gpu_inflate: %.1f %% of the tokens by the scalar code (a code longer than the table's index)\n", 100.0 * (double)nslow / (double)std::max<uint64_t>(1, ntok));
             fprintf(stderr, "gz_gpu_inflate: segment %lu: %.1f MB -> %.1f MB, %u chunks, %.1f M tokens: upload %.1f ms, block search %.1f ms, Huffman decoding %.1f ms, "
                     "k_gz_lz %.1f ms, windows %.1f ms, k_gz_resolve %.1f ms, k_gz_crc %.1f ms\n", (unsigned long)segments, (double)(seg_end - base) / 1e6, total / 1e6,
                     nchunks, ntok / 1e6, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, a, b, c, d);
