@@ -3,7 +3,7 @@
 canonical synthetic stream through td_count_file, decoded on the device (csrc/gz_gpu.hpp) -- for `rocprofv3 --kernel-trace
 --stats -- python3 tools/gz_tier.py` (the kernels' durations) and with TAGDIG_INFLATE_STATS=1 (the stages' wall times).
 
-  tools/gz_tier.py [reads] [calls]        (default 16 000 000 reads, 3 calls after a warm one)"""
+  tools/gz_tier.py [reads] [calls] [level]        (default 16 000 000 reads, 3 calls after a warm one, zlib level 1)"""
 import os
 import sys
 import tempfile
@@ -19,6 +19,7 @@ from compress_formats import gzip_one_member
 
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 16_000_000
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+level = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 cfg = SynthConfig.from_id(3, nreads=reads)
 eng = tagdigger_amd.Engine(0)
 nb = reads * cfg.record_bytes
@@ -36,8 +37,8 @@ eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
 with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR")) as tmp:
     path = os.path.join(tmp, "tier.fq.gz")
     with open(path, "wb") as fh:
-        fh.write(gzip_one_member(host, level=1, threads=16))
-    print("%d reads, %.1f MB of FASTQ in %.1f MB of gzip (one member, level 1)" % (reads, nb / 1e6, os.path.getsize(path) / 1e6), flush=True)
+        fh.write(gzip_one_member(host, level=level, threads=16))
+    print("%d reads, %.1f MB of FASTQ in %.1f MB of gzip (one member, level %d)" % (reads, nb / 1e6, os.path.getsize(path) / 1e6, level), flush=True)
     eng.count_file(path)                                   # (warm: buffers)
     for k in range(calls):
         eng.reset()
