@@ -1554,6 +1554,8 @@ struct GzGpuStream {
         auto giveup = [&](const char *w) { why = w; *gave_up = true; if (verbose) fprintf(stderr, "gz_gpu_inflate: %s (segment %lu)\n", w, (unsigned long)segments); return TD_OK; };
         td_handle::GzGpu &g = h->gzgpu;
         hipStream_t st = h->work_stream;
+        // (an allocation that fails -- another process on the card -- is a reason to leave the file to the host decoder, not an error)
+        auto no_room = [&]() { (void)hipGetLastError(); return giveup("no room on the device"); };
         const double t0 = PI::now();
         // the segment's bytes
         const uint64_t base = (next_bit >> 3) & ~(uint64_t)4095;
@@ -1561,7 +1563,7 @@ struct GzGpuStream {
         const uint64_t nb = up_end - base;
         const bool to_file_end = seg_end == n;
         const size_t buf_bytes = std::min<uint64_t>(n, SEG + 2 * MARGIN) + 8192 + 4096;
-        int rc = g.d_in.ensure(buf_bytes); if (rc) return rc;
+        int rc = g.d_in.ensure(buf_bytes); if (rc) return no_room();
         HIPCHK(hipStreamSynchronize(st));                                   // (the segment before may still read its bytes)
         const uint8_t *din = nullptr;
         size_t in_cap = 0;
@@ -1587,7 +1589,7 @@ struct GzGpuStream {
         // 1. block starts
         const uint64_t terr = (uint64_t)h->gz_gpu_terr_kb << 10;
         const uint32_t nterr = (uint32_t)((seg_end - base + terr - 1) / terr);
-        rc = g.d_found.ensure(nterr + 4); if (rc) return rc;
+        rc = g.d_found.ensure(nterr + 4); if (rc) return no_room();
         HIPCHK(hipMemsetAsync(g.d_found.p + nterr, 0, 32, st));
         if (nterr > 1)
             hipLaunchKernelGGL(tdgz2::k_gz_find, dim3((nterr - 1 + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
@@ -1617,10 +1619,10 @@ struct GzGpuStream {
                 chunks[i].tok_off = at; chunks[i].tok_cap = (uint32_t)cap;
                 at += (cap + 63) & ~(uint64_t)63;
             }
-            rc = g.d_tok.ensure(at + 64); if (rc) return rc;
+            rc = g.d_tok.ensure(at + 64); if (rc) return no_room();
         }
-        rc = g.d_chunks.ensure(2 * (size_t)nchunks); if (rc) return rc;               // (behind the chunks: the ones decoded a second time)
-        rc = g.d_res.ensure(2 * (size_t)nchunks); if (rc) return rc;
+        rc = g.d_chunks.ensure(2 * (size_t)nchunks); if (rc) return no_room();               // (behind the chunks: the ones decoded a second time)
+        rc = g.d_res.ensure(2 * (size_t)nchunks); if (rc) return no_room();
         HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)nchunks * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(g.d_res.p, 0, (size_t)nchunks * sizeof(tdgz2::ChunkOut), st));
         hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
@@ -1737,22 +1739,22 @@ struct GzGpuStream {
             const uint64_t need = 2 * total + total + ZB_CARRY + (uint64_t)nchunks * tdgz2::WINDOW + (uint64_t)nblk * 40 + ((uint64_t)64 << 20);
             if (need > free_b + g.d_sym.n * 2 + g.d_out.n + g.d_win.n) return giveup("no room on the device for the text");
         }
-        rc = g.d_sym.ensure(total + 64); if (rc) return rc;
+        rc = g.d_sym.ensure(total + 64); if (rc) return no_room();
         if (g.d_out.n < ZB_CARRY + total + 4096 + (total >> 3)) {
             // (the carried bytes lie at the front of the old buffer)
             DevBuf<uint8_t> bigger;
-            rc = bigger.ensure(ZB_CARRY + total + 4096 + (total >> 3) + (total >> 2)); if (rc) return rc;
+            rc = bigger.ensure(ZB_CARRY + total + 4096 + (total >> 3) + (total >> 2)); if (rc) return no_room();
             if (carry) HIPCHK(hipMemcpyAsync(bigger.p, g.d_out.p, carry, hipMemcpyDeviceToDevice, st));
             HIPCHK(hipStreamSynchronize(st));
             g.d_out.release();
             g.d_out = bigger; bigger.p = nullptr; bigger.n = 0;
         }
-        rc = g.d_win.ensure((size_t)nchunks * tdgz2::WINDOW); if (rc) return rc;
-        rc = g.d_carry.ensure(tdgz2::WINDOW); if (rc) return rc;
-        rc = g.d_symoff.ensure(nchunks + 1); if (rc) return rc;
-        rc = g.d_blk.ensure(nblk + 1); if (rc) return rc;
-        rc = g.d_crc.ensure(nblk + 1); if (rc) return rc;
-        rc = h->d_gzflag.ensure(4); if (rc) return rc;
+        rc = g.d_win.ensure((size_t)nchunks * tdgz2::WINDOW); if (rc) return no_room();
+        rc = g.d_carry.ensure(tdgz2::WINDOW); if (rc) return no_room();
+        rc = g.d_symoff.ensure(nchunks + 1); if (rc) return no_room();
+        rc = g.d_blk.ensure(nblk + 1); if (rc) return no_room();
+        rc = g.d_crc.ensure(nblk + 1); if (rc) return no_room();
+        rc = h->d_gzflag.ensure(4); if (rc) return no_room();
         if (!h->d_crctab) { bool ok = true; rc = ensure_bgzf_buffers(h, 0, 0, &ok); if (rc) return rc; }      // (the CRC tables)
         std::vector<tdgz::Block> blocks(nblk);
         {
@@ -1771,7 +1773,7 @@ struct GzGpuStream {
             // the bytes behind this segment on their way while its symbols, windows, bytes and CRC-32 are made and its text is
             // counted: the next segment begins somewhere in the first MARGIN of them.  (Started here, behind this segment's
             // allocations: hipMalloc and hipFree wait for the copies in flight.)
-            rc = g.d_in2.ensure(buf_bytes); if (rc) return rc;
+            rc = g.d_in2.ensure(buf_bytes); if (rc) return no_room();
             pf_buf = cur_alt ? g.d_in.p : g.d_in2.p;
             pf_base = seg_end & ~(uint64_t)4095;
             pf_nb = std::min<uint64_t>(n, pf_base + SEG + 2 * MARGIN) - pf_base;
@@ -1793,8 +1795,8 @@ struct GzGpuStream {
         mark(1);
         {   // the windows: segments of chunks (gz_gpu.hpp, 5.)
             const uint32_t seg_len = 32, nseg = (nchunks + seg_len - 1) / seg_len;
-            rc = g.d_maps.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return rc;
-            rc = g.d_segwin.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return rc;
+            rc = g.d_maps.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return no_room();
+            rc = g.d_segwin.ensure((size_t)nseg * tdgz2::WINDOW); if (rc) return no_room();
             if (!h->gz_attr_done) {                                          // (per device: a handle has one)
                 HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)tdgz2::WINDOW));
                 HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)tdgz2::WINDOW));

@@ -351,3 +351,33 @@ def test_streams_that_are_no_fastq(eng, tmp_path, seed):
         eng.set_option("gz_gpu_margin_kb", 16384)
         eng.set_option("gz_gpu_terr_kb", 128)
     assert took >= 8          # (most of them are the device decoder's: the thousandfold stretches overflow a chunk's tokens in some)
+
+
+def test_progress_windows_through_the_device_decoder(sample, tmp_path):
+    """find_tags_fastq's progress lines (reference :268-271) for a .gz file decoded on the device in small segments: the
+    windows of 50 000 reads are those of the plain bytes counted in one piece."""
+    import numpy as np
+    import tagdigger_amd
+    cfg, raw, want, ost = sample
+    path = str(tmp_path / "lib.fq.gz")
+    with open(path, "wb") as fh:
+        fh.write(gzip.compress(raw, compresslevel=6))
+    e = tagdigger_amd.Engine(0)
+    try:
+        e.set_option("progress", 1)
+        e.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+        e.count_bytes(raw)
+        plain = [tuple(int(x) for x in w) for w in e.progress_windows()]
+        lines_plain = e.progress_lines("lib.fq.gz")
+        e.reset()
+        e.set_option("gz_gpu_min", 0)
+        e.set_option("gz_gpu_terr_kb", 64)
+        e.set_option("gz_gpu_seg_kb", 2000)
+        e.set_option("gz_gpu_margin_kb", 256)
+        e.count_file(path)
+        assert e.last_gz_route() == 1
+        assert [tuple(int(x) for x in w) for w in e.progress_windows()] == plain
+        assert e.progress_lines("lib.fq.gz") == lines_plain and len(lines_plain) == NREADS // 50000
+        _check(e, want, ost, "with the progress windows")
+    finally:
+        e.close()
