@@ -155,6 +155,24 @@ int td_gunzip_file_gpu(td_handle *h, const char *path, void *dst, uint64_t capac
 /* 1: the .gz file td_count_file counted last was inflated by the device decoder; 0: by one of the others. */
 int td_last_gz_route(td_handle *h);
 
+/* ONE ordinary gzip file over several devices (tagdigger_amd/multi.py count_file_sharded; what gzip.open of
+ * tagdigger_fun.py:240-241 reads, decoded by N ranks): a rank's part of the pipeline of csrc/gz_gpu.hpp.
+ * td_gz_shard_open: the rank's byte range [byte_lo, byte_hi) of the compressed file goes to the device (and the bytes a
+ *   margin further); *start_bit = the first block start in it (`first` != 0 -- rank 0: the member's first block), ~0: none.
+ * td_gz_shard_decode: the stretch from there to stop_bit -- the next rank's start; ~0: to the member's end -- is decoded
+ *   into symbols; *end_bit where it ended (must equal the next rank's start: the caller checks the seams), *out_len its
+ *   bytes, *final whether it ended the member, map_out[32768]: what each place of the 32 KiB window behind the stretch
+ *   holds -- a byte, or 0x8000 | a place of the window in front of it.
+ * td_gz_shard_resolve: with window_in[32768] (the caller applies the maps of the ranks before this one to an empty
+ *   window) and the bytes the member inflated to before the stretch: the stretch's text in device memory (*d_text) and its
+ *   CRC-32 (td_crc32_join combines the ranks' in order; the caller checks the member's trailer).
+ * TD_E_LIMIT: the file is not one this scheme takes (a chunk that does not chain, a stretch larger than a segment): the
+ * caller lets one rank count it through td_count_file. */
+int td_gz_shard_open(td_handle *h, const char *path, uint64_t byte_lo, uint64_t byte_hi, int first, uint64_t *start_bit, uint64_t *file_bytes);
+int td_gz_shard_decode(td_handle *h, uint64_t stop_bit, uint64_t *end_bit, uint64_t *out_len, int *final, uint16_t *map_out);
+int td_gz_shard_resolve(td_handle *h, const uint8_t *window_in, uint64_t member_out_before, void **d_text, uint32_t *crc32);
+uint32_t td_crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
+
 /* What the reference's loop over gzip.open(path, 'rt'), left at read number max_reads (:272-273), meets in this
  * file (host only, no GPU): TD_OK -- it ends without an exception -- or TD_E_GZ_EOF / TD_E_GZ_BADFILE /
  * TD_E_GZ_DATA with the exception's message in td_last_error.  td_count_file, td_gunzip_file and td_split_file

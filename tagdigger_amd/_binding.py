@@ -110,6 +110,10 @@ def load():
     sig("td_gzip_check", i32, C.c_char_p, u64)
     sig("td_gunzip_file_gpu", i32, vp, C.c_char_p, vp, u64, C.POINTER(u64), C.POINTER(C.c_int))
     sig("td_last_gz_route", i32, vp)
+    sig("td_gz_shard_open", i32, vp, C.c_char_p, u64, u64, C.c_int, C.POINTER(u64), C.POINTER(u64))
+    sig("td_gz_shard_decode", i32, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int), vp)
+    sig("td_gz_shard_resolve", i32, vp, vp, u64, C.POINTER(vp), C.POINTER(u32))
+    sig("td_crc32_join", u32, u32, u32, u64)
     sig("td_set_splitter", i32, vp, C.POINTER(C.c_char_p), u32, C.c_char_p, C.c_char_p, C.c_char_p,
         C.POINTER(u32), C.POINTER(C.c_char_p), C.POINTER(C.c_int32), u32)
     sig("td_split_device", i32, vp, vp, u64, u64, vp, u64, vp, C.POINTER(u64))
@@ -144,7 +148,7 @@ def runtime_path():
 EXPORTS = [
     "td_last_error", "td_last_bad_index", "td_create", "td_destroy", "td_set_index",
     "td_bind_counts", "td_reset", "td_count_device", "td_count_host", "td_count_file",
-    "td_count_lines_device", "td_load_file_range", "td_bgzf_index", "td_bgzf_inflate_range", "td_gunzip_file", "td_gzip_check", "td_gunzip_file_gpu", "td_last_gz_route", "td_set_splitter", "td_split_device", "td_count_and_split_device", "td_split_file", "td_fold_rows", "td_inflate_raw_host", "td_format_csv_row", "td_get_counts", "td_get_stats", "td_get_progress", "td_split_progress", "td_set_option",
+    "td_count_lines_device", "td_load_file_range", "td_bgzf_index", "td_bgzf_inflate_range", "td_gunzip_file", "td_gzip_check", "td_gunzip_file_gpu", "td_last_gz_route", "td_gz_shard_open", "td_gz_shard_decode", "td_gz_shard_resolve", "td_crc32_join", "td_set_splitter", "td_split_device", "td_count_and_split_device", "td_split_file", "td_fold_rows", "td_inflate_raw_host", "td_format_csv_row", "td_get_counts", "td_get_stats", "td_get_progress", "td_split_progress", "td_set_option",
     "td_kernel_time_ms", "td_kernel_times_ms", "td_debug_counters", "td_dev_alloc", "td_dev_free", "td_memcpy_h2d", "td_memcpy_d2h",
     "td_device_sync", "td_synth_fill_device", "td_synth_expected_device",
 ]

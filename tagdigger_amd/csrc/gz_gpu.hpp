@@ -399,11 +399,11 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
 // ---------------------------------------------------------------- 1. the block search
 // found[t] (t >= 1): the first block start in territory t, or NONE
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_gz_find(const uint8_t *in, uint64_t in_bits, uint64_t nwords, uint64_t first_bit,
-                                                        uint64_t terr_bits, uint32_t nterr, uint64_t *found, uint32_t verify) {
+                                                        uint64_t terr_bits, uint32_t nterr, uint64_t *found, uint32_t verify, uint32_t t_first) {
     __shared__ WaveMem mem[WAVES];
     const int lane = (int)(threadIdx.x & 63u);
     const uint32_t wave = rfl(threadIdx.x >> 6);
-    const uint32_t t = blockIdx.x * WAVES + wave + 1u;
+    const uint32_t t = blockIdx.x * WAVES + wave + t_first;              // (t_first 1: territory 0 begins with the known start)
     if (t >= nterr) return;
     WaveMem &m = mem[wave];
     uint64_t lo = (uint64_t)t * terr_bits;
@@ -776,6 +776,29 @@ __global__ __launch_bounds__(1024) void k_gz_seg_windows(const uint16_t *maps, u
         cur ^= 1u;
     }
     for (uint32_t p = tid; p < WINDOW; p += 1024u) carry[p] = W[cur][p];
+}
+
+// the segments' maps composed, in order, into ONE map: what each place of the window behind the last segment holds in terms of
+// the window in front of the first (a rank's share of a file that is decoded by several devices: multi.count_file_sharded)
+__global__ __launch_bounds__(1024) void k_gz_compose_maps(const uint16_t *maps, uint32_t nseg, uint16_t *out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint16_t *W = reinterpret_cast<uint16_t *>(lds_raw);                 // two windows of symbols
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t p = tid; p < WINDOW; p += 1024u) W[p] = (uint16_t)(0x8000u | p);
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t sgm = 0; sgm < nseg; sgm++) {
+        const uint16_t *mp = maps + (size_t)sgm * WINDOW;
+        const uint16_t *Wc = W + cur * WINDOW;
+        uint16_t *Wn = W + (cur ^ 1u) * WINDOW;
+        for (uint32_t p = tid; p < WINDOW; p += 1024u) {
+            const uint32_t y = mp[p];
+            Wn[p] = (y & 0x8000u) ? Wc[y & 0x7FFFu] : (uint16_t)y;
+        }
+        __syncthreads();
+        cur ^= 1u;
+    }
+    for (uint32_t p = tid; p < WINDOW; p += 1024u) out[p] = W[cur * WINDOW + p];
 }
 
 }  // namespace tdgz2

@@ -225,6 +225,10 @@ struct td_handle {
                    void release() { d_in.release(); d_in2.release(); d_out.release(); d_win.release(); d_carry.release(); d_tok.release(); d_crc.release(); d_sym.release();
                                     d_chunks.release(); d_res.release(); d_found.release(); d_symoff.release(); d_blk.release(); d_segwin.release(); d_maps.release(); } } gzgpu;
     bool gz_attr_done = false;
+    // one gzip file over several devices: this rank's share between td_gz_shard_open / _decode / _resolve
+    struct GzShard { bool open = false, decoded = false; std::string path; uint64_t n = 0, base = 0, in_bits = 0, nwords = 0, start_rel = 0;
+                     std::vector<uint64_t> found; std::vector<tdgz2::Chunk> chunks; std::vector<tdgz2::ChunkOut> res; std::vector<uint64_t> sym_off;
+                     uint64_t total = 0; uint32_t nseg = 0; } gzshard;
     int last_gz_route = 0;                    // how the last .gz file was decoded: 1 Huffman + LZ77 on the GPU, 0 otherwise
     int gpu_huffman = 1;                      // ordinary gzip: Huffman decoding on the GPU too (0: host threads decode, the GPU resolves)
     uint64_t gz_gpu_min = (uint64_t)8 << 20;  // ... for files of this many compressed bytes and more
@@ -1593,7 +1597,7 @@ struct GzGpuStream {
         HIPCHK(hipMemsetAsync(g.d_found.p + nterr, 0, 32, st));
         if (nterr > 1)
             hipLaunchKernelGGL(tdgz2::k_gz_find, dim3((nterr - 1 + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
-                               din, in_bits, nwords, first_bit, terr * 8, nterr, g.d_found.p, (uint32_t)h->gz_gpu_verify);
+                               din, in_bits, nwords, first_bit, terr * 8, nterr, g.d_found.p, (uint32_t)h->gz_gpu_verify, 1u);
         HIPCHK(hipGetLastError());
         std::vector<uint64_t> found(nterr);
         if (nterr > 1) HIPCHK(hipMemcpyAsync(found.data() + 1, g.d_found.p + 1, (size_t)(nterr - 1) * 8, hipMemcpyDeviceToHost, st));
@@ -1991,6 +1995,212 @@ int td_gunzip_file_gpu(td_handle *h, const char *path, void *dst, uint64_t capac
 }
 
 int td_last_gz_route(td_handle *h) { return h ? h->last_gz_route : 0; }
+
+// ---- one ordinary gzip file over several devices (tagdigger_amd/multi.py count_file_sharded): a rank's part of the pipeline
+// of csrc/gz_gpu.hpp.  Every rank takes a byte range of the compressed file: open (its bytes to the device, the first block
+// start in them), decode (up to the next rank's start: symbols, and the MAP of its stretch -- what each place of the window
+// behind it holds in terms of the window in front of it), resolve (with the window the maps of the ranks before it give: text).
+int td_gz_shard_open(td_handle *h, const char *path, uint64_t byte_lo, uint64_t byte_hi, int first, uint64_t *start_bit, uint64_t *file_bytes) {
+    using FI = tdhost::FastInflate;
+    if (!h || !path || !start_bit || !file_bytes) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    td_handle::GzShard &sh = h->gzshard;
+    sh = td_handle::GzShard();
+    MappedFile mf(path);
+    if (!mf.ok) return fail(TD_E_IO, std::string("cannot open ") + path);
+    const uint64_t n = mf.n;
+    *file_bytes = n; *start_bit = ~0ull;
+    if (byte_hi > n) byte_hi = n;
+    if (byte_lo >= byte_hi) { sh.open = true; sh.path = path; sh.n = n; return TD_OK; }            // (nothing of the file: no start)
+    uint64_t first_abs = ~0ull;
+    if (first) {
+        const uint8_t *body = nullptr; const char *herr = nullptr;
+        if (FI::parse_member_header(mf.p, mf.p + n, &body, &herr, true) != 1) return fail(TD_E_IO, "gzip: no member header");
+        first_abs = (uint64_t)(body - mf.p) * 8;
+        byte_lo = 0;
+    }
+    const uint64_t MARGIN = (uint64_t)h->gz_gpu_margin_kb << 10, SEG = (uint64_t)h->gz_gpu_seg_kb << 10;
+    const uint64_t base = byte_lo & ~(uint64_t)4095, up_end = std::min<uint64_t>(n, byte_hi + MARGIN), nb = up_end - base;
+    if (nb > SEG + 2 * MARGIN) return fail(TD_E_LIMIT, "gzip shard larger than a segment");
+    td_handle::GzGpu &g = h->gzgpu;
+    int rc = g.d_in.ensure(nb + 8192 + 4096); if (rc) return rc;
+    const size_t in_cap = ((nb + 4096 + 15) & ~(size_t)15);
+    HIPCHK(hipStreamSynchronize(h->work_stream));
+    HIPCHK(hipMemsetAsync(g.d_in.p + (nb & ~(size_t)15), 0, in_cap - (nb & ~(size_t)15), h->copy_stream));
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    rc = td_load_file_range(h, path, base, nb, g.d_in.p); if (rc) return rc;
+    const uint64_t in_bits = nb * 8, nwords = in_cap / 4;
+    const uint64_t terr = (uint64_t)h->gz_gpu_terr_kb << 10;
+    const uint32_t nterr = (uint32_t)((byte_hi - base + terr - 1) / terr);
+    // block starts at or behind byte_lo (the first rank: behind its known start)
+    const uint64_t lo_rel = first ? first_abs - base * 8 : std::max<uint64_t>((byte_lo - base) * 8, 1) - 1;
+    rc = g.d_found.ensure(nterr + 4); if (rc) return rc;
+    hipStream_t st = h->work_stream;
+    HIPCHK(hipMemsetAsync(g.d_found.p, 0xFF, (size_t)nterr * 8, st));
+    HIPCHK(hipMemsetAsync(g.d_found.p + nterr, 0, 32, st));
+    hipLaunchKernelGGL(tdgz2::k_gz_find, dim3((nterr + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
+                       g.d_in.p, in_bits, nwords, lo_rel, terr * 8, nterr, g.d_found.p, (uint32_t)h->gz_gpu_verify, 0u);
+    HIPCHK(hipGetLastError());
+    sh.found.assign(nterr, tdgz2::NONE);
+    HIPCHK(hipMemcpyAsync(sh.found.data(), g.d_found.p, (size_t)nterr * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // (a start at or past byte_hi is the next rank's)
+    const uint64_t hi_rel = (byte_hi - base) * 8;
+    for (auto &f : sh.found) if (f != tdgz2::NONE && f >= hi_rel) f = tdgz2::NONE;
+    uint64_t start_rel = tdgz2::NONE;
+    if (first) start_rel = first_abs - base * 8;
+    else for (uint64_t f : sh.found) if (f != tdgz2::NONE) { start_rel = f; break; }
+    sh.open = true; sh.path = path; sh.n = n; sh.base = base; sh.in_bits = in_bits; sh.nwords = nwords; sh.start_rel = start_rel;
+    *start_bit = start_rel == tdgz2::NONE ? ~0ull : base * 8 + start_rel;
+    return TD_OK;
+}
+
+// stop_bit: where the next rank with a start begins (~0: this rank's stretch runs to the member's end).  *final: it ended the member.
+int td_gz_shard_decode(td_handle *h, uint64_t stop_bit, uint64_t *end_bit, uint64_t *out_len, int *final, uint16_t *map_out) {
+    if (!h || !end_bit || !out_len || !final || !map_out) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    td_handle::GzShard &sh = h->gzshard;
+    td_handle::GzGpu &g = h->gzgpu;
+    if (!sh.open || sh.start_rel == tdgz2::NONE) return fail(TD_E_STATE, "td_gz_shard_open found no block start for this rank");
+    hipStream_t st = h->work_stream;
+    const uint64_t stop_rel = stop_bit == ~0ull ? ~0ull : stop_bit - sh.base * 8;
+    if (stop_rel != ~0ull && stop_rel > sh.in_bits) return fail(TD_E_LIMIT, "gzip shard: the next rank's start lies beyond this rank's bytes");
+    std::vector<tdgz2::Chunk> chunks;
+    { tdgz2::Chunk c{}; c.start_bit = sh.start_rel; chunks.push_back(c); }
+    for (uint64_t f : sh.found) if (f != tdgz2::NONE && f > sh.start_rel && f < stop_rel) { tdgz2::Chunk c{}; c.start_bit = f; chunks.push_back(c); }
+    uint32_t nchunks = (uint32_t)chunks.size();
+    {
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < nchunks; i++) {
+            chunks[i].stop_bit = i + 1 < nchunks ? chunks[i + 1].start_bit : stop_rel;
+            const uint64_t span_end = i + 1 < nchunks ? chunks[i + 1].start_bit : (stop_rel == ~0ull ? sh.in_bits : std::min<uint64_t>(sh.in_bits, stop_rel + ((uint64_t)h->gz_gpu_margin_kb << 13)));
+            const uint64_t span = (span_end - chunks[i].start_bit + 7) / 8;
+            const uint64_t cap = std::min<uint64_t>(4 * span + 4096, 0xFFFFFF00u);
+            chunks[i].tok_off = at; chunks[i].tok_cap = (uint32_t)cap;
+            at += (cap + 63) & ~(uint64_t)63;
+        }
+        int rc = g.d_tok.ensure(at + 64); if (rc) return rc;
+    }
+    int rc = g.d_chunks.ensure(2 * (size_t)nchunks); if (rc) return rc;
+    rc = g.d_res.ensure(2 * (size_t)nchunks); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)nchunks * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(g.d_res.p, 0, (size_t)nchunks * sizeof(tdgz2::ChunkOut), st));
+    hipLaunchKernelGGL(tdgz2::k_gz_tokens, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
+                       g.d_in.p, sh.in_bits, sh.nwords, g.d_chunks.p, nchunks, g.d_tok.p, g.d_res.p);
+    HIPCHK(hipGetLastError());
+    std::vector<tdgz2::ChunkOut> res(nchunks);
+    HIPCHK(hipMemcpyAsync(res.data(), g.d_res.p, (size_t)nchunks * sizeof(tdgz2::ChunkOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // the chain inside the rank (a false start is dropped where the chunk in front of it ends on a later start; anything else
+    // sends the file to the one-rank path)
+    std::vector<uint8_t> dead(nchunks, 0);
+    bool ended = false;
+    for (uint32_t i = 0;;) {
+        const tdgz2::ChunkOut &o = res[i];
+        if (o.status != tdgz2::S_BOUNDARY && o.status != tdgz2::S_FINAL) return fail(TD_E_LIMIT, "gzip shard: a chunk this decoder does not finish");
+        if (o.status == tdgz2::S_FINAL) { for (uint32_t k = i + 1; k < nchunks; k++) dead[k] = 1; ended = true; break; }
+        uint32_t j = i + 1;
+        while (j < nchunks && (dead[j] || chunks[j].start_bit < o.end_bit)) { dead[j] = 1; j++; }
+        if (j == nchunks) break;
+        if (chunks[j].start_bit != o.end_bit) return fail(TD_E_LIMIT, "gzip shard: a chunk does not end on a block start that was found");
+        i = j;
+    }
+    {
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < nchunks; i++) if (!dead[i]) { chunks[w] = chunks[i]; res[w] = res[i]; w++; }
+        chunks.resize(w); res.resize(w); nchunks = w;
+        HIPCHK(hipMemcpyAsync(g.d_chunks.p, chunks.data(), (size_t)nchunks * sizeof(tdgz2::Chunk), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(g.d_res.p, res.data(), (size_t)nchunks * sizeof(tdgz2::ChunkOut), hipMemcpyHostToDevice, st));
+    }
+    sh.sym_off.assign(nchunks + 1, 0);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < nchunks; i++) { sh.sym_off[i] = total; total += res[i].out_len; }
+    sh.sym_off[nchunks] = total;
+    rc = g.d_sym.ensure(total + 64); if (rc) return rc;
+    rc = g.d_symoff.ensure(nchunks + 1); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(g.d_symoff.p, sh.sym_off.data(), (size_t)(nchunks + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(tdgz2::k_gz_lz, dim3((nchunks + tdgz2::WAVES - 1) / tdgz2::WAVES), dim3(64 * tdgz2::WAVES), 0, st,
+                       g.d_tok.p, g.d_chunks.p, g.d_res.p, g.d_symoff.p, nchunks, g.d_sym.p);
+    const uint32_t seg_len = 32, nseg = (nchunks + seg_len - 1) / seg_len;
+    rc = g.d_maps.ensure((size_t)(nseg + 1) * tdgz2::WINDOW); if (rc) return rc;
+    if (!h->gz_attr_done) {
+        HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)tdgz2::WINDOW));
+        HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_windows<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)tdgz2::WINDOW));
+        h->gz_attr_done = true;
+    }
+    HIPCHK(hipFuncSetAttribute((const void *)tdgz2::k_gz_compose_maps, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (int)tdgz2::WINDOW));
+    hipLaunchKernelGGL(tdgz2::k_gz_windows<uint16_t>, dim3(nseg), dim3(1024), 4 * tdgz2::WINDOW, st, g.d_sym.p, g.d_symoff.p, g.d_res.p, nchunks, seg_len,
+                       (const uint16_t *)nullptr, g.d_maps.p, (uint8_t *)nullptr);
+    hipLaunchKernelGGL(tdgz2::k_gz_compose_maps, dim3(1), dim3(1024), 4 * tdgz2::WINDOW, st, g.d_maps.p, nseg, g.d_maps.p + (size_t)nseg * tdgz2::WINDOW);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(map_out, g.d_maps.p + (size_t)nseg * tdgz2::WINDOW, (size_t)tdgz2::WINDOW * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    sh.chunks = chunks; sh.res = res; sh.total = total; sh.nseg = nseg; sh.decoded = true;
+    *end_bit = sh.base * 8 + res[nchunks - 1].end_bit;
+    *out_len = total;
+    *final = ended ? 1 : 0;
+    return TD_OK;
+}
+
+// window_in: the 32 KiB in front of this rank's stretch (from the maps of the ranks before it); member_out_before: the bytes the
+// member has inflated to before it.  *d_text: the stretch's text in device memory (out_len bytes; room behind it for an eighth more),
+// *crc32: its CRC-32.
+int td_gz_shard_resolve(td_handle *h, const uint8_t *window_in, uint64_t member_out_before, void **d_text, uint32_t *crc32) {
+    using FI = tdhost::FastInflate;
+    if (!h || !window_in || !d_text || !crc32) return fail(TD_E_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    td_handle::GzShard &sh = h->gzshard;
+    td_handle::GzGpu &g = h->gzgpu;
+    if (!sh.decoded) return fail(TD_E_STATE, "td_gz_shard_decode has not run");
+    hipStream_t st = h->work_stream;
+    const uint32_t nchunks = (uint32_t)sh.chunks.size(), seg_len = 32;
+    const uint64_t total = sh.total;
+    uint64_t nblk64 = 0;
+    for (uint32_t i = 0; i < nchunks; i++) nblk64 += (sh.res[i].out_len + tdgz::BLOCK_SYMS - 1) / tdgz::BLOCK_SYMS;
+    if (nblk64 >= 0x7FFFFFFFull) return fail(TD_E_LIMIT, "gzip shard too large");
+    const uint32_t nblk = (uint32_t)nblk64;
+    int rc = g.d_out.ensure(total + 4096 + (total >> 3) + ((size_t)1 << 20)); if (rc) return rc;
+    rc = g.d_win.ensure((size_t)nchunks * tdgz2::WINDOW); if (rc) return rc;
+    rc = g.d_carry.ensure(tdgz2::WINDOW); if (rc) return rc;
+    rc = g.d_segwin.ensure((size_t)sh.nseg * tdgz2::WINDOW); if (rc) return rc;
+    rc = g.d_blk.ensure(nblk + 1); if (rc) return rc;
+    rc = g.d_crc.ensure(nblk + 1); if (rc) return rc;
+    rc = h->d_gzflag.ensure(4); if (rc) return rc;
+    if (!h->d_crctab) { bool ok = true; rc = ensure_bgzf_buffers(h, 0, 0, &ok); if (rc) return rc; }
+    std::vector<tdgz::Block> blocks(nblk);
+    {
+        size_t kb = 0;
+        for (uint32_t i = 0; i < nchunks; i++) {
+            const uint32_t min_idx = tdgz2::WINDOW - (uint32_t)std::min<uint64_t>(tdgz2::WINDOW, member_out_before + sh.sym_off[i]);
+            for (uint64_t o = 0; o < sh.res[i].out_len; o += tdgz::BLOCK_SYMS)
+                blocks[kb++] = tdgz::Block{(sh.sym_off[i] + o) * 2, sh.sym_off[i] + o, (uint32_t)std::min<uint64_t>(tdgz::BLOCK_SYMS, sh.res[i].out_len - o), i, min_idx, 0u};
+        }
+    }
+    HIPCHK(hipMemcpyAsync(g.d_carry.p, window_in, tdgz2::WINDOW, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(g.d_blk.p, blocks.data(), (size_t)nblk * sizeof(tdgz::Block), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(h->d_gzflag.p, 0, 16, st));
+    hipLaunchKernelGGL(tdgz2::k_gz_seg_windows, dim3(1), dim3(1024), 0, st, g.d_maps.p, sh.nseg, g.d_segwin.p, g.d_carry.p);
+    hipLaunchKernelGGL(tdgz2::k_gz_windows<uint8_t>, dim3(sh.nseg), dim3(1024), 2 * tdgz2::WINDOW, st, g.d_sym.p, g.d_symoff.p, g.d_res.p, nchunks, seg_len,
+                       (const uint8_t *)g.d_segwin.p, (uint8_t *)nullptr, g.d_win.p);
+    std::vector<uint32_t> crcs(nblk);
+    uint32_t flag = 0;
+    if (nblk) {
+        hipLaunchKernelGGL(tdgz::k_gz_resolve, dim3(nblk), dim3(256), 0, st, (const uint8_t *)g.d_sym.p, g.d_win.p, g.d_out.p, g.d_blk.p, nblk, h->d_gzflag.p);
+        hipLaunchKernelGGL(tdgz::k_gz_crc, dim3((nblk + 63) / 64), dim3(64), 0, st, g.d_out.p, g.d_blk.p, nblk, h->d_crctab, g.d_crc.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(crcs.data(), g.d_crc.p, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipMemcpyAsync(&flag, h->d_gzflag.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (flag) return fail(TD_E_IO, "gzip: distance reaches before the start of the output");
+    uint32_t crc = 0;
+    for (uint32_t k = 0; k < nblk; k++) crc = FI::crc32_join(crc, crcs[k], blocks[k].len);
+    *crc32 = crc;
+    *d_text = g.d_out.p;
+    return TD_OK;
+}
+
+uint32_t td_crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) { return tdhost::FastInflate::crc32_join(crc_a, crc_b, len_b); }
 
 int td_gzip_check(const char *path, uint64_t max_reads) {
     if (!path) return fail(TD_E_ARG, "NULL argument");

@@ -165,6 +165,34 @@ class Engine:
         B.check(self._L.td_gunzip_file_gpu(self._h, path.encode(), buf, capacity, C.byref(n), C.byref(on_gpu)))
         return bytes(memoryview(buf)[:n.value]) if on_gpu.value else None
 
+    # one ordinary gzip file over several ranks (multi.count_file_sharded): include/tagdig.h td_gz_shard_*
+    def gz_shard_open(self, path, byte_lo, byte_hi, first):
+        """-> (first block start in the range as a bit position of the file, or None; the file's size)"""
+        start, size = C.c_uint64(0), C.c_uint64(0)
+        B.check(self._L.td_gz_shard_open(self._h, path.encode(), int(byte_lo), int(byte_hi), 1 if first else 0, C.byref(start), C.byref(size)))
+        return (None if start.value == 2 ** 64 - 1 else start.value), size.value
+
+    def gz_shard_decode(self, stop_bit):
+        """-> (end bit, bytes of text, ended the member, map: numpy uint16[32768])"""
+        import numpy as np
+        end, n, fin = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        m = np.zeros(32768, dtype=np.uint16)
+        B.check(self._L.td_gz_shard_decode(self._h, 2 ** 64 - 1 if stop_bit is None else int(stop_bit), C.byref(end), C.byref(n), C.byref(fin),
+                                           m.ctypes.data_as(C.c_void_p)))
+        return end.value, n.value, bool(fin.value), m
+
+    def gz_shard_resolve(self, window_in, member_out_before):
+        """-> (device pointer of the stretch's text, its CRC-32)"""
+        import numpy as np
+        w = np.ascontiguousarray(window_in, dtype=np.uint8)
+        assert w.size == 32768
+        ptr, crc = C.c_void_p(0), C.c_uint32(0)
+        B.check(self._L.td_gz_shard_resolve(self._h, w.ctypes.data_as(C.c_void_p), int(member_out_before), C.byref(ptr), C.byref(crc)))
+        return int(ptr.value or 0), crc.value
+
+    def crc32_join(self, crc_a, crc_b, len_b):
+        return int(self._L.td_crc32_join(int(crc_a), int(crc_b), int(len_b)))
+
     def last_gz_route(self):
         """1: the .gz file counted last was inflated on the device; 0: by a host decoder."""
         return int(self._L.td_last_gz_route(self._h))

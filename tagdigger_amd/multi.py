@@ -203,6 +203,166 @@ def _agree(exc, where):
         raise RuntimeError("tagdigger_amd: another rank failed on its share of the file; see its message")
 
 
+class _DevRange:
+    """a stretch of device memory with the one method of a tensor that count_file_sharded's counting block uses"""
+    def __init__(self, ptr):
+        self._ptr = int(ptr)
+
+    def data_ptr(self):
+        return self._ptr
+
+
+def _gzip_shard_text(eng, path, dev):
+    """ONE ordinary gzip file (a single member) over the ranks, each decoding a byte range of the compressed file on its
+    device (include/tagdig.h td_gz_shard_*, csrc/gz_gpu.hpp): every rank finds the first block start in its range,
+    decodes from there to the next rank's start into symbols -- its first window is unknown -- and leaves the MAP of its
+    stretch (what the 32 KiB behind it hold in terms of the 32 KiB in front of it); the maps, all-gathered, give every
+    rank its window; the stretches' CRC-32s joined in rank order are checked against the member's trailer.  A rank's
+    lines run from behind the first terminator of its text to the first terminator of the next rank's (all-gathered heads);
+    the bytes between the 16-byte boundary below that start and the start are overwritten with blanks (a line is stripped,
+    reference :256).  Returns (device range, its length) -- or None on EVERY rank where the file is not one this scheme
+    takes (several members, a seam that does not close, a line longer than 64 KiB at a seam): one rank counts it then."""
+    import os
+    import struct
+    rank, world = _rank_world()
+    fsize = os.path.getsize(path)
+    NONE = -1
+    HEAD = 1 << 16
+
+    def gather(values):
+        mine = torch.tensor(values, dtype=torch.int64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return [[int(x) for x in t.tolist()] for t in every]
+
+    def all_ok(ok):
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return int(flag[0]) == 0
+
+    from ._binding import TagdigError
+    # 1. every rank's first block start
+    lo, hi = fsize * rank // world, fsize * (rank + 1) // world
+    start, ok = NONE, True
+    try:
+        s, _ = eng.gz_shard_open(path, lo, hi, rank == 0)
+        start = NONE if s is None else s
+    except TagdigError:
+        ok = False
+    if not all_ok(ok):
+        return None
+    starts = [v[0] for v in gather([start])]
+    live = [r for r in range(world) if starts[r] != NONE]
+    if not live or live[0] != 0:
+        return None
+    nxt = [starts[r] for r in live[live.index(rank) + 1:]][:1] if rank in live else []
+    # 2. the stretches, decoded; the seams
+    end, nout, final, ok = 0, 0, 0, True
+    mp = np.zeros(32768, dtype=np.uint16)
+    if rank in live:
+        try:
+            end, nout, fin, mp = eng.gz_shard_decode(nxt[0] if nxt else None)
+            final = 1 if fin else 0
+        except TagdigError:
+            ok = False
+    if not all_ok(ok):
+        return None
+    info = gather([end, nout, final])
+    for a, b in zip(live, live[1:]):
+        if info[a][0] != starts[b] or info[a][2]:
+            return None                                        # (a false start at a seam, or a member that ends inside the file)
+    last = live[-1]
+    if not info[last][2]:
+        return None
+    # the member's trailer, and nothing but zeros behind it (more members: the one-rank path reads them)
+    trailer = (info[last][0] + 7) // 8
+    total_len = sum(info[r][1] for r in live)
+    with open(path, "rb") as fh:
+        fh.seek(trailer)
+        tail = fh.read()
+    if len(tail) < 8 or any(tail[8:]):
+        return None
+    want_crc, want_len = struct.unpack("<II", tail[:8])
+    if want_len != total_len & 0xFFFFFFFF:
+        return None
+    # 3. the windows through the maps, the text, the CRC-32
+    maps_t = torch.from_numpy(mp.astype(np.int32)).to(dev)
+    every = [torch.zeros_like(maps_t) for _ in range(world)]
+    dist.all_gather(every, maps_t)
+    window = np.zeros(32768, dtype=np.uint8)
+    before = 0
+    for r in live:
+        if r >= rank:
+            break
+        m = every[r].cpu().numpy().astype(np.uint16)
+        window = np.where(m & 0x8000, window[m & 0x7FFF], (m & 0xFF).astype(np.uint8)).astype(np.uint8)
+        before += info[r][1]
+    ptr, crc, ok = 0, 0, True
+    if rank in live:
+        try:
+            ptr, crc = eng.gz_shard_resolve(window, before)
+        except TagdigError:
+            ok = False
+    if not all_ok(ok):
+        return None
+    crcs = [v[0] for v in gather([crc])]
+    joined = 0
+    for r in live:
+        joined = eng.crc32_join(joined, crcs[r], info[r][1])
+    if joined != want_crc:
+        return None                                            # (the one-rank path raises what gzip.open raises)
+    # 4. lines: a rank gives its text up to and including its first terminator to the rank before it
+    head = b""
+    if rank in live and nout:
+        head = eng.d2h(ptr, min(nout, HEAD))
+    cut = None                                                 # (bytes of my text that are the previous rank's line)
+    for k, c in enumerate(head):
+        if c == 10:
+            cut = k + 1
+            break
+        if c == 13:
+            if k + 1 < len(head):
+                cut = k + 2 if head[k + 1] == 10 else k + 1
+                break
+            if nout == len(head):                              # (a '\r' that ends the text: the next rank's '\n', if any, goes with it)
+                cut = k + 1
+                break
+    if rank == 0:
+        cut = 0
+    whole = cut is None                                        # (no terminator in sight: all of a short text is the previous rank's)
+    ok = not (whole and nout > len(head))
+    if not all_ok(ok):
+        return None
+    give = nout if whole else cut
+    heads_t = torch.zeros(HEAD + 2, dtype=torch.int32, device=dev)
+    heads_t[0] = give
+    heads_t[1] = 1 if whole else 0
+    if give:
+        heads_t[2:2 + give] = torch.tensor(list(head[:give]), dtype=torch.int32, device=dev)
+    every = [torch.zeros_like(heads_t) for _ in range(world)]
+    dist.all_gather(every, heads_t)
+    tail_bytes = b""
+    for r in range(rank + 1, world):
+        g = int(every[r][0])
+        tail_bytes += bytes(every[r][2:2 + g].cpu().numpy().astype(np.uint8).tobytes())
+        if r in live and not int(every[r][1]):                 # (its text has a terminator: my last line ends in what it gave)
+            break
+    # a '\r' that ended a rank's text and the '\n' the next rank's text begins with are one terminator: that '\n' is in
+    # the head it gave away (its first terminator is that '\n'), so nothing more to do
+    if rank not in live or whole:
+        return _DevRange(0), 0
+    own0, own1 = give, nout
+    if tail_bytes:
+        if len(tail_bytes) > 4096 + (nout >> 3):
+            return None
+        eng.h2d(ptr + nout, tail_bytes)
+        own1 = nout + len(tail_bytes)
+    al = own0 - own0 % 16
+    if own0 > al:
+        eng.h2d(ptr + al, b" " * (own0 - al))
+    return _DevRange(ptr + al), own1 - al
+
+
 def _count_one_stream(path, barcodes, tags, cutsite, bound, counter, dev, as_array, progress):
     """An ordinary gzip file (one DEFLATE stream: no place to cut it without decoding everything before) under
     count_file_sharded: the reference reads any .gz by name (:240-241), so it is counted -- by rank 0 alone, through
@@ -328,89 +488,97 @@ def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, coun
             if "BGZF" not in e.detail:
                 raise
             moff = None
-        if moff is None:
+        gz_text = None
+        if moff is None and use_gpu and world > 1:
+            got = _gzip_shard_text(eng, path, dev)
+            if got is not None:
+                gz_text = got
+        if moff is None and gz_text is None:
             return _count_one_stream(path, barcodes, tags, cutsite, bound, counter, dev if use_gpu else None, as_array, progress)
-        fsize = os.path.getsize(path)
-        ends = np.append(moff[1:], np.uint64(fsize))
-        gpos = np.concatenate(([0], np.cumsum(misz.astype(np.int64))))            # inflated offset of every member (and the total)
-        m0, m1 = bgzf_member_ranges(moff, fsize, world)[rank]
-        own_len = int(gpos[m1] - gpos[m0])
-        # the byte before my members (the last byte of the nearest non-empty member before them)
-        prev_byte = None
-        k = m0 - 1
-        while k >= 0 and misz[k] == 0:
-            k -= 1
-        if k >= 0:
-            prev_byte = _bgzf_member_bytes(path, moff[k], ends[k])[-1]
-        err, a = None, 0
-        try:
-            if use_gpu:
-                buf = torch.empty(max(16, own_len + (1 << 20)), dtype=torch.uint8, device=dev)
-                torch.cuda.current_stream(dev).synchronize()      # (the library inflates into it on its own streams)
-                got = eng.bgzf_inflate_range(path, int(moff[m0]) if m0 < len(moff) else fsize, int(moff[m1]) if m1 < len(moff) else fsize,
-                                             buf.data_ptr(), own_len) if own_len else 0
-                if got != own_len:
-                    raise RuntimeError("tagdigger_amd: members %d..%d of %s inflate to %d bytes, their headers say %d" % (m0, m1, path, got, own_len))
-                # my first line start: the first terminator is looked for in pieces copied back (the first one holds it)
-                a, seen, pb = own_len, 0, prev_byte
-                while seen < own_len:
-                    piece = buf[seen:min(own_len, seen + (1 << 20))].cpu().numpy().tobytes()
-                    f = first_line_start(piece, pb)
-                    if f < len(piece):
-                        a = seen + f
-                        break
-                    seen += len(piece)
-                    pb = piece[-1]           # (a terminator in the piece's last byte: the next piece's first byte decides)
-            else:
-                own = _bgzf_member_bytes(path, moff[m0], ends[m1 - 1]) if m1 > m0 else b""
-                a = first_line_start(own, prev_byte)
-        except Exception as e:                 # noqa: BLE001 -- raised on every rank by _agree
-            err = e
-        _agree(err, where)
-        # every rank's first line start as an offset into the inflated file; mine end where the next one's begin
-        starts = gather_ints(int(gpos[m0]) + a if a < own_len else -1, where) + [int(gpos[-1])]
-        for r in range(world - 1, -1, -1):                                         # (a shard without a line start owns nothing)
-            if starts[r] < 0:
-                starts[r] = starts[r + 1]
-        g0, g1 = starts[rank], starts[rank + 1]
-        n = g1 - g0
-        # the part of my lines that lies in the members behind mine (a rank that owns no line has no such part)
-        tail_len = max(0, g1 - int(gpos[m1])) if n else 0
-        err = None
-        try:
-            if use_gpu:
-                if tail_len:
-                    mt = int(np.searchsorted(gpos, g1, side="left"))               # members m1 .. mt - 1 hold it
-                    cap = int(gpos[mt] - gpos[m1])
-                    if own_len + cap > buf.numel():
-                        bigger = torch.empty(own_len + cap, dtype=torch.uint8, device=dev)
-                        bigger[:own_len].copy_(buf[:own_len])
-                        buf = bigger
-                    torch.cuda.current_stream(dev).synchronize()  # (the copy above, before the library writes behind it)
-                    eng.bgzf_inflate_range(path, int(moff[m1]), int(moff[mt]) if mt < len(moff) else fsize, buf.data_ptr() + own_len, cap)
-                lo = g0 - int(gpos[m0])
-                if n == 0:
-                    shard = torch.empty(16, dtype=torch.uint8, device=dev)
-                elif lo % 16 == 0:
-                    shard = buf[lo:lo + n]                        # (where it lies: the kernels want 16-byte alignment, no more)
+        if gz_text is not None:
+            shard, n = gz_text
+        else:
+            fsize = os.path.getsize(path)
+            ends = np.append(moff[1:], np.uint64(fsize))
+            gpos = np.concatenate(([0], np.cumsum(misz.astype(np.int64))))            # inflated offset of every member (and the total)
+            m0, m1 = bgzf_member_ranges(moff, fsize, world)[rank]
+            own_len = int(gpos[m1] - gpos[m0])
+            # the byte before my members (the last byte of the nearest non-empty member before them)
+            prev_byte = None
+            k = m0 - 1
+            while k >= 0 and misz[k] == 0:
+                k -= 1
+            if k >= 0:
+                prev_byte = _bgzf_member_bytes(path, moff[k], ends[k])[-1]
+            err, a = None, 0
+            try:
+                if use_gpu:
+                    buf = torch.empty(max(16, own_len + (1 << 20)), dtype=torch.uint8, device=dev)
+                    torch.cuda.current_stream(dev).synchronize()      # (the library inflates into it on its own streams)
+                    got = eng.bgzf_inflate_range(path, int(moff[m0]) if m0 < len(moff) else fsize, int(moff[m1]) if m1 < len(moff) else fsize,
+                                                 buf.data_ptr(), own_len) if own_len else 0
+                    if got != own_len:
+                        raise RuntimeError("tagdigger_amd: members %d..%d of %s inflate to %d bytes, their headers say %d" % (m0, m1, path, got, own_len))
+                    # my first line start: the first terminator is looked for in pieces copied back (the first one holds it)
+                    a, seen, pb = own_len, 0, prev_byte
+                    while seen < own_len:
+                        piece = buf[seen:min(own_len, seen + (1 << 20))].cpu().numpy().tobytes()
+                        f = first_line_start(piece, pb)
+                        if f < len(piece):
+                            a = seen + f
+                            break
+                        seen += len(piece)
+                        pb = piece[-1]           # (a terminator in the piece's last byte: the next piece's first byte decides)
                 else:
-                    # moved down inside the buffer to the next lower multiple of 16, front to back through a 64 MiB piece
-                    # (a copy of the whole shard would hold it twice; a piece's destination ends before the next piece's source)
-                    al = lo - lo % 16
-                    step = 64 << 20
-                    for o in range(0, n, step):
-                        m = min(step, n - o)
-                        buf[al + o:al + o + m].copy_(buf[lo + o:lo + o + m].clone())
-                    shard = buf[al:al + n]
-            else:
-                if tail_len:
-                    mt = int(np.searchsorted(gpos, g1, side="left"))
-                    own = own + _bgzf_member_bytes(path, moff[m1], ends[mt - 1])
-                lo = g0 - int(gpos[m0])
-                data = own[lo:lo + n]
-        except Exception as e:                 # noqa: BLE001 -- raised on every rank by _agree
-            err = e
-        _agree(err, where)
+                    own = _bgzf_member_bytes(path, moff[m0], ends[m1 - 1]) if m1 > m0 else b""
+                    a = first_line_start(own, prev_byte)
+            except Exception as e:                 # noqa: BLE001 -- raised on every rank by _agree
+                err = e
+            _agree(err, where)
+            # every rank's first line start as an offset into the inflated file; mine end where the next one's begin
+            starts = gather_ints(int(gpos[m0]) + a if a < own_len else -1, where) + [int(gpos[-1])]
+            for r in range(world - 1, -1, -1):                                         # (a shard without a line start owns nothing)
+                if starts[r] < 0:
+                    starts[r] = starts[r + 1]
+            g0, g1 = starts[rank], starts[rank + 1]
+            n = g1 - g0
+            # the part of my lines that lies in the members behind mine (a rank that owns no line has no such part)
+            tail_len = max(0, g1 - int(gpos[m1])) if n else 0
+            err = None
+            try:
+                if use_gpu:
+                    if tail_len:
+                        mt = int(np.searchsorted(gpos, g1, side="left"))               # members m1 .. mt - 1 hold it
+                        cap = int(gpos[mt] - gpos[m1])
+                        if own_len + cap > buf.numel():
+                            bigger = torch.empty(own_len + cap, dtype=torch.uint8, device=dev)
+                            bigger[:own_len].copy_(buf[:own_len])
+                            buf = bigger
+                        torch.cuda.current_stream(dev).synchronize()  # (the copy above, before the library writes behind it)
+                        eng.bgzf_inflate_range(path, int(moff[m1]), int(moff[mt]) if mt < len(moff) else fsize, buf.data_ptr() + own_len, cap)
+                    lo = g0 - int(gpos[m0])
+                    if n == 0:
+                        shard = torch.empty(16, dtype=torch.uint8, device=dev)
+                    elif lo % 16 == 0:
+                        shard = buf[lo:lo + n]                        # (where it lies: the kernels want 16-byte alignment, no more)
+                    else:
+                        # moved down inside the buffer to the next lower multiple of 16, front to back through a 64 MiB piece
+                        # (a copy of the whole shard would hold it twice; a piece's destination ends before the next piece's source)
+                        al = lo - lo % 16
+                        step = 64 << 20
+                        for o in range(0, n, step):
+                            m = min(step, n - o)
+                            buf[al + o:al + o + m].copy_(buf[lo + o:lo + o + m].clone())
+                        shard = buf[al:al + n]
+                else:
+                    if tail_len:
+                        mt = int(np.searchsorted(gpos, g1, side="left"))
+                        own = own + _bgzf_member_bytes(path, moff[m1], ends[mt - 1])
+                    lo = g0 - int(gpos[m0])
+                    data = own[lo:lo + n]
+            except Exception as e:                 # noqa: BLE001 -- raised on every rank by _agree
+                err = e
+            _agree(err, where)
 
     if use_gpu:
         eng.set_index(barcodes, tags, cutsite)

@@ -570,3 +570,68 @@ def test_a_failing_rank_raises_on_every_rank(tmp_path):
     got = [open("%s.%d" % (out, r)).read() for r in range(3)]
     assert got[1].startswith("OSError: rank 1 cannot read")
     assert got[0].startswith("RuntimeError") and got[2].startswith("RuntimeError")
+
+
+def _gzip_shard_worker(rank, world, port, path, barcodes, tags, cutsite, maxreads, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import io
+    import contextlib
+    from tagdigger_amd import multi
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        res = multi.count_file_sharded(path, barcodes, tags, cutsite, maxreads=maxreads, device=torch.device("cuda", 0))
+    if rank == 0:
+        torch.save((res, err.getvalue()), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,maxreads,style", [(2, 5e9, "lf"), (3, 123_457, "lf"), (GPU_REHEARSAL_RANKS, 5e9, "crlf"), (4, 5e9, "cr")])
+def test_one_ordinary_gzip_file_over_the_ranks(tmp_path, world, maxreads, style):
+    """ONE gzip member decoded by several ranks (multi._gzip_shard_text over td_gz_shard_*: every rank a byte range of the
+    compressed file, symbols first, the windows through the ranks' maps, the CRC-32s joined, lines handed across the seams):
+    the matrix of the whole file, with the bound inside a later rank's share, with CRLF and CR-only lines; no rank says that
+    it reads the file alone."""
+    import gzip
+    from oracle import c_oracle
+    from tagdigger_amd.synth import SynthConfig
+    from helpers import synth_host_bytes
+    cfg = SynthConfig.from_id(2, nreads=200_000)
+    raw = synth_host_bytes(cfg, 0, cfg.nreads).tobytes()
+    if style == "crlf":
+        raw = raw.replace(b"\n", b"\r\n")
+    elif style == "cr":
+        raw = raw.replace(b"\n", b"\r")
+    gz = str(tmp_path / "lib.fq.gz")
+    with open(gz, "wb") as fh:
+        fh.write(gzip.compress(raw, compresslevel=6))
+    want = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(raw, maxreads=int(min(maxreads, 10 ** 12))).tolist()
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_gzip_shard_worker, args=(world, _free_port(), gz, list(cfg.barcodes), list(cfg.tags), cfg.cutsite, maxreads, out), nprocs=world, join=True)
+    res, err = torch.load(out)
+    assert res == want
+    assert "reads it alone" not in err, err
+
+
+@pytest.mark.gpu
+def test_gzip_files_the_ranks_cannot_share_go_to_rank_0(tmp_path):
+    """Two members, and a damaged member: the sharded scheme declines on every rank alike and rank 0 counts the file (or
+    raises what gzip.open raises) as before."""
+    import gzip
+    from oracle import c_oracle
+    from tagdigger_amd.synth import SynthConfig
+    from helpers import synth_host_bytes
+    cfg = SynthConfig.from_id(2, nreads=120_000)
+    raw = synth_host_bytes(cfg, 0, cfg.nreads).tobytes()
+    half = raw.index(b"\n@", len(raw) // 2) + 1
+    gz = str(tmp_path / "two.fq.gz")
+    with open(gz, "wb") as fh:
+        fh.write(gzip.compress(raw[:half], compresslevel=6) + gzip.compress(raw[half:], compresslevel=1))
+    want = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(raw).tolist()
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_gzip_shard_worker, args=(3, _free_port(), gz, list(cfg.barcodes), list(cfg.tags), cfg.cutsite, 5e9, out), nprocs=3, join=True)
+    res, err = torch.load(out)
+    assert res == want and "reads it alone" in err
