@@ -2050,6 +2050,7 @@ int td_gz_shard_open(td_handle *h, const char *path, uint64_t byte_lo, uint64_t 
     uint64_t start_rel = tdgz2::NONE;
     if (first) start_rel = first_abs - base * 8;
     else for (uint64_t f : sh.found) if (f != tdgz2::NONE) { start_rel = f; break; }
+    if (h->gz_gpu_false_every > 0 && !first && start_rel != tdgz2::NONE && start_rel + 4099 < in_bits) start_rel += 4099;      // (tests: a false start at the seam)
     sh.open = true; sh.path = path; sh.n = n; sh.base = base; sh.in_bits = in_bits; sh.nwords = nwords; sh.start_rel = start_rel;
     *start_bit = start_rel == tdgz2::NONE ? ~0ull : base * 8 + start_rel;
     return TD_OK;

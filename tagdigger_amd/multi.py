@@ -417,8 +417,10 @@ def _count_one_stream(path, barcodes, tags, cutsite, bound, counter, dev, as_arr
 
 def count_file_sharded(path, barcodes, tags, cutsite="TGCAG", maxreads=5e9, counter=None, device=None, as_array=False,
                        progress=False):
-    """find_tags_fastq on one FASTQ file -- plain, or BGZF-compressed (bgzip) -- sharded over the ranks of the default
-    process group; any other gzip file is counted by rank 0 alone (_count_one_stream) (every rank calls this with the same arguments; backend "nccl" = RCCL for GPUs).
+    """find_tags_fastq on one FASTQ file -- plain, BGZF-compressed (bgzip), or ONE ordinary gzip member (device path:
+    _gzip_shard_text) -- sharded over the ranks of the default process group; any other gzip file (several members, or the
+    CPU stand-in) is counted by rank 0 alone (_count_one_stream) (every rank calls this with the same arguments; backend
+    "nccl" = RCCL for GPUs).
     Returns the whole file's matrix on every rank, bit-identical to the single-GPU result for any
     number of ranks.
 

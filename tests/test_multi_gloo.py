@@ -572,13 +572,15 @@ def test_a_failing_rank_raises_on_every_rank(tmp_path):
     assert got[0].startswith("RuntimeError") and got[2].startswith("RuntimeError")
 
 
-def _gzip_shard_worker(rank, world, port, path, barcodes, tags, cutsite, maxreads, out):
+def _gzip_shard_worker(rank, world, port, path, barcodes, tags, cutsite, maxreads, out, false_seams=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import io
     import contextlib
-    from tagdigger_amd import multi
+    from tagdigger_amd import multi, tagdigger_fun
+    if false_seams:
+        tagdigger_fun.default_engine(0).set_option("gz_gpu_false_every", 1)      # (every rank's start but the first is moved by 4099 bits)
     err = io.StringIO()
     with contextlib.redirect_stderr(err):
         res = multi.count_file_sharded(path, barcodes, tags, cutsite, maxreads=maxreads, device=torch.device("cuda", 0))
@@ -633,5 +635,25 @@ def test_gzip_files_the_ranks_cannot_share_go_to_rank_0(tmp_path):
     want = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(raw).tolist()
     out = str(tmp_path / "res.pt")
     mp.spawn(_gzip_shard_worker, args=(3, _free_port(), gz, list(cfg.barcodes), list(cfg.tags), cfg.cutsite, 5e9, out), nprocs=3, join=True)
+    res, err = torch.load(out)
+    assert res == want and "reads it alone" in err
+
+
+@pytest.mark.gpu
+def test_a_false_block_start_at_a_seam_sends_the_file_to_rank_0(tmp_path):
+    """A rank whose first block start is none: the rank before it ends elsewhere, the seam does not close, every rank sees
+    that in the gathered positions and rank 0 counts the file alone -- the matrix is the same."""
+    import gzip
+    from oracle import c_oracle
+    from tagdigger_amd.synth import SynthConfig
+    from helpers import synth_host_bytes
+    cfg = SynthConfig.from_id(2, nreads=150_000)
+    raw = synth_host_bytes(cfg, 0, cfg.nreads).tobytes()
+    gz = str(tmp_path / "lib.fq.gz")
+    with open(gz, "wb") as fh:
+        fh.write(gzip.compress(raw, compresslevel=6))
+    want = c_oracle.COracle(cfg.barcodes, cfg.tags, cfg.cutsite).count_bytes(raw).tolist()
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_gzip_shard_worker, args=(3, _free_port(), gz, list(cfg.barcodes), list(cfg.tags), cfg.cutsite, 5e9, out, True), nprocs=3, join=True)
     res, err = torch.load(out)
     assert res == want and "reads it alone" in err
