@@ -364,16 +364,16 @@ def _gzip_shard_text(eng, path, dev):
 
 
 def _count_one_stream(path, barcodes, tags, cutsite, bound, counter, dev, as_array, progress):
-    """An ordinary gzip file (one DEFLATE stream: no place to cut it without decoding everything before) under
+    """A gzip file that _gzip_shard_text does not take (several members, a seam that does not close; the CPU stand-in) under
     count_file_sharded: the reference reads any .gz by name (:240-241), so it is counted -- by rank 0 alone, through
-    td_count_file (decoded by its host's threads, resolved on its GPU), the other ranks adding zeros to the same
-    all-reduce.  One library per rank (find_tags_fastq_many) or bgzip is the way to use every GPU."""
+    td_count_file (decoded on its device, or by its host's threads), the other ranks adding zeros to the same all-reduce."""
     import gzip
     import sys
     rank, world = _rank_world()
     if rank == 0 and world > 1:
-        print("tagdigger_amd: %s is one gzip stream and cannot be shared out; rank 0 reads it alone "
-              "(bgzip-compressed files are sharded by members)" % path, file=sys.stderr)
+        print("tagdigger_amd: %s is a gzip file the ranks cannot share (several members, a seam between two ranks' ranges that does "
+              "not close, or the CPU stand-in); rank 0 reads it alone "
+              "(one ordinary gzip member is decoded by all ranks, bgzip-compressed files are sharded by members)" % path, file=sys.stderr)
     if counter is not None:
         out = np.zeros((len(barcodes), len(tags)), dtype=np.int64)
         err = None
