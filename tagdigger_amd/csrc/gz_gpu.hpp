@@ -2,20 +2,21 @@
 // The host threads of par_inflate.hpp bound that tier (16 cores decode ~3 GB/s of compressed data into symbols, and the
 // symbols are twice the size of the text on their way over PCIe); here only the compressed bytes go to the device:
 //   1. k_gz_find     one wave per territory of the compressed file (128 KiB): the first bit position where a block
-//                    starts that only a compressor would write -- non-final, dynamic Huffman, all three codes complete --
-//                    and that decodes to its end code and is followed by another plausible header.  64 positions a step:
-//                    a lane each for the header's fixed fields and the code-length code's Kraft sum; the few that pass are
-//                    looked at by the whole wave.
-//   2. k_gz_tokens   one wave per chunk (from one found start to the next): the Huffman decoding, SERIAL per stream and
-//                    therefore wave-uniform scalar code -- bit buffer, positions and table entries live in scalar registers,
-//                    the tables (10-bit literal/length, 8-bit distance, canonical arrays for longer codes) in 3.5 KiB of LDS
-//                    per wave, the lanes work together where there is something to share out (a block's tables, the
-//                    compressed bytes: 64 words a load, read by lane number; the tokens: staged in a register, stored 64 at a
-//                    time).  Output: TOKENS (a literal, or length + distance) -- the decoder never reads what it has decoded,
-//                    so no memory latency sits in its loop.  A chunk ends at the first block boundary at or past its
-//                    successor's start.
+//                    starts that only a compressor would write -- non-final, dynamic Huffman, all three codes complete, an
+//                    end code present.  64 positions a step: a lane each for the header's fixed fields and the code-length
+//                    code's Kraft sum; the few that pass are looked at by the whole wave, which builds the tables as the
+//                    decoder does (option gz_gpu_verify: it also decodes the block and asks for a header behind it).
+//   2. k_gz_tokens   one wave per chunk (from one found start to the next): the Huffman decoding.  WHERE a code starts is
+//                    serial, WHAT would start at a bit is not: every lane decodes the token that would begin at its bit of the
+//                    next 64 (two table look-ups for all lanes at once: 10-bit literal/length and 8-bit distance tables of
+//                    32-bit entries, 6 KiB of LDS per wave, built by the wave's lanes), the wave follows the chain from bit 0
+//                    by lane number, the lanes that were real store their tokens.  Block headers and the rare longer codes
+//                    are read by wave-uniform scalar code; the compressed bytes sit in two registers, 64 words each.
+//                    Output: TOKENS (a literal, or length + distance) -- the decoder never reads what it has decoded, so no
+//                    memory latency sits in its loop.  A chunk ends at the first block boundary at or past its successor's
+//                    start.
 //   3. the host chains the chunks (each must begin exactly where its predecessor ended: the result never depends on
-//      what step 1 found), and sums their sizes;
+//      what step 1 found; the stretch behind a false start is decoded a second time), and sums their sizes;
 //   4. k_gz_lz       one wave per chunk, 64 tokens at a time: positions by a wave scan, literals stored, copies made lane
 //                    by lane in rounds (a copy waits for the copies in front of it that it reads from); a copy that reaches
 //                    before its chunk gives MARKERS (0x8000 | position in the unknown 32 KiB before the chunk), as in
