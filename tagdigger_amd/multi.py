@@ -240,14 +240,13 @@ def _gzip_shard_text(eng, path, dev):
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         return int(flag[0]) == 0
 
-    from ._binding import TagdigError
     # 1. every rank's first block start
     lo, hi = fsize * rank // world, fsize * (rank + 1) // world
     start, ok = NONE, True
     try:
         s, _ = eng.gz_shard_open(path, lo, hi, rank == 0)
         start = NONE if s is None else s
-    except TagdigError:
+    except Exception:                          # noqa: BLE001 -- every rank learns of it in all_ok and declines alike
         ok = False
     if not all_ok(ok):
         return None
@@ -263,7 +262,7 @@ def _gzip_shard_text(eng, path, dev):
         try:
             end, nout, fin, mp = eng.gz_shard_decode(nxt[0] if nxt else None)
             final = 1 if fin else 0
-        except TagdigError:
+        except Exception:                      # noqa: BLE001 -- every rank learns of it in all_ok and declines alike
             ok = False
     if not all_ok(ok):
         return None
@@ -277,10 +276,16 @@ def _gzip_shard_text(eng, path, dev):
     # the member's trailer, and nothing but zeros behind it (more members: the one-rank path reads them)
     trailer = (info[last][0] + 7) // 8
     total_len = sum(info[r][1] for r in live)
-    with open(path, "rb") as fh:
-        fh.seek(trailer)
-        tail = fh.read()
-    if len(tail) < 8 or any(tail[8:]):
+    tail = None
+    try:
+        with open(path, "rb") as fh:
+            fh.seek(trailer)
+            tail = fh.read(8 + (1 << 20))                      # (zero padding behind a member is short; more than that: the one-rank path)
+    except OSError:
+        pass
+    if not all_ok(tail is not None):
+        return None
+    if len(tail) < 8 or any(tail[8:]) or trailer + len(tail) < fsize:
         return None
     want_crc, want_len = struct.unpack("<II", tail[:8])
     if want_len != total_len & 0xFFFFFFFF:
@@ -301,7 +306,7 @@ def _gzip_shard_text(eng, path, dev):
     if rank in live:
         try:
             ptr, crc = eng.gz_shard_resolve(window, before)
-        except TagdigError:
+        except Exception:                      # noqa: BLE001 -- every rank learns of it in all_ok and declines alike
             ok = False
     if not all_ok(ok):
         return None
@@ -312,9 +317,14 @@ def _gzip_shard_text(eng, path, dev):
     if joined != want_crc:
         return None                                            # (the one-rank path raises what gzip.open raises)
     # 4. lines: a rank gives its text up to and including its first terminator to the rank before it
-    head = b""
-    if rank in live and nout:
-        head = eng.d2h(ptr, min(nout, HEAD))
+    head, ok = b"", True
+    try:
+        if rank in live and nout:
+            head = eng.d2h(ptr, min(nout, HEAD))
+    except Exception:                          # noqa: BLE001
+        ok = False
+    if not all_ok(ok):
+        return None
     cut = None                                                 # (bytes of my text that are the previous rank's line)
     for k, c in enumerate(head):
         if c == 10:
@@ -341,23 +351,30 @@ def _gzip_shard_text(eng, path, dev):
         heads_t[2:2 + give] = torch.tensor(list(head[:give]), dtype=torch.int32, device=dev)
     every = [torch.zeros_like(heads_t) for _ in range(world)]
     dist.all_gather(every, heads_t)
-    tail_bytes = b""
-    for r in range(rank + 1, world):
-        g = int(every[r][0])
-        tail_bytes += bytes(every[r][2:2 + g].cpu().numpy().astype(np.uint8).tobytes())
-        if r in live and not int(every[r][1]):                 # (its text has a terminator: my last line ends in what it gave)
-            break
+    gives = [int(every[r][0]) for r in range(world)]
+    wholes = [int(every[r][1]) for r in range(world)]
+
+    def tail_of(q):
+        """the ranks whose heads end rank q's last line"""
+        took = []
+        for r in range(q + 1, world):
+            took.append(r)
+            if r in live and not wholes[r]:                    # (its text has a terminator: the line ends in what it gave)
+                break
+        return took
+    # (every rank sees every rank's numbers: room behind a text for the heads it takes -- td_gz_shard_resolve leaves 1 MiB and an eighth)
+    if any(sum(gives[r] for r in tail_of(q)) > (1 << 20) + (info[q][1] >> 3) for q in live):
+        return None
+    tail_bytes = b"".join(bytes(every[r][2:2 + gives[r]].cpu().numpy().astype(np.uint8).tobytes()) for r in tail_of(rank))
     # a '\r' that ended a rank's text and the '\n' the next rank's text begins with are one terminator: that '\n' is in
     # the head it gave away (its first terminator is that '\n'), so nothing more to do
     if rank not in live or whole:
         return _DevRange(0), 0
     own0, own1 = give, nout
+    al = own0 - own0 % 16
     if tail_bytes:
-        if len(tail_bytes) > 4096 + (nout >> 3):
-            return None
         eng.h2d(ptr + nout, tail_bytes)
         own1 = nout + len(tail_bytes)
-    al = own0 - own0 % 16
     if own0 > al:
         eng.h2d(ptr + al, b" " * (own0 - al))
     return _DevRange(ptr + al), own1 - al
