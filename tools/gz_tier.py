@@ -34,6 +34,8 @@ cfg.expected_device(eng, dw, 0, reads)
 want = np.frombuffer(eng.d2h(dw, cells * 4), dtype=np.uint32).reshape(len(cfg.barcodes), len(cfg.tags))
 eng.dev_free(dw)
 eng.set_index(cfg.barcodes, cfg.tags, cfg.cutsite)
+for kv in os.environ.get('TD_OPTS', '').split():      # e.g. TD_OPTS='gz_gpu_seg_kb=170000 gz_gpu_terr_kb=32'
+    k, v = kv.split('='); eng.set_option(k, int(v))
 with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR")) as tmp:
     path = os.path.join(tmp, "tier.fq.gz")
     with open(path, "wb") as fh:
