@@ -399,9 +399,10 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
 
 // ---------------------------------------------------------------- 1. the block search
 // found[t] (t >= 1): the first block start in territory t, or NONE
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_gz_find(const uint8_t *in, uint64_t in_bits, uint64_t nwords, uint64_t first_bit,
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_gz_find(const uint8_t *in, uint64_t in_bits, uint64_t nwords, uint64_t first_bit,
                                                         uint64_t terr_bits, uint32_t nterr, uint64_t *found, uint32_t verify, uint32_t t_first) {
     __shared__ WaveMem mem[WAVES];
+    __shared__ uint64_t queue[WAVES][128];
     const int lane = (int)(threadIdx.x & 63u);
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint32_t t = blockIdx.x * WAVES + wave + t_first;              // (t_first 1: territory 0 begins with the known start)
@@ -413,54 +414,34 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(6, 8
     uint64_t result = NONE;
     Bits b;
     b.base = reinterpret_cast<const uint32_t *>(in); b.nwords = nwords;
-    for (uint64_t p0 = lo; p0 < hi && result == NONE; p0 += 64u) {
-        const uint64_t p = p0 + (uint32_t)lane;
-        // the header's fixed fields and the code-length code's lengths: 17 + 3 x 19 bits from p
+    // the 17 + 3 x 19 bits of a header's fixed fields and code-length code from bit p on
+    auto window = [&](uint64_t p, uint64_t &x0, uint64_t &x1) {
         uint64_t w0, w1;
         __builtin_memcpy(&w0, in + (p >> 3), 8);
         __builtin_memcpy(&w1, in + (p >> 3) + 8, 8);
         const uint32_t sh = (uint32_t)p & 7u;
-        const uint64_t x0 = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0, x1 = w1 >> sh;
-        bool cand = p < hi && ((uint32_t)x0 & 7u) == 4u && (((uint32_t)x0 >> 3) & 31u) <= 29u && (((uint32_t)x0 >> 8) & 31u) <= 29u;
-        if (cand) {
-            const uint32_t ncl = (((uint32_t)x0 >> 13) & 15u) + 4u;
-            const uint64_t y = (x0 >> 17) | (x1 << 47);
-            uint32_t kraft = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < 19u; i++) {
-                const uint32_t l = (uint32_t)(y >> (3u * i)) & 7u;
-                kraft += i < ncl && l ? 128u >> l : 0u;
-            }
-            cand = kraft == 128u;
-        }
-        uint64_t mask = __ballot(cand);
-        while (mask) {
-            const uint32_t l = (uint32_t)__builtin_ctzll(mask);
-            mask &= mask - 1u;
-            const uint64_t pc = p0 + l;
-            // the whole wave on this position: the header, the block to its end code, the header behind it
-            bits_init(b, pc, lane);
-            uint32_t final, stored;
-            if (read_header(b, m, true, final, stored, lane) != 2) continue;
-            if (lane == 0) atomicAdd((unsigned long long *)(found + nterr), 1ull);          // (statistics: headers that pass)
-            // verify: the block is decoded to its end code, and another header must follow -- else the headers' checks are
-            // trusted (they left no false start in 10^9 positions of the measured file), and a false start costs the chunk in
-            // front of it a second decoding when the host chains the chunks
-            if (!verify) {
-                result = pc;
-                if (lane == 0) atomicAdd((unsigned long long *)(found + nterr + 1), 1ull);
-                break;
-            }
+        x0 = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
+        x1 = w1 >> sh;
+    };
+    // the whole wave on one position: the header (and with `verify` the block to its end code and the header behind it)
+    auto validate = [&](uint64_t pc) -> bool {
+        bits_init(b, pc, lane);
+        uint32_t final, stored;
+        if (read_header(b, m, true, final, stored, lane) != 2) return false;
+        if (lane == 0) atomicAdd((unsigned long long *)(found + nterr), 1ull);          // (statistics: headers that pass)
+        // verify: the block is decoded to its end code, and another header must follow -- else the headers' checks are
+        // trusted (they left no false start in 10^9 positions of the measured file), and a false start costs the chunk in
+        // front of it a second decoding when the host chains the chunks
+        if (verify) {
             uint64_t at = bitpos(b);
             uint32_t nsym = 0;
             const uint32_t dr = decode_block(b, at, in_bits, m, lane, [&](uint64_t mask, uint32_t) { nsym += (uint32_t)__builtin_popcountll(mask); return nsym < (1u << 21); });
-            if (dr != S_NONE || at + 3u > in_bits) continue;
+            if (dr != S_NONE || at + 3u > in_bits) return false;
             bits_init(b, at, lane);
-            // what follows must read as a header as well
             refill(b, lane);
             const uint32_t nx = (uint32_t)b.bb;
             const uint32_t ntype = (nx >> 1) & 3u;
-            if (ntype == 3u) continue;
+            if (ntype == 3u) return false;
             if (ntype == 0u) {
                 drop(b, 3);
                 drop(b, b.bc & 7u);
@@ -468,15 +449,62 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(6, 8
                 const uint32_t len = take(b, 16);
                 refill(b, lane);
                 const uint32_t nlen = take(b, 16);
-                if ((len ^ nlen) != 0xFFFFu) continue;
+                if ((len ^ nlen) != 0xFFFFu) return false;
             } else if (ntype == 2u) {
-                if (((nx >> 3) & 31u) > 29u || ((nx >> 8) & 31u) > 29u) continue;
+                if (((nx >> 3) & 31u) > 29u || ((nx >> 8) & 31u) > 29u) return false;
             }
-            result = pc;
-            if (lane == 0) atomicAdd((unsigned long long *)(found + nterr + 1), 1ull);      // (... of them block starts)
-            break;
         }
+        if (lane == 0) atomicAdd((unsigned long long *)(found + nterr + 1), 1ull);      // (... of them block starts)
+        return true;
+    };
+    // Two sieves.  The first (three header bits, two 5-bit counts: one position in nine passes) runs on 64 positions a step; what
+    // passes waits in a queue until 64 are together for the second (the code-length code's Kraft sum: nineteen fields) -- run on
+    // the few lanes of every step it was two thirds of the search's instructions.
+    uint64_t *q = queue[wave];
+    uint32_t nq = 0;
+    auto drain = [&](bool all) {
+        while (result == NONE && (nq >= 64u || (all && nq))) {
+            const uint32_t n = nq < 64u ? nq : 64u;
+            const uint64_t pq = (uint32_t)lane < n ? q[lane] : 0ull;
+            bool pass = false;
+            if ((uint32_t)lane < n) {
+                uint64_t x0, x1;
+                window(pq, x0, x1);
+                const uint32_t ncl = (((uint32_t)x0 >> 13) & 15u) + 4u;
+                const uint64_t y = (x0 >> 17) | (x1 << 47);
+                uint32_t kraft = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 19u; i++) {
+                    const uint32_t l = (uint32_t)(y >> (3u * i)) & 7u;
+                    kraft += i < ncl && l ? 128u >> l : 0u;
+                }
+                pass = kraft == 128u;
+            }
+            uint64_t pm = __ballot(pass);
+            while (pm && result == NONE) {                              // (in the order of the positions: the first start counts)
+                const int l = (int)__builtin_ctzll(pm);
+                pm &= pm - 1u;
+                const uint64_t pc = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pq >> 32), l) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pq, l);
+                if (validate(pc)) result = pc;
+            }
+            const bool more = (uint32_t)lane + n < nq;
+            const uint64_t rest = more ? q[(uint32_t)lane + n] : 0ull;
+            if (more) q[lane] = rest;
+            nq -= n;
+        }
+    };
+    for (uint64_t p0 = lo; p0 < hi && result == NONE; p0 += 64u) {
+        const uint64_t p = p0 + (uint32_t)lane;
+        uint64_t x0, x1;
+        window(p, x0, x1);
+        const bool cand = p < hi && ((uint32_t)x0 & 7u) == 4u && (((uint32_t)x0 >> 3) & 31u) <= 29u && (((uint32_t)x0 >> 8) & 31u) <= 29u;
+        const uint64_t cm = __ballot(cand);
+        if (cand) q[nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u))] = p;
+        nq += (uint32_t)__builtin_popcountll(cm);
+        drain(false);
     }
+    drain(true);
     if (lane == 0) found[t] = result;
 }
 
