@@ -381,3 +381,47 @@ def test_progress_windows_through_the_device_decoder(sample, tmp_path):
         _check(e, want, ost, "with the progress windows")
     finally:
         e.close()
+
+
+def test_campaign_against_zlib(eng, tmp_path):
+    """Random structured bytes, random compressor settings (level, strategy, memLevel, window size, flushes), random territory
+    and segment sizes, for TD_GZ_FUZZ_SECONDS seconds (default 15; a soak run uses minutes): the device decoder's text is
+    zlib's, or it leaves the file to the host decoders."""
+    import time
+    budget = float(os.environ.get("TD_GZ_FUZZ_SECONDS", "15"))
+    seed0 = int(os.environ.get("TD_GZ_FUZZ_SEED", "4242"))
+    t_end = time.time() + budget
+    ncase = took = 0
+    try:
+        while time.time() < t_end:
+            rng = random.Random(seed0 + ncase)
+            data = _structured_bytes(rng, rng.randint(200_000, 3_000_000))
+            level = rng.choice([1, 1, 4, 6, 6, 9])
+            strategy = rng.choice([zlib.Z_DEFAULT_STRATEGY] * 4 + [zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])
+            co = zlib.compressobj(level, zlib.DEFLATED, -rng.choice([15, 15, 15, 12, 9]), rng.choice([8, 8, 9, 4, 1]), strategy)
+            every = rng.choice([0, 0, 3000, 40_000, 400_000])
+            parts = []
+            if every:
+                for i in range(0, len(data), every):
+                    parts.append(co.compress(data[i:i + every]))
+                    parts.append(co.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH])))
+            else:
+                parts.append(co.compress(data))
+            parts.append(co.flush())
+            blob = _member(data, b"".join(parts)) + b"\0" * rng.choice([0, 0, 7, 513])
+            path = str(tmp_path / "c.gz")
+            with open(path, "wb") as fh:
+                fh.write(blob)
+            eng.set_option("gz_gpu_terr_kb", rng.choice([16, 32, 64, 128]))
+            eng.set_option("gz_gpu_seg_kb", rng.choice([1 << 20, 1 << 20, 300, 1100]))
+            eng.set_option("gz_gpu_margin_kb", rng.choice([16384, 128, 512]))
+            eng.set_option("gz_gpu_verify", rng.choice([0, 0, 1]))
+            got = eng.gunzip_file_gpu(path, len(data) + 64)
+            assert got is None or got == data, ("seed", seed0 + ncase)
+            took += got is not None
+            ncase += 1
+    finally:
+        for k, v in (("gz_gpu_seg_kb", 1 << 20), ("gz_gpu_margin_kb", 16384), ("gz_gpu_terr_kb", 128), ("gz_gpu_verify", 0)):
+            eng.set_option(k, v)
+    print(" [gzip campaign: %d cases, %d decoded on the device] " % (ncase, took), end="")
+    assert ncase > 0 and took * 2 >= ncase
