@@ -372,13 +372,17 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
                 sbits.bb = ((((uint64_t)smid << 32) | slo) >> sr) | (((uint64_t)shi << 1) << (63u - sr));
                 sbits.bc = 64u;
                 uint32_t tk = 0;
-                const uint32_t se = next_entry<0>(sbits, m.ltab, LROOT, m.lsym, m.lcnt);
+                // (the tables through a pointer the compiler cannot see through: it had hoisted the loads of the canonical arrays -- six LDS
+                // reads and their unpacking -- out of this rare branch into every step of the loop)
+                const WaveMem *mm = &m;
+                asm volatile("" : "+v"(mm));
+                const uint32_t se = next_entry<0>(sbits, mm->ltab, LROOT, mm->lsym, mm->lcnt);
                 if (se == E_NONE || (se & F_BAD)) return S_ERR;
                 if (se & F_END) { info = (64u - sbits.bc) | (2u << 8); }
                 else if (!(se & F_COPY)) { tk = (se >> 8) & 0xFFu; info = 64u - sbits.bc; }
                 else {
                     const uint32_t slen = ((se >> 8) & 0xFFFFu) + take(sbits, (se >> 4) & 15u);
-                    const uint32_t sd = next_entry<1>(sbits, m.dtab, DROOT, m.dsym, m.dcnt);
+                    const uint32_t sd = next_entry<1>(sbits, mm->dtab, DROOT, mm->dsym, mm->dcnt);
                     if (sd == E_NONE || (sd & F_BAD)) return S_ERR;
                     const uint32_t sdist = ((sd >> 8) & 0xFFFFu) + take(sbits, (sd >> 4) & 15u);
                     tk = 0x80000000u | (slen << 15) | (sdist - 1u);
