@@ -360,9 +360,10 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
         uint32_t o = 0;
         uint64_t onpath = 0;
         bool ended = false;
-        while (o < 64u) {
+        do {
             uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)vinfo, (int)o);
-            if (__builtin_expect((info >> 8) == 3u, 0)) {
+            if (__builtin_expect(info >= 0x200u, 0)) {                    // (one test on the way of a literal or a copy: the end code, or the scalar code's token)
+            if (info >= 0x300u) {
                 // the scalar decoder on this one token: 64 bits from its position are enough (15 + 5 + 15 + 13)
                 if (nslow) (*nslow)++;
                 const uint32_t sb = off + o, sq = sb >> 5, sr = sb & 31u;
@@ -391,9 +392,10 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
                 if ((uint32_t)lane == o) vtok = tk;
             }
             if ((info >> 8) == 2u) { ended = true; o += info & 0xFFu; break; }
+            }
             onpath |= 1ull << o;
             o += info & 0xFFu;
-        }
+        } while (o < 64u);
         // the real tokens, in order, to the sink (false: it has no room, or has seen enough)
         if (onpath && !sink(onpath, vtok)) return S_TOKCAP;
         cur += o;
