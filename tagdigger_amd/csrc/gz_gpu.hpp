@@ -356,13 +356,23 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
         const uint32_t kind = rare ? 3u : (e & F_END) ? 2u : copy ? 1u : 0u;
         uint32_t vtok = copy ? 0x80000000u | (len << 15) | (dist - 1u) : (e >> 8) & 0xFFu;
         uint32_t vinfo = (copy ? l1 + ext + l2 + dext : l1) | (kind << 8);
-        // the chain from bit 0: which lanes' tokens are real
+        // the chain from bit 0: which lanes' tokens are real.  The common way is five scalar instructions a token: the jump to the next
+        // token's lane; an end code or a token for the scalar code jumps out of the window and is looked at behind the loop.
+        const uint32_t vjump = kind >= 2u ? 64u : (vinfo & 0xFFu);
         uint32_t o = 0;
         uint64_t onpath = 0;
         bool ended = false;
-        do {
-            uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)vinfo, (int)o);
-            if (__builtin_expect(info >= 0x200u, 0)) {                    // (one test on the way of a literal or a copy: the end code, or the scalar code's token)
+        for (;;) {
+            uint32_t last;
+            do {
+                last = o;
+                onpath |= 1ull << o;
+                o += (uint32_t)__builtin_amdgcn_readlane((int)vjump, (int)o);
+            } while (o < 64u);
+            uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)vinfo, (int)last);
+            if (__builtin_expect(info < 0x200u, 1)) break;
+            onpath &= ~(1ull << last);
+            o = last;
             if (info >= 0x300u) {
                 // the scalar decoder on this one token: 64 bits from its position are enough (15 + 5 + 15 + 13)
                 if (nslow) (*nslow)++;
@@ -392,10 +402,10 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
                 if ((uint32_t)lane == o) vtok = tk;
             }
             if ((info >> 8) == 2u) { ended = true; o += info & 0xFFu; break; }
-            }
             onpath |= 1ull << o;
             o += info & 0xFFu;
-        } while (o < 64u);
+            if (o >= 64u) break;
+        }
         // the real tokens, in order, to the sink (false: it has no room, or has seen enough)
         if (onpath && !sink(onpath, vtok)) return S_TOKCAP;
         cur += o;
