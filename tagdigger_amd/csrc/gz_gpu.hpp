@@ -632,14 +632,48 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_lz(const uint32_t *tok, const
             const uint32_t fhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)pos >> 32), first);
             const int64_t F = (int64_t)(((uint64_t)fhi << 32) | flo);
             const bool ready = pending && src + (int64_t)need <= F;
+            // long copies (48 symbols and more, source and destination apart) by the whole wave: four symbols a lane, up to four
+            // copies' loads in flight before their stores -- one lane alone takes a memory round trip per sixteen symbols
+            const bool coop = ready && L >= 48u && L <= dist && src >= 0;
+            const uint32_t cdone = coop ? (L & ~3u) < 256u ? (L & ~3u) : 256u : 0u;      // what the wave copies of this lane's copy
+            for (uint64_t cm = __ballot(coop); cm;) {
+                int64_t cs[4], cp[4];
+                uint32_t cn[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    cn[q] = 0; cs[q] = 0; cp[q] = 0;
+                    if (cm) {
+                        const int l = (int)__builtin_ctzll(cm);
+                        cm &= cm - 1u;
+                        cs[q] = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)src >> 32), l) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)src, l));
+                        cp[q] = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)pos >> 32), l) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)pos, l));
+                        cn[q] = (uint32_t)__builtin_amdgcn_readlane((int)cdone, l);
+                    }
+                }
+                uint64_t cv[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (4u * (uint32_t)lane < cn[q]) __builtin_memcpy(&cv[q], out + cs[q] + 4 * lane, 8);
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (4u * (uint32_t)lane < cn[q]) __builtin_memcpy(out + cp[q] + 4 * lane, &cv[q], 8);
+            }
             if (ready) {
-                if (L <= dist && src >= 0) {
+                if (dist == 1u && src >= 0 && L > 1u) {
+                    // a run of one symbol (the commonest overlap): one load, stores only
+                    const uint64_t y = out[src];
+                    const uint64_t v4 = y | (y << 16) | (y << 32) | (y << 48);
+                    uint16_t *dp = out + pos;
+                    uint32_t j = 0;
+                    for (; j + 4u <= L; j += 4u) __builtin_memcpy(dp + j, &v4, 8);
+                    for (; j < L; j++) dp[j] = (uint16_t)y;
+                } else if (L <= dist && src >= 0) {
                     // the common copy -- source and destination apart, nothing from before the chunk: four symbols (8 bytes, at any
                     // 2-byte boundary) a load, sixteen symbols in flight before the first store (a load that had to wait for the
                     // store before it would take a memory round trip per piece)
                     const uint16_t *sp = out + src;
                     uint16_t *dp = out + pos;
-                    uint32_t j = 0;
+                    uint32_t j = cdone;
                     for (; j + 16u <= L; j += 16u) {
                         uint64_t v[4];
 #pragma unroll
