@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace tdhost {
@@ -206,11 +207,23 @@ class FastInflate {
     static uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
         struct Powers { uint32_t t[64]; Powers() { uint32_t p = 1u << 30; t[0] = p; for (int k = 1; k < 64; k++) t[k] = p = poly_mul(p, p); } };
         static const Powers pw;                                   // t[k] = x^(2^k) mod P
-        if (len_b == 0) return crc_a;
-        uint32_t f = 1u << 31;                                    // x^0
+        // crc_a * x^(8 len_b): one multiplication by x^(8 * 2^k) for every bit k of len_b, each a constant -- linear in crc_a, so
+        // four look-ups in tables of 256 entries, made when a k is first met.  (A device-decoded segment of 1 GiB joins 86 000 blocks
+        // of 64 KiB and 8 000 of odd lengths: with bit-by-bit multiplications that was 19 ms of host time a segment, nothing running.)
+        struct Shift { std::once_flag once; uint32_t t[4][256]; };
+        static Shift sh[61];
+        uint32_t v = crc_a;
         uint64_t n = len_b;
-        for (int k = 3; n; n >>= 1, k++) if (n & 1) f = poly_mul(pw.t[k], f);        // x^(8 len_b)
-        return poly_mul(f, crc_a) ^ crc_b;
+        for (int k = 0; n && k < 61; n >>= 1, k++) {
+            if (!(n & 1)) continue;
+            Shift &s = sh[k];
+            std::call_once(s.once, [&s, k]() {
+                const uint32_t f = pw.t[k + 3];
+                for (int j = 0; j < 4; j++) for (uint32_t b = 0; b < 256; b++) s.t[j][b] = poly_mul(f, b << (8 * j));
+            });
+            v = s.t[0][v & 255u] ^ s.t[1][(v >> 8) & 255u] ^ s.t[2][(v >> 16) & 255u] ^ s.t[3][v >> 24];
+        }
+        return v ^ crc_b;
     }
     // zlib's convention (inverted going in and coming out)
     static uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n) {

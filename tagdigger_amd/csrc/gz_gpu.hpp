@@ -322,20 +322,33 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
     Bits t = rd;
     t.w0 = (pos >> 5) & ~(uint64_t)63;
     uint32_t cur = (uint32_t)(pos - (t.w0 << 5));
+    // three blocks of 64 words in registers: the two a step reads from, and the one behind them -- loaded a block ahead and waited
+    // for only where it moves up.  (With two, the step's first read of vnext made the compiler wait for the memory counter in
+    // EVERY step, and on this hardware that counter holds the stores as well: each step waited for the token store of the
+    // step before, a round trip to the L2.)
     uint32_t vin = bits_block(t, 0u, lane), vnext = bits_block(t, 1u, lane);
+    asm volatile("" : "+v"(vin), "+v"(vnext));
+    uint32_t vnn = bits_block(t, 2u, lane);
     for (;;) {
         if (cur >= 2048u) {
             t.w0 += 64u; cur -= 2048u;
-            vin = vnext; vnext = bits_block(t, 1u, lane);
+            vin = vnext; vnext = vnn;
+            asm volatile("" : "+v"(vnext));
+            vnn = bits_block(t, 2u, lane);
         }
         if ((t.w0 << 5) + cur > in_bits) return S_ERR;
         const uint32_t k0 = cur >> 5, off = cur & 31u;
         uint32_t W[5];
+        if (__builtin_expect(k0 + 4u < 64u, 1)) {                      // (fifteen steps in sixteen: all five words in the first register)
 #pragma unroll
-        for (uint32_t i = 0; i < 5u; i++) {
-            const uint32_t k = k0 + i;
-            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)(k & 63u)), c = (uint32_t)__builtin_amdgcn_readlane((int)vnext, (int)(k & 63u));
-            W[i] = k < 64u ? a : c;
+            for (uint32_t i = 0; i < 5u; i++) W[i] = (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)(k0 + i));
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 5u; i++) {
+                const uint32_t k = k0 + i;
+                const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)(k & 63u)), c = (uint32_t)__builtin_amdgcn_readlane((int)vnext, (int)(k & 63u));
+                W[i] = k < 64u ? a : c;
+            }
         }
         // this lane's 64 bits from its position on
         const uint32_t bp = off + (uint32_t)lane, q = bp >> 5, r = bp & 31u;
@@ -363,12 +376,13 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
         uint64_t onpath = 0;
         bool ended = false;
         for (;;) {
-            uint32_t last;
+            uint32_t last, j;
             do {
-                last = o;
-                onpath |= 1ull << o;
-                o += (uint32_t)__builtin_amdgcn_readlane((int)vjump, (int)o);
+                asm("s_bitset1_b64 %0, %1" : "+s"(onpath) : "s"(o));            // onpath |= 1 << o
+                j = (uint32_t)__builtin_amdgcn_readlane((int)vjump, (int)o);
+                o += j;
             } while (o < 64u);
+            last = o - j;
             uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)vinfo, (int)last);
             if (__builtin_expect(info < 0x200u, 1)) break;
             onpath &= ~(1ull << last);
@@ -609,9 +623,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_lz(const uint32_t *tok, const
     const uint32_t *tk = tok + chunks[ci].tok_off;
     uint16_t *out = sym + sym_off[ci];
     int64_t base = 0;
+    uint32_t tnext = (uint32_t)lane < ntok ? tk[lane] : 0u;
     for (uint32_t g = 0; g < ntok; g += 64u) {
         const bool valid = g + (uint32_t)lane < ntok;
-        const uint32_t t = valid ? tk[g + (uint32_t)lane] : 0u;
+        const uint32_t t = tnext;
+        // the next 64 tokens are asked for now: their way from memory lies behind this group's first wait for its stores
+        tnext = g + 64u + (uint32_t)lane < ntok ? tk[g + 64u + (uint32_t)lane] : 0u;
         const bool match = valid && (t >> 31);
         const uint32_t L = match ? (t >> 15) & 0x1FFu : (valid ? 1u : 0u);
         const uint32_t dist = (t & 0x7FFFu) + 1u;

@@ -104,3 +104,32 @@ def test_write_counts_numpy_path_is_byte_identical(tmp_path):
     tf.writeCounts(b, np.array(counts, dtype=np.int64), names, tags)
     assert open(a, "rb").read() == open(b, "rb").read()
     assert open(a, "rb").read().split(b"\r\n")[1] == b",0,1,2"
+
+
+def test_crc32_join_against_zlib():
+    """td_crc32_join (host arithmetic, no GPU): CRC-32 of a || b from the two halves' CRC-32s and len(b), against zlib over
+    lengths with every bit pattern the decoders meet -- the device decoder's 64 KiB blocks, odd remainders, empty halves, and
+    lengths past 2^32 (by the law join(join(a, b), c) == join(a, join(b, c)))."""
+    import zlib
+    from tagdigger_amd import _binding as B
+    L = B.load()
+    rng = random.Random(12)
+    data = rng.randbytes(1 << 20)
+    for _ in range(300):
+        la = rng.choice([0, 1, 7, 65536, rng.randrange(1 << 18)])
+        lb = rng.choice([0, 1, 3, 255, 256, 65535, 65536, 65537, rng.randrange(1 << 19)])
+        a, b = data[:la], data[la:la + lb]
+        assert L.td_crc32_join(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b), (la, lb)
+    # a run of joins in the decoder's order equals the CRC-32 of the whole
+    run, at = zlib.crc32(b""), 0
+    while at < len(data):
+        n = min(len(data) - at, rng.choice([65536, 65536, 65536, rng.randrange(1, 65536)]))
+        run = L.td_crc32_join(run, zlib.crc32(data[at:at + n]), n)
+        at += n
+    assert run == zlib.crc32(data)
+    # lengths no buffer here holds: associativity
+    ca, cb, cc = (rng.getrandbits(32) for _ in range(3))
+    for lb, lc in [((1 << 33) + 12345, (1 << 35) + 1), (1 << 40, (1 << 32) - 1), (5, 1 << 50)]:
+        left = L.td_crc32_join(L.td_crc32_join(ca, cb, lb), cc, lc)
+        right = L.td_crc32_join(ca, L.td_crc32_join(cb, cc, lc), lb + lc)
+        assert left == right, (lb, lc)
