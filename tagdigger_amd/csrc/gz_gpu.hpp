@@ -48,7 +48,8 @@ constexpr uint64_t NONE = ~0ull;
 // A table entry (32 bits): bits 0-3 the code's length (0: no code of this index -- E_NONE -- or a longer one -- E_SLOW);
 // bits 4-7 the number of extra bits; bits 8-23 the value: a literal's byte, a copy's base length, a distance's base;
 // F_COPY / F_END / F_BAD: a length symbol, the end-of-block symbol, a symbol DEFLATE does not define (286, 287; 30, 31)
-constexpr uint32_t E_NONE = 0u, E_SLOW = 0x10u, F_COPY = 1u << 24, F_END = 1u << 25, F_BAD = 1u << 26;
+// F_RARE: what the 64-positions-a-step decoder leaves to the scalar code -- set in E_NONE, E_SLOW and with F_BAD
+constexpr uint32_t F_COPY = 1u << 24, F_END = 1u << 25, F_BAD = 1u << 26, F_RARE = 1u << 27, E_NONE = F_RARE, E_SLOW = 0x10u | F_RARE;
 struct __attribute__((aligned(16))) WaveMem {         // one wave's tables (LDS)
     uint32_t ltab[1 << LROOT];                        // literal/length
     uint32_t dtab[1 << DROOT];                        // distance (and the code-length code while a header is read)
@@ -135,14 +136,14 @@ __device__ __forceinline__ void distance_code(uint32_t ds, uint32_t &base, uint3
 template <int KIND> __device__ __forceinline__ uint32_t entry_of(uint32_t i) {
     if (KIND == 2) return i << 8;
     if (KIND == 1) {
-        if (i > 29u) return F_BAD;
+        if (i > 29u) return F_BAD | F_RARE;
         uint32_t base, ext;
         distance_code(i, base, ext);
         return (base << 8) | (ext << 4);
     }
     if (i < 256u) return i << 8;
     if (i == 256u) return F_END;
-    if (i > 285u) return F_BAD;
+    if (i > 285u) return F_BAD | F_RARE;
     uint32_t base, ext;
     length_code(i, base, ext);
     return F_COPY | (base << 8) | (ext << 4);
@@ -338,40 +339,52 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
         }
         if ((t.w0 << 5) + cur > in_bits) return S_ERR;
         const uint32_t k0 = cur >> 5, off = cur & 31u;
-        uint32_t W[5];
-        if (__builtin_expect(k0 + 4u < 64u, 1)) {                      // (fifteen steps in sixteen: all five words in the first register)
-#pragma unroll
-            for (uint32_t i = 0; i < 5u; i++) W[i] = (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)(k0 + i));
-        } else {
-#pragma unroll
-            for (uint32_t i = 0; i < 5u; i++) {
-                const uint32_t k = k0 + i;
-                const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)(k & 63u)), c = (uint32_t)__builtin_amdgcn_readlane((int)vnext, (int)(k & 63u));
-                W[i] = k < 64u ? a : c;
-            }
-        }
-        // this lane's 64 bits from its position on
+        // this lane's 64 bits from its position on: three words of the input, the first one word (off + lane) / 32 of the step's
         const uint32_t bp = off + (uint32_t)lane, q = bp >> 5, r = bp & 31u;
-        const uint32_t lo = q == 0u ? W[0] : q == 1u ? W[1] : W[2], mid = q == 0u ? W[1] : q == 1u ? W[2] : W[3], hi = q == 0u ? W[2] : q == 1u ? W[3] : W[4];
-        uint64_t x = ((((uint64_t)mid << 32) | lo) >> r) | (((uint64_t)hi << 1) << (63u - r));
-        const uint32_t e = m.ltab[(uint32_t)x & ((1u << LROOT) - 1u)];
+        uint32_t lo, mid, hi;
+#ifdef TD_GZ_BPERM
+        if (__builtin_expect(k0 + 4u < 64u, 1)) {                      // (fifteen steps in sixteen: all of them in the first register)
+            const int a = (int)((k0 + q) << 2);
+            lo = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)vin);
+            mid = (uint32_t)__builtin_amdgcn_ds_bpermute(a + 4, (int)vin);
+            hi = (uint32_t)__builtin_amdgcn_ds_bpermute(a + 8, (int)vin);
+        } else
+#endif
+        {
+            uint32_t W[5];
+            if (__builtin_expect(k0 + 4u < 64u, 1)) {                  // (fifteen steps in sixteen: all five words in the first register)
+#pragma unroll
+                for (uint32_t i = 0; i < 5u; i++) W[i] = (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)(k0 + i));
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < 5u; i++) {
+                    const uint32_t k = k0 + i;
+                    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)(k & 63u)), c = (uint32_t)__builtin_amdgcn_readlane((int)vnext, (int)(k & 63u));
+                    W[i] = k < 64u ? a : c;
+                }
+            }
+            lo = q == 0u ? W[0] : q == 1u ? W[1] : W[2]; mid = q == 0u ? W[1] : q == 1u ? W[2] : W[3]; hi = q == 0u ? W[2] : q == 1u ? W[3] : W[4];
+        }
+        // (x1:x0, and every field out of them by one 32-bit funnel shift: the fields begin at bit 0, l1 <= 15, l1 + ext <= 20 and
+        // l1 + ext + l2 -- a copy whose distance bits would begin past bit 31 is the scalar code's; 64-bit shifts are slower)
+        const uint32_t x0 = __builtin_amdgcn_alignbit(mid, lo, r), x1 = __builtin_amdgcn_alignbit(hi, mid, r);
+        const uint32_t e = m.ltab[x0 & ((1u << LROOT) - 1u)];
         const uint32_t l1 = e & 15u, ext = (e >> 4) & 15u;
-        x >>= l1;
-        const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)x & ((1u << ext) - 1u));
-        x >>= ext;
-        const uint32_t d = m.dtab[(uint32_t)x & ((1u << DROOT) - 1u)];
+        const uint32_t len = ((e >> 8) & 0xFFFFu) + (__builtin_amdgcn_alignbit(x1, x0, l1) & ((1u << ext) - 1u));
+        const uint32_t s2 = l1 + ext;
+        const uint32_t d = m.dtab[__builtin_amdgcn_alignbit(x1, x0, s2) & ((1u << DROOT) - 1u)];
         const uint32_t l2 = d & 15u, dext = (d >> 4) & 15u;
-        x >>= l2;
-        const uint32_t dist = ((d >> 8) & 0xFFFFu) + ((uint32_t)x & ((1u << dext) - 1u));
+        const uint32_t s3 = s2 + l2;
+        const uint32_t dist = ((d >> 8) & 0xFFFFu) + (__builtin_amdgcn_alignbit(x1, x0, s3) & ((1u << dext) - 1u));
         const bool copy = (e & F_COPY) != 0;
-        // kind: 0 literal, 1 copy, 2 end code, 3 for the scalar code (a longer code, or none)
-        const bool rare = l1 == 0u || (e & F_BAD) || (copy && (l2 == 0u || (d & F_BAD)));
-        const uint32_t kind = rare ? 3u : (e & F_END) ? 2u : copy ? 1u : 0u;
+        // vinfo: the token's size in bits | 0x200 the end code | 0x800 for the scalar code (a longer code, none, or an undefined symbol)
+        uint32_t flags = ((e | (copy ? d : 0u)) >> 16) & ((F_END | F_RARE) >> 16);
+        if (copy && s3 > 31u) flags |= F_RARE >> 16;
         uint32_t vtok = copy ? 0x80000000u | (len << 15) | (dist - 1u) : (e >> 8) & 0xFFu;
-        uint32_t vinfo = (copy ? l1 + ext + l2 + dext : l1) | (kind << 8);
-        // the chain from bit 0: which lanes' tokens are real.  The common way is five scalar instructions a token: the jump to the next
+        uint32_t vinfo = (copy ? s3 + dext : s2) | flags;
+        // the chain from bit 0: which lanes' tokens are real.  The common way is six scalar instructions a token: the jump to the next
         // token's lane; an end code or a token for the scalar code jumps out of the window and is looked at behind the loop.
-        const uint32_t vjump = kind >= 2u ? 64u : (vinfo & 0xFFu);
+        const uint32_t vjump = flags ? 64u : (vinfo & 0xFFu);
         uint32_t o = 0;
         uint64_t onpath = 0;
         bool ended = false;
@@ -390,11 +403,8 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
             if (info >= 0x300u) {
                 // the scalar decoder on this one token: 64 bits from its position are enough (15 + 5 + 15 + 13)
                 if (nslow) (*nslow)++;
-                const uint32_t sb = off + o, sq = sb >> 5, sr = sb & 31u;
-                const uint32_t slo = sq == 0u ? W[0] : sq == 1u ? W[1] : W[2], smid = sq == 0u ? W[1] : sq == 1u ? W[2] : W[3],
-                               shi = sq == 0u ? W[2] : sq == 1u ? W[3] : W[4];
                 Bits sbits = t;
-                sbits.bb = ((((uint64_t)smid << 32) | slo) >> sr) | (((uint64_t)shi << 1) << (63u - sr));
+                sbits.bb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)x1, (int)o) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)x0, (int)o);      // (its lane's)
                 sbits.bc = 64u;
                 uint32_t tk = 0;
                 // (the tables through a pointer the compiler cannot see through: it had hoisted the loads of the canonical arrays -- six LDS
