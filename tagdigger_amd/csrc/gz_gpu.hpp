@@ -8,10 +8,11 @@
 //                    decoder does (option gz_gpu_verify: it also decodes the block and asks for a header behind it).
 //   2. k_gz_tokens   one wave per chunk (from one found start to the next): the Huffman decoding.  WHERE a code starts is
 //                    serial, WHAT would start at a bit is not: every lane decodes the token that would begin at its bit of the
-//                    next 64 (two table look-ups for all lanes at once: 10-bit literal/length and 8-bit distance tables of
-//                    32-bit entries, 6 KiB of LDS per wave, built by the wave's lanes), the wave follows the chain from bit 0
-//                    by lane number, the lanes that were real store their tokens.  Block headers and the rare longer codes
-//                    are read by wave-uniform scalar code; the compressed bytes sit in two registers, 64 words each.
+//                    next 64 (its three words of input by ds_bpermute, the fields by 32-bit funnel shifts, two table look-ups
+//                    for all lanes at once: 10-bit literal/length and 8-bit distance tables of 32-bit entries, 6 KiB of LDS
+//                    per wave, built by the wave's lanes), the wave follows the chain from bit 0 by lane number (six scalar
+//                    instructions a token), the lanes that were real store their tokens.  Block headers and the rare
+//                    longer codes are read by wave-uniform scalar code; the compressed bytes sit in registers, 64 words each.
 //                    Output: TOKENS (a literal, or length + distance) -- the decoder never reads what it has decoded, so no
 //                    memory latency sits in its loop.  A chunk ends at the first block boundary at or past its successor's
 //                    start.
@@ -32,8 +33,10 @@
 // members, a chunk that does not chain, tables zlib would refuse, an overflowing token buffer -- sends the file to the host
 // decoder (count_gzip_dev) before anything has been counted; later, and for a failed CRC or length check, to the reference's
 // reading rules (gz_pyrules.hpp).
-// Measured (16 M reads, 662 MB of gzip, 427 M tokens of which 0.7 % need the scalar code): upload 14 ms, k_gz_find 8,
-// k_gz_tokens 43, k_gz_lz 24, windows 2, k_gz_resolve 3, k_gz_crc 6: 105 ms, 152 M reads/s (16 host threads: 79 M).
+// Measured (16 M reads, 662 MB of gzip, 427 M tokens of which 0.7 % need the scalar code): upload 13 ms, k_gz_find 7.4,
+// k_gz_tokens 17.8, k_gz_lz 20.3, windows 2, k_gz_resolve 3, k_gz_crc 6: 72 ms, 222 M reads/s (16 host threads: 75-79 M).
+// The decoder is bound by the instructions it issues (five waves a SIMD, no memory wait in its loop): what made it faster
+// was fewer of them -- DESIGN 5. has the steps from 122 ms.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -342,26 +345,20 @@ __device__ __forceinline__ uint32_t decode_block(const Bits &rd, uint64_t &pos, 
         // this lane's 64 bits from its position on: three words of the input, the first one word (off + lane) / 32 of the step's
         const uint32_t bp = off + (uint32_t)lane, q = bp >> 5, r = bp & 31u;
         uint32_t lo, mid, hi;
-#ifdef TD_GZ_BPERM
-        if (__builtin_expect(k0 + 4u < 64u, 1)) {                      // (fifteen steps in sixteen: all of them in the first register)
+        if (__builtin_expect(k0 + 4u < 64u, 1)) {
+            // fifteen steps in sixteen all of them lie in the first register: three ds_bpermute (a lane each its own index) -- the five
+            // words by readlane into scalar registers and six selects a lane were a fifth of the step's vector instructions
             const int a = (int)((k0 + q) << 2);
             lo = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)vin);
             mid = (uint32_t)__builtin_amdgcn_ds_bpermute(a + 4, (int)vin);
             hi = (uint32_t)__builtin_amdgcn_ds_bpermute(a + 8, (int)vin);
-        } else
-#endif
-        {
+        } else {
             uint32_t W[5];
-            if (__builtin_expect(k0 + 4u < 64u, 1)) {                  // (fifteen steps in sixteen: all five words in the first register)
 #pragma unroll
-                for (uint32_t i = 0; i < 5u; i++) W[i] = (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)(k0 + i));
-            } else {
-#pragma unroll
-                for (uint32_t i = 0; i < 5u; i++) {
-                    const uint32_t k = k0 + i;
-                    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)(k & 63u)), c = (uint32_t)__builtin_amdgcn_readlane((int)vnext, (int)(k & 63u));
-                    W[i] = k < 64u ? a : c;
-                }
+            for (uint32_t i = 0; i < 5u; i++) {
+                const uint32_t k = k0 + i;
+                const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)vin, (int)(k & 63u)), c = (uint32_t)__builtin_amdgcn_readlane((int)vnext, (int)(k & 63u));
+                W[i] = k < 64u ? a : c;
             }
             lo = q == 0u ? W[0] : q == 1u ? W[1] : W[2]; mid = q == 0u ? W[1] : q == 1u ? W[2] : W[3]; hi = q == 0u ? W[2] : q == 1u ? W[3] : W[4];
         }
@@ -649,15 +646,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_lz(const uint32_t *tok, const
         const int64_t src = pos - (int64_t)dist;
         const uint32_t need = L < dist ? L : dist;
         bool pending = match;
-        wave_mem_fence();
+        // everything in front of F is in place: in the first round what the groups before have written -- the copies that read only
+        // that go with the literals, one wait for both --, then everything in front of the first copy still pending
+        int64_t F = base;
         for (;;) {
-            const uint64_t pm = __ballot(pending);
-            if (!pm) break;
-            // everything in front of the first pending copy's destination is in place
-            const int first = (int)__builtin_ctzll(pm);
-            const uint32_t flo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)pos, first);
-            const uint32_t fhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)pos >> 32), first);
-            const int64_t F = (int64_t)(((uint64_t)fhi << 32) | flo);
             const bool ready = pending && src + (int64_t)need <= F;
             // long copies (48 symbols and more, source and destination apart) by the whole wave: four symbols a lane, up to four
             // copies' loads in flight before their stores -- one lane alone takes a memory round trip per sixteen symbols
@@ -739,6 +731,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gz_lz(const uint32_t *tok, const
             }
             wave_mem_fence();
             pending = pending && !ready;
+            const uint64_t pm = __ballot(pending);
+            if (!pm) break;
+            const int first = (int)__builtin_ctzll(pm);
+            const uint32_t flo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)pos, first);
+            const uint32_t fhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)pos >> 32), first);
+            F = (int64_t)(((uint64_t)fhi << 32) | flo);
         }
         base += total;
     }
